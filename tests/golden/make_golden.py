@@ -1,0 +1,324 @@
+"""Generate tests/golden/* from the REFERENCE's own classes (run in the build container only: needs /root/reference).
+
+    python tests/golden/make_golden.py
+
+What is produced (all tiny seeded configs, fp32, attn_implementation='sdpa'):
+  cfg{A,B}_weights.npz   the reference model's parameters (checkpoint names) + the config as json
+  cfg{A,B}_ops.npz       per-stage vectors from the reference model: tower / connector / pooling (bilinear, average,
+                         max) / visual_embed, and a 6-step LLM sequence (first step with prompt, frame step, query
+                         step, frame step, decode step, 2-frame chunk) with logits + head logits + final hidden state
+  cfgA_streams.json      whole-stream runs of the reference's LiveInferForBenchmark.inference() (test/inference.py:276-313)
+                         for every threshold mode x remove_assistant_turns x repetition_penalty: per-frame scores,
+                         response list (token ids + text), final KV length, penalty list
+  templates.json         renders of the reference chat template (models/tokenization_live.py:34-63)
+  preprocess.npz         uint8 frames and the image_processor output for R == size and R != size
+The fixtures are data only (inputs + expected outputs); no reference source is stored.
+"""
+import os, sys, json, copy, collections
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE); sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import ref_harness as R
+
+CFG = {
+    'A': dict(llm=dict(vocab_size=512, hidden_size=64, intermediate_size=160, num_hidden_layers=2, num_attention_heads=4,
+                       num_key_value_heads=2, max_position_embeddings=4096, rope_theta=1e6, rms_norm_eps=1e-6,
+                       tie_word_embeddings=False, frame_num_tokens=4, video_pooling_stride=2, frame_resolution=56,
+                       v_placeholder='<image>', mm_spatial_pool_mode='bilinear'),
+              vit=dict(hidden_size=48, intermediate_size=80, num_hidden_layers=3, num_attention_heads=2, image_size=56, patch_size=14)),
+    'B': dict(llm=dict(vocab_size=320, hidden_size=128, intermediate_size=192, num_hidden_layers=3, num_attention_heads=4,
+                       num_key_value_heads=1, max_position_embeddings=4096, rope_theta=1e4, rms_norm_eps=1e-5,
+                       tie_word_embeddings=False, frame_num_tokens=9, video_pooling_stride=2, frame_resolution=70,
+                       v_placeholder='<image>', mm_spatial_pool_mode='bilinear'),
+              vit=dict(hidden_size=64, intermediate_size=96, num_hidden_layers=2, num_attention_heads=4, image_size=70, patch_size=14)),
+}
+
+
+def set_vit(v):
+    for k, val in v.items():
+        setattr(R.TinyVisionCfg, k, val)
+
+
+def build(name, seed):
+    c = CFG[name]
+    set_vit(c['vit'])
+    return R.build_reference_model(dict(c['llm']), dtype=torch.float32, seed=seed)
+
+
+def flat_config(name):
+    c = CFG[name]
+    l, v = c['llm'], c['vit']
+    return dict(vocab_size=l['vocab_size'], hidden_size=l['hidden_size'], intermediate_size=l['intermediate_size'],
+                num_hidden_layers=l['num_hidden_layers'], num_attention_heads=l['num_attention_heads'],
+                num_key_value_heads=l['num_key_value_heads'], rope_theta=l['rope_theta'], rms_norm_eps=l['rms_norm_eps'],
+                vit_hidden_size=v['hidden_size'], vit_intermediate_size=v['intermediate_size'],
+                vit_layers=v['num_hidden_layers'] - 1, vit_heads=v['num_attention_heads'], vit_image_size=v['image_size'],
+                vit_patch_size=v['patch_size'], video_pooling_stride=l['video_pooling_stride'],
+                mm_spatial_pool_mode=l['mm_spatial_pool_mode'], frame_num_tokens=l['frame_num_tokens'],
+                frame_resolution=l['frame_resolution'])
+
+
+def dump_weights(name, model):
+    from oracle.duet_oracle import weights_from_reference_state_dict
+    w = weights_from_reference_state_dict(model.state_dict())
+    arrs = {k: v.numpy() for k, v in w.items()}
+    arrs['__config__'] = np.frombuffer(json.dumps(flat_config(name)).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, f'cfg{name}_weights.npz'), **arrs)
+
+
+@torch.no_grad()
+def dump_ops(name, model, seed):
+    g = torch.Generator().manual_seed(seed)
+    c = CFG[name]
+    H = c['llm']['hidden_size']; V = c['llm']['vocab_size']; img = c['vit']['image_size']; nt = c['llm']['frame_num_tokens']
+    out = {}
+    px = torch.randn(3, 3, img, img, generator=g)
+    out['pixel_values'] = px
+    tower = model.vision_encode(model.vision_encoder, px)                      # video_head_live_llava_qwen.py:96
+    out['tower'] = tower
+    proj = model.connector(tower)                                              # :90
+    out['connector'] = proj
+    for mode in ('bilinear', 'average', 'max'):
+        model.config.mm_spatial_pool_mode = mode
+        out['pool_' + mode] = model.post_projector_pooling(proj)               # :100-119
+    model.config.mm_spatial_pool_mode = c['llm']['mm_spatial_pool_mode']
+    ve = model.visual_embed(px)                                                # modeling_live.py:26-33
+    out['visual_embed'] = ve
+    frames = ve.split(nt)
+    emb = model.get_input_embeddings()
+    ids0 = torch.randint(0, V, (1, 10), generator=g); idsq = torch.randint(0, V, (1, 7), generator=g)
+    idd = torch.randint(0, V, (1, 1), generator=g)
+    out['ids0'], out['idsq'], out['idd'] = ids0, idsq, idd
+    steps = [torch.cat([emb(ids0), frames[0][None]], 1), frames[1][None], emb(idsq), frames[2][None], emb(idd),
+             torch.cat([frames[0][None], frames[2][None]], 1)]
+    cache = None
+    for i, x in enumerate(steps):
+        o = model(inputs_embeds=x, past_key_values=cache, use_cache=True, return_dict=True, output_hidden_states=False)
+        cache = o.past_key_values
+        out[f'step{i}_in'] = x[0]
+        out[f'step{i}_logits'] = o.logits[0]
+        out[f'step{i}_inf'] = o.informative_logits[0]
+        out[f'step{i}_rel'] = o.relevance_logits[0]
+        out[f'step{i}_kvlen'] = torch.tensor(cache.get_seq_length())
+    # long-context continuation (exercises split-KV attention): 150 + 130 text tokens then a frame step
+    for j, n in enumerate((150, 130)):
+        idl = torch.randint(0, V, (1, n), generator=g)
+        out[f'long{j}_ids'] = idl
+        o = model(inputs_embeds=emb(idl), past_key_values=cache, use_cache=True, return_dict=True)
+        cache = o.past_key_values
+        out[f'long{j}_logits_last'] = o.logits[0, -1]
+        out[f'long{j}_inf'] = o.informative_logits[0]
+    o = model(inputs_embeds=frames[1][None], past_key_values=cache, use_cache=True, return_dict=True)
+    out['long2_logits_last'] = o.logits[0, -1]; out['long2_inf'] = o.informative_logits[0]; out['long2_rel'] = o.relevance_logits[0]
+    out['long2_kvlen'] = torch.tensor(o.past_key_values.get_seq_length())
+    # joint_embed (modeling_live.py:35-48): ids with placeholders + frames
+    vid = V - 1
+    model.config.v_placeholder_id = vid
+    jid = torch.randint(0, V - 1, (1, 6 + 2 * nt), generator=g)
+    jid[0, 3:3 + 2 * nt] = vid
+    out['joint_ids'] = jid
+    out['joint_embed'] = model.joint_embed(jid, px[:2])[0]
+    out['v_placeholder_id'] = torch.tensor(vid)
+    np.savez_compressed(os.path.join(HERE, f'cfg{name}_ops.npz'), **{k: v.numpy() for k, v in out.items()})
+
+
+class RefTokenizer:
+    """The byte-level stand-in tokenizer carrying the REFERENCE chat template; returns plain tensors like transformers 4.44."""
+    def __init__(self, tok, template):
+        self.tok = tok; self.template = template
+        self.bos_token, self.eos_token = tok.bos_token, tok.eos_token
+    def apply_chat_template(self, msgs, return_tensors=None, tokenize=True, **flags):
+        saved = self.tok.chat_template
+        self.tok.chat_template = self.template
+        try:
+            if not tokenize:
+                return self.tok.apply_chat_template(msgs, tokenize=False, **flags)
+            return self.tok.apply_chat_template(msgs, return_tensors='pt', return_dict=False, **flags)
+        finally:
+            self.tok.chat_template = saved
+    def decode(self, ids, **kw):
+        kw.pop('clean_up_tokenization_spaces', None)
+        return self.tok.decode(ids, clean_up_tokenization_spaces=False, **kw)
+
+
+def make_ref_driver(model, tokenizer, *, eos_token_id, max_new, system_prompt, frame_fps, opts):
+    """Build the reference's LiveInferForBenchmark without its __init__ (which needs from_pretrained): the attribute
+    block of test/inference.py:27-64 is re-done by hand around our random tiny model."""
+    import test.inference as TI
+    d = object.__new__(TI.LiveInferForBenchmark)
+    d.torch_dtype = torch.float32
+    d.model, d.tokenizer = model, tokenizer
+    d.image_processor = model.get_vision_tower().image_processor
+    d.hidden_size = model.config.hidden_size
+    d.set_fps(frame_fps)
+    d.frame_resolution = model.config.frame_resolution
+    d.frame_num_tokens = model.config.frame_num_tokens
+    d.frame_v_placeholder = model.config.v_placeholder * d.frame_num_tokens
+    d.system_prompt = system_prompt
+    d.inplace_output_ids = torch.zeros(1, max_new, dtype=torch.long)
+    d.stream_end_prob_threshold = opts.get('stream_end_prob_threshold')
+    d.response_min_interval_frames = None
+    d.threshold_z = None
+    d.first_n_frames_no_generate = 0
+    d.running_list_length = opts.get('running_list_length', 20)
+    d.stream_end_score_sum_threshold = opts.get('stream_end_score_sum_threshold')
+    d.score_heads = opts.get('score_heads', 'informative_score').split(',')
+    d.consecutive_n_frames_threshold = 1
+    d.remove_assistant_turns = opts.get('remove_assistant_turns', False)
+    d.eos_token_id = eos_token_id
+    d._start_ids = tokenizer.apply_chat_template([{'role': 'system', 'content': system_prompt}], return_tensors='pt')
+    d._added_stream_prompt_ids = tokenizer.apply_chat_template([{}], add_stream_prompt=True, return_tensors='pt')
+    d._added_stream_generation_ids = tokenizer.apply_chat_template([{}], add_stream_generation_prompt=True, return_tensors='pt')
+    d.repetition_penalty = opts.get('repetition_penalty')
+    with R.CudaToCpu():
+        d.reset()
+    return d
+
+
+STREAM_CASES = [
+    # name, frames R, T, fps, conversation, driver opts
+    ('grounding_q0', 56, 10, 1.0, [{'role': 'user', 'content': 'what?', 'time': 0.0}],
+     dict(stream_end_prob_threshold=2.0, score_heads='informative_score,relevance_score')),
+    ('grounding_noquery_resize', 48, 6, 2.0, [], dict(stream_end_prob_threshold=1.0)),
+    ('prob_keep', 56, 12, 1.0, [{'role': 'user', 'content': 'Describe it.', 'time': 2.5}],
+     dict(stream_end_prob_threshold='Q60', score_heads='informative_score')),
+    ('prob_keep_pen', 56, 12, 1.0, [{'role': 'user', 'content': 'Describe it.', 'time': 0.0}],
+     dict(stream_end_prob_threshold='Q60', score_heads='informative_score', repetition_penalty=1.15)),
+    ('sum_remove_pen', 56, 14, 2.0, [{'role': 'user', 'content': 'Narrate.', 'time': 1.0}, {'role': 'user', 'content': 'And now?', 'time': 4.0}],
+     dict(stream_end_score_sum_threshold=2.0, score_heads='informative_score,relevance_score', remove_assistant_turns=True, repetition_penalty=1.15)),
+    ('sum_remove', 56, 12, 1.0, [{'role': 'user', 'content': 'Narrate.', 'time': 0.0}],
+     dict(stream_end_score_sum_threshold=1.6, score_heads='informative_score', remove_assistant_turns=True, running_list_length=3)),
+]
+
+
+@torch.no_grad()
+def dump_streams(model, seed):
+    import test.inference as TI
+    from models.tokenization_live import chat_template_llava, get_stream_placeholder_jinja2
+    from mmduet_amd.tokenization_live import build_byte_level_tokenizer
+    tok = build_byte_level_tokenizer()
+    tok.add_special_tokens({'additional_special_tokens': ['<image>']})
+    tok.bos_token, tok.eos_token = '<|im_start|>', '<|im_end|>'
+    rtok = RefTokenizer(tok, chat_template_llava(tok, get_stream_placeholder_jinja2(model.config)))
+
+    # documented (transformers 4.44.2) cache semantic for remove_assistant_turns: the handle held by the driver must
+    # still denote the pre-generation context after fast_greedy_generate (SURVEY.md §8c TRAP) -> deep-copy shim.
+    orig_fgg = TI.fast_greedy_generate
+    def fgg(*, past_key_values, **kw):
+        return orig_fgg(past_key_values=copy.deepcopy(past_key_values), **kw)
+    TI.fast_greedy_generate = fgg
+
+    system_prompt = 'A tiny assistant.'
+    g = torch.Generator().manual_seed(seed)
+    results = {'system_prompt': system_prompt, 'cases': {}}
+
+    # choose an eos id the random model actually emits so that responses have different lengths
+    probe_frames = torch.randint(0, 256, (12, 3, 56, 56), dtype=torch.uint8, generator=torch.Generator().manual_seed(seed + 1))
+    d = make_ref_driver(model, rtok, eos_token_id=-1, max_new=12, system_prompt=system_prompt, frame_fps=1.0,
+                        opts=dict(stream_end_prob_threshold=0.0))
+    with R.CudaToCpu():
+        d.input_video_stream(probe_frames); d.input_query_stream([]); resp = d.inference()
+    # take the most common 3rd..6th generated token as "eos"
+    cnt = collections.Counter()
+    d2_ids = []
+    d = make_ref_driver(model, rtok, eos_token_id=-1, max_new=12, system_prompt=system_prompt, frame_fps=1.0,
+                        opts=dict(stream_end_prob_threshold=0.0, repetition_penalty=1.0))   # penalty 1.0 just records ids
+    with R.CudaToCpu():
+        d.input_video_stream(probe_frames); d.input_query_stream([]); d.inference()
+    ids = d.generated_token_ids
+    for i in range(0, len(ids), 12):
+        for t in ids[i + 2:i + 7]:
+            cnt[t] += 1
+    eos_id = cnt.most_common(1)[0][0]
+    results['eos_token_id'] = int(eos_id)
+    print('chosen eos id', eos_id, cnt.most_common(3))
+
+    for name, Rr, T, fps, conv, opts in STREAM_CASES:
+        frames = torch.randint(0, 256, (T, 3, Rr, Rr), dtype=torch.uint8, generator=g)
+        opts = dict(opts)
+        if opts.get('stream_end_prob_threshold') == 'Q60':
+            # calibrate the threshold at the 60th percentile of a grounding pass so that some frames respond
+            dd = make_ref_driver(model, rtok, eos_token_id=eos_id, max_new=12, system_prompt=system_prompt, frame_fps=fps,
+                                 opts=dict(stream_end_prob_threshold=1.0))
+            with R.CudaToCpu():
+                dd.input_video_stream(frames); dd.input_query_stream(conv); dd.inference()
+            sc = sorted(x['informative_score'] for x in dd.debug_data_list)
+            opts['stream_end_prob_threshold'] = float(round(sc[int(0.6 * len(sc))] - 1e-4, 4))
+        d = make_ref_driver(model, rtok, eos_token_id=eos_id, max_new=12, system_prompt=system_prompt, frame_fps=fps, opts=opts)
+        gen_log = []
+        def fgg_log(*, past_key_values, **kw):
+            o = orig_fgg(past_key_values=copy.deepcopy(past_key_values), **kw)
+            gen_log.append(o[0][0].tolist())
+            return o
+        TI.fast_greedy_generate = fgg_log
+        with R.CudaToCpu():
+            d.input_video_stream(frames)
+            d.input_query_stream(conv)
+            responses = d.inference()
+        TI.fast_greedy_generate = fgg
+        results['cases'][name] = dict(
+            frames_seed_order=len(results['cases']), R=Rr, T=T, fps=fps, conversation=conv, opts=opts,
+            frames=None, debug_data=d.debug_data_list, responses=responses, generated=gen_log,
+            final_kv_len=int(d.past_key_values.get_seq_length()), penalty_ids=[int(x) for x in d.generated_token_ids],
+            n_responses=len(gen_log))
+        np.save(os.path.join(HERE, f'stream_{name}_frames.npy'), frames.numpy())
+        print(name, 'responses', len(gen_log), 'kv', results['cases'][name]['final_kv_len'],
+              [len(x) for x in gen_log])
+    TI.fast_greedy_generate = orig_fgg
+    json.dump(results, open(os.path.join(HERE, 'cfgA_streams.json'), 'w'), indent=1)
+
+
+def dump_templates():
+    from models.tokenization_live import chat_template_llava, get_stream_placeholder_jinja2
+    from mmduet_amd.tokenization_live import build_byte_level_tokenizer
+    from types import SimpleNamespace
+    tok = build_byte_level_tokenizer(); tok.add_special_tokens({'additional_special_tokens': ['<image>']})
+    tok.bos_token, tok.eos_token = '<|im_start|>', '<|im_end|>'
+    cfg = SimpleNamespace(frame_num_tokens=3, v_placeholder='<image>')
+    tok.chat_template = chat_template_llava(tok, get_stream_placeholder_jinja2(cfg))
+    chat = [{'role': 'system', 'content': 'System message 1.'}, {'role': 'stream', 'num_frames': 2},
+            {'role': 'user', 'content': 'User message 1?'}, {'role': 'assistant', 'content': 'Assistant message 1.', 'learn': True},
+            {'role': 'stream', 'num_frames': 3}, {'role': 'assistant', 'content': 'Assistant message 2.', 'learn': True},
+            {'role': 'user', 'content': 'User message 2?'}, {'role': 'stream', 'num_frames': 0},
+            {'role': 'stream', 'num_frames': 4}, {'role': 'assistant', 'content': 'Assistant message 3.', 'learn': True}]
+    cases = [(chat, {}), (chat, dict(add_generation_prompt=True)), (chat[1:], dict(add_stream_prompt=True)),
+             ([{}], dict(add_stream_prompt=True)), ([{}], dict(add_stream_generation_prompt=True)),
+             ([{'role': 'user', 'content': 'q?'}], dict(add_stream_query_prompt=True, add_stream_prompt=True)),
+             ([{'role': 'user', 'content': 'q?'}], dict(add_stream_query_prompt=False, add_stream_prompt=True)),
+             ([{'role': 'system', 'content': 'S'}], {}), (chat[2:4], dict(add_generation_prompt=True, add_stream_prompt=True))]
+    out = []
+    for msgs, fl in cases:
+        out.append(dict(messages=msgs, flags=fl, text=tok.apply_chat_template(msgs, tokenize=False, **fl),
+                        ids=tok.apply_chat_template(msgs, return_tensors='pt', return_dict=False, **fl)[0].tolist()))
+    json.dump(dict(frame_num_tokens=3, v_placeholder='<image>', cases=out), open(os.path.join(HERE, 'templates.json'), 'w'), indent=1)
+
+
+def dump_preprocess():
+    """image_processor.preprocess (test/inference.py:203) for R == size, R != size, and the BASELINE 336 -> 384 case
+    (for the last one only the resized uint8 image is stored; normalisation is covered by the small cases)."""
+    R.install()
+    g = torch.Generator().manual_seed(7)
+    out = {}
+    for tag, Rr, size in (('same', 56, 56), ('up', 48, 56), ('down', 70, 56)):
+        fr = torch.randint(0, 256, (2, 3, Rr, Rr), dtype=torch.uint8, generator=g)
+        out[f'{tag}_frames'] = fr.numpy()
+        out[f'{tag}_pixel_values'] = R.SigLipImageProcessor(size).preprocess(fr, return_tensors='pt')['pixel_values'].numpy()
+    fr = torch.randint(0, 256, (1, 3, 336, 336), dtype=torch.uint8, generator=g)
+    pv = R.SigLipImageProcessor(384).preprocess(fr, return_tensors='pt')['pixel_values']
+    out['up336_frames'] = fr.numpy()
+    out['up336_resized_u8'] = torch.round((pv * 0.5 + 0.5) * 255).to(torch.uint8).numpy()
+    np.savez_compressed(os.path.join(HERE, 'preprocess.npz'), **out)
+
+
+if __name__ == '__main__':
+    torch.set_num_threads(4)
+    mA = build('A', seed=0); dump_weights('A', mA); dump_ops('A', mA, seed=100)
+    mB = build('B', seed=1); dump_weights('B', mB); dump_ops('B', mB, seed=101)
+    dump_templates()
+    set_vit(CFG['A']['vit'])
+    mA = build('A', seed=0)
+    dump_streams(mA, seed=200)
+    dump_preprocess()
+    print('done')
