@@ -1,0 +1,156 @@
+/*
+ * mmduet.h -- C ABI of libmmduet_hip.so: the MI355X-native (gfx950) streaming video-text-duet forward path.
+ *
+ * The reference (yellow-binary-tree/MMDuet) has no native/FFI interface of its own: its drop-in boundary is the
+ * Python duck-type the stream driver uses.  This header is the native layer underneath that
+ * Python surface; every entry point names the reference interface it stands in for (paths relative to the reference
+ * repository root).  The Python shim that binds it with ctypes is mmduet_amd/_lib.py.
+ *
+ * Conventions
+ *   - all functions return 0 on success or a negative MMD_E* code; mmd_last_error() gives the message.
+ *     No C++ exception crosses the ABI.
+ *   - pointers are DEVICE pointers unless the parameter is documented as host.
+ *   - one hipStream_t per context (mmd_set_stream); calls on one context are not thread-safe -- the Python layer
+ *     holds a per-model mutex (the reference's Gradio demo calls the model from two threads, demo/app.py:84-85).
+ *   - activation / weight element type is chosen per context (mmd_config.dtype): MMD_BF16 (production) or MMD_F32
+ *     (bit-for-bit-class parity runs against the fp32 oracle).  Logit outputs are always fp32, like the reference's
+ *     `.float()` (models/live_llava/video_head_live_llava_qwen.py:155,160-161).
+ */
+#ifndef MMDUET_H
+#define MMDUET_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMD_OK 0
+#define MMD_EINVAL (-22)
+#define MMD_ENOMEM (-12)
+#define MMD_ENOENT (-2)
+#define MMD_ERANGE (-34)
+#define MMD_EHIP (-5)
+
+typedef enum { MMD_F32 = 0, MMD_BF16 = 1 } mmd_dtype;
+typedef enum { MMD_POOL_BILINEAR = 0, MMD_POOL_AVERAGE = 1, MMD_POOL_MAX = 2 } mmd_pool_mode;
+
+/* Shape of the model.  Mirrors the fields of VideoHeadLiveLlavaQwenConfig (models/live_llava/video_head_live_llava_qwen.py:41-45,
+ * models/configuration_live.py:22-36) plus the SigLIP tower shape LLaVA-NeXT hard-codes. */
+typedef struct mmd_config {
+    int32_t struct_size;          /* = sizeof(mmd_config), ABI guard */
+    int32_t dtype;                /* mmd_dtype of weights and activations */
+    /* Qwen2 decoder */
+    int32_t vocab_size, hidden_size, intermediate_size, num_layers, num_heads, num_kv_heads, head_dim;
+    float rope_theta, rms_norm_eps;
+    /* SigLIP tower (vit_layers = layers that RUN) */
+    int32_t vit_hidden, vit_intermediate, vit_layers, vit_heads, vit_image, vit_patch;
+    float vit_ln_eps;
+    int32_t vit_post_layernorm;
+    /* connector / pooling (models/live_llava/video_head_live_llava_qwen.py:100-119) */
+    int32_t pool_mode, pool_stride, frame_num_tokens;
+    /* workspace sizing */
+    int32_t max_vit_batch;        /* frames per mmd_vit_encode call (reference: 32, test/inference.py:208) */
+    int32_t max_step_tokens;      /* max rows of one mmd_llm_step call */
+} mmd_config;
+
+typedef struct mmd_ctx mmd_ctx;
+typedef struct mmd_stream mmd_stream;
+
+/* ---- context ------------------------------------------------------------------------------------------------ */
+/* replaces model construction in build_live (models/modeling_live.py:80-129) */
+int mmd_create(const mmd_config* cfg, int device, mmd_ctx** out);
+void mmd_destroy(mmd_ctx* ctx);
+const char* mmd_last_error(const mmd_ctx* ctx);          /* ctx may be NULL: error of the last failed mmd_create */
+int mmd_set_stream(mmd_ctx* ctx, void* hip_stream);      /* hipStream_t; NULL = the context's own stream */
+void* mmd_get_stream(mmd_ctx* ctx);
+int mmd_synchronize(mmd_ctx* ctx);
+
+/* ---- weights -------------------------------------------------------------------------------------------------- */
+/* replaces from_pretrained weight materialisation (models/modeling_live.py:96-99).  `name` is the checkpoint name
+ * (e.g. "model.layers.3.self_attn.q_proj.weight"); data is row-major in `src_dtype`; on_device != 0 if `data` is a
+ * device pointer.  Tensors are converted to the context dtype.  LoRA deltas (models/modeling_live.py:123, peft
+ * y = Wx + (alpha/r) B(Ax)) are merged with mmd_merge_lora before mmd_finalize_weights. */
+int mmd_load_tensor(mmd_ctx* ctx, const char* name, const void* data, int src_dtype, const int64_t* shape, int rank,
+                    int on_device);
+int mmd_merge_lora(mmd_ctx* ctx, const char* weight_name, const float* A_host, const float* B_host, int r, float scale);
+/* RoPE inverse frequencies theta^(-2i/d), i < head_dim/2 (host fp32).  Optional: the default table is computed in
+ * double precision; the Python shim passes the table torch computes with the reference's own expression
+ * (transformers qwen2/modeling_qwen2.py:84-85) so that fp32 parity at large positions does not hinge on pow() ulps. */
+int mmd_set_rope_inv_freq(mmd_ctx* ctx, const float* inv_freq_host, int n);
+int mmd_finalize_weights(mmd_ctx* ctx);                  /* builds fused layouts; fails listing the first missing tensor */
+int64_t mmd_weight_bytes(const mmd_ctx* ctx);
+
+/* ---- vision side ---------------------------------------------------------------------------------------------- */
+/* replaces LiveMixin.visual_embed (models/modeling_live.py:26-33): tower -> connector -> pooling.
+ * pixel_values [B,3,img,img] in ctx dtype; out [B*frame_num_tokens, hidden] in ctx dtype. */
+int mmd_vit_encode(mmd_ctx* ctx, const void* pixel_values, int B, void* out);
+/* intermediate taps for parity tests: stage 0 = tower output [B*tokens, vit_hidden], 1 = connector output
+ * [B*tokens, hidden]; valid until the next mmd_vit_encode. */
+int mmd_vit_debug_tap(mmd_ctx* ctx, int stage, void* out, int64_t out_elems);
+/* replaces image_processor.preprocess (test/inference.py:203; LLaVA SigLipImageProcessor): uint8 [T,3,R,R] ->
+ * PIL-bicubic resize to img x img (bit-exact with Pillow's 8-bit resampler), x/255, (x-.5)/.5 -> ctx dtype. */
+int mmd_preprocess_frames(mmd_ctx* ctx, const uint8_t* frames, int T, int R, void* pixel_values);
+
+/* ---- language side -------------------------------------------------------------------------------------------- */
+/* replaces model.get_input_embeddings()(ids) (test/inference.py:236,251,259; models/modeling_live.py:76). ids: device int64 */
+int mmd_embed_tokens(mmd_ctx* ctx, const int64_t* ids, int k, void* out);
+
+/* KV arena of one video stream; replaces the DynamicCache / legacy tuple cache handed around as `past_key_values`
+ * (test/inference.py:183,239-240).  O(1) append and O(1) truncate; grows by reallocation beyond `initial_tokens`. */
+int mmd_stream_create(mmd_ctx* ctx, int64_t initial_tokens, mmd_stream** out);
+void mmd_stream_destroy(mmd_stream* s);
+int64_t mmd_kv_len(const mmd_stream* s);
+int64_t mmd_kv_capacity(const mmd_stream* s);
+int mmd_kv_truncate(mmd_stream* s, int64_t new_len);     /* rollback: remove_assistant_turns (test/inference.py:265-269), speculative chunks */
+
+/* replaces VideoHeadLiveLlavaQwenForCausalLM.forward body (models/live_llava/video_head_live_llava_qwen.py:141) ==
+ * Qwen2Model.forward for batch 1: embeds [S, hidden] are appended at positions kv_len..kv_len+S-1; hidden_out
+ * [S, hidden] receives the post-final-RMSNorm hidden state (may be NULL). */
+int mmd_llm_step(mmd_ctx* ctx, mmd_stream* s, const void* embeds, int S, void* hidden_out);
+/* informative_head / relevance_head (models/live_llava/video_head_live_llava_qwen.py:160-161): hidden rows [M, hidden] ->
+ * out [M,4] fp32 = (informative[0], informative[1], relevance[0], relevance[1]). */
+int mmd_video_heads(mmd_ctx* ctx, const void* hidden, int M, float* out);
+/* lm_head (models/live_llava/video_head_live_llava_qwen.py:155): hidden rows [M, hidden] -> logits [M, vocab] fp32 */
+int mmd_lm_head(mmd_ctx* ctx, const void* hidden, int M, float* logits);
+/* one fused per-frame step for the streaming loop (test/inference.py:239-244): llm_step + heads at the rows listed in
+ * head_rows (host int32[n_rows], e.g. the last token of every frame in a chunk); scores_out host fp32 [n_rows,4]
+ * (synchronises the stream). */
+int mmd_frame_step(mmd_ctx* ctx, mmd_stream* s, const void* embeds, int S, const int32_t* head_rows_host, int n_rows,
+                   float* head_logits_host);
+/* replaces fast_greedy_generate (models/modeling_live.py:51-77): feeds prompt_embeds [S,hidden], then up to max_new
+ * greedy steps.  prev_ids_host / n_prev: the repetition-penalty list persisted across turns (grown in place, capacity
+ * prev_cap); rep_penalty <= 0 disables the penalty (and the list is not updated, like the reference).  EOS is written
+ * to out_ids but neither fed back nor added to the list.  out_ids_host int64[max_new]; n_out = tokens written. */
+int mmd_greedy_generate(mmd_ctx* ctx, mmd_stream* s, const void* prompt_embeds, int S, int64_t eos_id, float rep_penalty,
+                        int64_t* prev_ids_host, int* n_prev, int prev_cap, int64_t* out_ids_host, int max_new, int* n_out);
+
+/* ---- measurement ---------------------------------------------------------------------------------------------- */
+/* HIP-event timing of kernel classes on the context's stream (bench.py `roofline`).  While enabled every launch of a
+ * class is bracketed by events; mmd_prof_read returns accumulated ms and launch counts. */
+enum { MMD_K_GEMM_SKINNY = 0, MMD_K_GEMM_TILE = 1, MMD_K_ATTN_LLM = 2, MMD_K_ATTN_VIT = 3, MMD_K_NORM_ROPE = 4,
+       MMD_K_OTHER = 5, MMD_K_COUNT = 6 };
+int mmd_prof_enable(mmd_ctx* ctx, int on);
+int mmd_prof_read(mmd_ctx* ctx, double* ms_out /*[MMD_K_COUNT]*/, int64_t* launches_out /*[MMD_K_COUNT]*/,
+                  double* bytes_out /*[MMD_K_COUNT] algorithmic bytes*/, double* flops_out /*[MMD_K_COUNT]*/);
+int mmd_prof_reset(mmd_ctx* ctx);
+
+/* ---- raw operator entry points (parity tests call the kernels through these) ------------------------------------ */
+/* Y[M,N] = epilogue(X[M,K] . W[N,K]^T + bias).  epi: 0 none, 1 gelu(tanh), 2 gelu(erf), 3 add residual R[M,N],
+ * 4 SwiGLU (W rows interleaved gate/up in blocks of 16 -> Y[M,N/2]).  out_f32 != 0 writes fp32. variant: 0 auto,
+ * 1 generic tile, 2 skinny/split-K, 3 large tile. */
+int mmd_op_gemm(mmd_ctx* ctx, const void* X, const void* W, const void* bias, const void* R, void* Y, int M, int N, int K,
+                int epi, int out_f32, int variant);
+int mmd_op_rmsnorm(mmd_ctx* ctx, const void* x, const void* w, void* y, int M, int H, float eps);
+int mmd_op_layernorm(mmd_ctx* ctx, const void* x, const void* w, const void* b, void* y, int M, int H, float eps);
+/* q [S, nh*d] (rotated in place), k/v [S, nkv*d] appended rotated/unrotated at pos0.. into Kc/Vc [nkv, cap, d] */
+int mmd_op_rope_append(mmd_ctx* ctx, void* qkv, int S, int nh, int nkv, int d, float theta, int64_t pos0, void* q_out,
+                       void* Kc, void* Vc, int64_t cap);
+/* causal GQA attention with query offset: q [S, nh*d], Kc/Vc [nkv, cap, d], n_ctx = tokens before this step;
+ * out [S, nh*d].  causal = 0 -> full attention over n_ctx + S keys.  variant: 0 auto, 1 simple, 2 mfma. */
+int mmd_op_attention(mmd_ctx* ctx, const void* q, const void* Kc, const void* Vc, void* out, int S, int nh, int nkv, int d,
+                     int64_t n_ctx, int64_t cap, int causal, int variant);
+int mmd_op_pool(mmd_ctx* ctx, const void* x, void* y, int B, int grid, int H, int mode, int stride);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -100,10 +100,8 @@ def _parser_for(cls):
             et = type(default[0]) if default else str
             p.add_argument(f'--{f.name}', type=et, nargs='+', default=default)
         else:
-            base = {int: int, float: float, str: str}.get(type(default), None)
-            if base is None:        # Optional[...] with default None
-                s = str(tp)
-                base = float if 'float' in s else int if 'int' in s else str
+            s = str(tp)             # the annotation decides (`frame_fps: float = 2`), Optional[...] included
+            base = float if 'float' in s else int if 'int' in s else str
             p.add_argument(f'--{f.name}', type=base, default=default)
     return p
 

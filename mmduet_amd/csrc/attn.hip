@@ -1,0 +1,287 @@
+// attn.hip -- softmax attention for both halves of the path (gfx950).
+//
+//   * LLM: causal GQA attention with a query offset over the KV arena -- Qwen2Attention.forward +
+//     create_causal_mask (transformers qwen2/modeling_qwen2.py:200-240, 372-388): query row s sits at position
+//     n_ctx + s and sees keys 0..n_ctx+s; 28 q heads share 4 kv heads (x7).
+//   * ViT: full (non-causal) MHSA of SiglipAttention.forward (siglip/modeling_siglip.py:273-307), head_dim 72.
+//
+// attn_mfma_kernel (bf16): flash-style, 4 waves x 16 query rows, 32-key tiles.  Query rows of the heads that share a
+//   kv head are flattened into one row space (row = tok*G + g) so a K/V tile staged in LDS is used by the whole
+//   group.  S^T = mfma(K, Q) puts a query row in lane&15, so the online-softmax state (m, l, rescale) is lane-local
+//   plus two xor-shuffles; O^T = mfma(V^T, P) consumes P straight from the S^T accumulator registers
+//   (k-slot order {g*4+j, 16+g*4+j} on both operands).  Long contexts are split over grid.z and merged by
+//   attn_combine_kernel (flash-decoding).
+// attn_simple_kernel (any dtype / head_dim): one wave per (row, head); the fp32 parity path and the cross-check of
+//   the MFMA kernel.
+// softmax statistics are fp32; P is rounded to the storage type before P.V (flash / sdpa semantics).
+#include "common.h"
+
+struct AttnP {
+    const void* q; const void* K; const void* V; void* out; float* ws_o; float* ws_ml;
+    long long ldq, ldo, k_hs, k_ts, v_hs, v_ts, q_bs, kv_bs, o_bs;
+    long long n_ctx;
+    int S, nh, nkv, d, causal, splits, kv_per_split;
+    float scale_log2;
+};
+
+// ------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void attn_simple_kernel(AttnP p) {
+    int s = blockIdx.x, h = blockIdx.y, b = blockIdx.z, lane = threadIdx.x;
+    int G = p.nh / p.nkv, kvh = h / G;
+    const T* q = (const T*)p.q + b * p.q_bs + (long long)s * p.ldq + (long long)h * p.d;
+    const T* K = (const T*)p.K + b * p.kv_bs + kvh * p.k_hs;
+    const T* V = (const T*)p.V + b * p.kv_bs + kvh * p.v_hs;
+    long long n_keys = p.causal ? p.n_ctx + s + 1 : p.n_ctx + p.S;
+    int d = p.d;
+    float q0 = lane < d ? to_f<T>(q[lane]) : 0.f, q1 = lane + 64 < d ? to_f<T>(q[lane + 64]) : 0.f;
+    float m = -INFINITY, l = 0.f, o0 = 0.f, o1 = 0.f;
+    for (long long j = 0; j < n_keys; ++j) {
+        const T* kr = K + j * p.k_ts;
+        float part = (lane < d ? q0 * to_f<T>(kr[lane]) : 0.f) + (lane + 64 < d ? q1 * to_f<T>(kr[lane + 64]) : 0.f);
+        float sc = wave_sum(part) * p.scale_log2;
+        float mn = fmaxf(m, sc);
+        float alpha = exp2f(m - mn), pj = exp2f(sc - mn);
+        const T* vr = V + j * p.v_ts;
+        float pr = rnd<T>(pj);
+        o0 = o0 * alpha + (lane < d ? pr * to_f<T>(vr[lane]) : 0.f);
+        o1 = o1 * alpha + (lane + 64 < d ? pr * to_f<T>(vr[lane + 64]) : 0.f);
+        l = l * alpha + pj;
+        m = mn;
+    }
+    T* o = (T*)p.out + b * p.o_bs + (long long)s * p.ldo + (long long)h * p.d;
+    if (lane < d) o[lane] = from_f<T>(o0 / l);
+    if (lane + 64 < d) o[lane + 64] = from_f<T>(o1 / l);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+template <int DP>
+__global__ __launch_bounds__(256) void attn_mfma_kernel(AttnP p) {
+    constexpr int KT = 32;                    // keys per tile
+    constexpr int KLD = DP + 8;               // K tile row stride (elements)
+    constexpr int VLD = KT + 8;               // V^T row stride
+    constexpr int NC = DP / 32;               // QK k-steps
+    constexpr int DVT = DP / 16;              // max PV d-tiles
+    __shared__ __attribute__((aligned(16))) bf16_t Ks[KT * KLD];
+    __shared__ __attribute__((aligned(16))) bf16_t Vt[DP * VLD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int G = p.nh / p.nkv;
+    const int kvh = blockIdx.y % p.nkv, b = blockIdx.y / p.nkv;
+    const int rows_total = p.S * G;
+    const int row0 = blockIdx.x * 64;
+    const int d = p.d;
+    const int dvt = (d + 15) >> 4;
+
+    const bf16_t* Kg = (const bf16_t*)p.K + b * p.kv_bs + kvh * p.k_hs;
+    const bf16_t* Vg = (const bf16_t*)p.V + b * p.kv_bs + kvh * p.v_hs;
+
+    // this lane's query row (as the B operand of S^T = K.Q^T the row index is lane&15)
+    const int my_row = row0 + wave * 16 + lr;
+    const bool row_ok = my_row < rows_total;
+    const int my_tok = row_ok ? my_row / G : 0;
+    const int my_head = kvh * G + (row_ok ? my_row % G : 0);
+    const long long n_tot = p.n_ctx + p.S;
+    const long long my_limit = !row_ok ? 0 : (p.causal ? p.n_ctx + my_tok + 1 : n_tot);   // keys [0, my_limit) visible
+
+    bf16x8_t qf[NC];
+    {
+        const bf16_t* qrow = (const bf16_t*)p.q + b * p.q_bs + (long long)my_tok * p.ldq + (long long)my_head * d;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            int e = c * 32 + lq * 8;
+            s16x8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (row_ok && e + 8 <= d) v = *reinterpret_cast<const s16x8_t*>(qrow + e);
+            qf[c] = __builtin_bit_cast(bf16x8_t, v);
+        }
+    }
+
+    // key range of this block / split
+    int last_row = min(row0 + 63, rows_total - 1);
+    long long blk_limit = p.causal ? min(n_tot, p.n_ctx + (long long)(last_row / G) + 1) : n_tot;
+    long long kbeg = (long long)blockIdx.z * p.kv_per_split;
+    long long kend = min(blk_limit, kbeg + p.kv_per_split);
+
+    f32x4_t oacc[DVT];
+#pragma unroll
+    for (int t = 0; t < DVT; ++t) oacc[t] = f32x4_t{0, 0, 0, 0};
+    float m_run = -INFINITY, l_run = 0.f;
+
+    for (long long k0 = kbeg; k0 < kend; k0 += KT) {
+        __syncthreads();
+        // stage K [32][DP] and V^T [DP][32]; 16-byte global loads, zero fill outside (keys >= kend, dims >= d)
+        for (int i = tid; i < KT * (DP / 8); i += 256) {
+            int kr = i / (DP / 8), c = (i % (DP / 8)) * 8;
+            long long key = k0 + kr;
+            s16x8_t kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (key < kend && c + 8 <= d) {
+                kv = *reinterpret_cast<const s16x8_t*>(Kg + key * p.k_ts + c);
+                vv = *reinterpret_cast<const s16x8_t*>(Vg + key * p.v_ts + c);
+            }
+            *reinterpret_cast<s16x8_t*>(Ks + kr * KLD + c) = kv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) Vt[(c + e) * VLD + kr] = (bf16_t)vv[e];
+        }
+        __syncthreads();
+
+        // S^T tiles: st[t][r] = S[q = lr][key = k0 + t*16 + lq*4 + r]
+        f32x4_t st[2] = {f32x4_t{0, 0, 0, 0}, f32x4_t{0, 0, 0, 0}};
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + (t * 16 + lr) * KLD + c * 32 + lq * 8);
+                st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[c], st[t], 0, 0, 0);
+            }
+        float sv[8];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                long long key = k0 + t * 16 + lq * 4 + r;
+                float v = (key < my_limit && key < kend) ? st[t][r] * p.scale_log2 : -INFINITY;
+                sv[t * 4 + r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float m_new = fmaxf(m_run, mx);
+        float m_use = m_new == -INFINITY ? 0.f : m_new;      // fully masked so far: keep everything at zero
+        float alpha = exp2f(m_run - m_use);                  // m_run = -inf -> 0
+        float psum = 0.f;
+        s16x8_t pk;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float pv = exp2f(sv[i] - m_use);
+            psum += pv;
+            pk[i] = (short)f2bf(pv);
+        }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+        bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pk);
+#pragma unroll
+        for (int t = 0; t < DVT; ++t) {
+            if (t < dvt) {
+                oacc[t] *= alpha;
+                const bf16_t* vrow = Vt + (t * 16 + lr) * VLD;
+                s16x4_t lo = *reinterpret_cast<const s16x4_t*>(vrow + lq * 4);
+                s16x4_t hi = *reinterpret_cast<const s16x4_t*>(vrow + 16 + lq * 4);
+                s16x8_t vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                oacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vf), pf, oacc[t], 0, 0, 0);
+            }
+        }
+    }
+
+    // reduce l over the 4 lanes that share a query row
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+
+    if (!row_ok) return;
+    if (p.splits == 1) {
+        bf16_t* orow = (bf16_t*)p.out + b * p.o_bs + (long long)my_tok * p.ldo + (long long)my_head * d;
+        float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+#pragma unroll
+        for (int t = 0; t < DVT; ++t) {
+            int e = t * 16 + lq * 4;
+            if (t < dvt && e + 4 <= d) {
+                s16x4_t o = {(short)f2bf(oacc[t][0] * inv), (short)f2bf(oacc[t][1] * inv), (short)f2bf(oacc[t][2] * inv), (short)f2bf(oacc[t][3] * inv)};
+                *reinterpret_cast<s16x4_t*>(orow + e) = o;
+            } else if (t < dvt) {
+                for (int r = 0; r < 4; ++r) if (e + r < d) orow[e + r] = f2bf(oacc[t][r] * inv);
+            }
+        }
+    } else {
+        long long grow = ((long long)b * p.nkv + kvh) * rows_total + my_row;       // global row id
+        float* wo = p.ws_o + ((long long)blockIdx.z * gridDim.y * rows_total + grow) * DP;
+#pragma unroll
+        for (int t = 0; t < DVT; ++t) if (t < dvt) *reinterpret_cast<f32x4_t*>(wo + t * 16 + lq * 4) = oacc[t];
+        if (lq == 0) {
+            float* wml = p.ws_ml + ((long long)blockIdx.z * gridDim.y * rows_total + grow) * 2;
+            wml[0] = m_run; wml[1] = l_run;
+        }
+    }
+}
+
+// merge split-KV partials: out = sum_s 2^(m_s - M) o_s / sum_s 2^(m_s - M) l_s
+template <int DP>
+__global__ void attn_combine_kernel(AttnP p, int nrows_total_all) {
+    int grow = blockIdx.x;                       // ((b*nkv + kvh) * rows_total + row)
+    int G = p.nh / p.nkv;
+    int rows_total = p.S * G;
+    int row = grow % rows_total, bk = grow / rows_total, kvh = bk % p.nkv, b = bk / p.nkv;
+    int tok = row / G, head = kvh * G + row % G;
+    float M = -INFINITY;
+    for (int s = 0; s < p.splits; ++s) M = fmaxf(M, p.ws_ml[((long long)s * nrows_total_all + grow) * 2]);
+    float L = 0.f;
+    for (int s = 0; s < p.splits; ++s) {
+        const float* ml = p.ws_ml + ((long long)s * nrows_total_all + grow) * 2;
+        if (ml[0] != -INFINITY) L += exp2f(ml[0] - M) * ml[1];
+    }
+    bf16_t* orow = (bf16_t*)p.out + b * p.o_bs + (long long)tok * p.ldo + (long long)head * p.d;
+    for (int e = threadIdx.x; e < p.d; e += blockDim.x) {
+        float acc = 0.f;
+        for (int s = 0; s < p.splits; ++s) {
+            const float* ml = p.ws_ml + ((long long)s * nrows_total_all + grow) * 2;
+            if (ml[0] != -INFINITY) acc += exp2f(ml[0] - M) * p.ws_o[((long long)s * nrows_total_all + grow) * DP + e];
+        }
+        orow[e] = f2bf(L > 0.f ? acc / L : 0.f);
+    }
+}
+
+template <int DP>
+static hipError_t launch_mfma(AttnP& p, const AttnArgs& a, hipStream_t st) {
+    int G = a.nh / a.nkv;
+    int rows_total = a.S * G;
+    int qtiles = cdiv(rows_total, 64);
+    int by = a.nkv * a.batch;
+    long long n_tot = a.n_ctx + a.S;
+    int blocks = qtiles * by;
+    int splits = 1;
+    if (blocks < 256) {
+        int want = cdiv(512, blocks);
+        int maxs = (int)(n_tot / 256); if (maxs < 1) maxs = 1;
+        splits = want < maxs ? want : maxs;
+        if (splits > 64) splits = 64;
+        if (a.ws == nullptr) splits = 1;
+        while (splits > 1 && (size_t)splits * by * rows_total * (DP + 2) * sizeof(float) > a.ws_bytes) --splits;
+    }
+    int per = (int)round_up(cdiv(n_tot, splits), 32);
+    splits = cdiv(n_tot, per);
+    p.splits = splits; p.kv_per_split = per;
+    int nrows_all = by * rows_total;
+    p.ws_o = a.ws;
+    p.ws_ml = a.ws ? a.ws + (size_t)splits * nrows_all * DP : nullptr;
+    hipLaunchKernelGGL((attn_mfma_kernel<DP>), dim3(qtiles, by, splits), dim3(256), 0, st, p);
+    if (splits > 1) hipLaunchKernelGGL((attn_combine_kernel<DP>), dim3(nrows_all), dim3(64), 0, st, p, nrows_all);
+    return hipGetLastError();
+}
+
+hipError_t launch_attention(int dtype, const AttnArgs& a, hipStream_t st) {
+    if (a.S <= 0) return hipSuccess;
+    AttnP p;
+    p.q = a.q; p.K = a.K; p.V = a.V; p.out = a.out; p.ws_o = nullptr; p.ws_ml = nullptr;
+    p.ldq = a.ldq; p.ldo = a.ldo;
+    p.k_hs = a.k_hs; p.k_ts = a.k_ts; p.v_hs = a.v_hs; p.v_ts = a.v_ts;
+    p.q_bs = a.q_bstride; p.kv_bs = a.kv_bstride; p.o_bs = a.o_bstride;
+    p.n_ctx = a.n_ctx; p.S = a.S; p.nh = a.nh; p.nkv = a.nkv; p.d = a.d; p.causal = a.causal;
+    p.splits = 1; p.kv_per_split = 0;
+    p.scale_log2 = (1.0f / sqrtf((float)a.d)) * 1.4426950408889634f;
+    bool can_mfma = dtype == MMD_BF16 && (a.d % 8) == 0 && a.d <= 128 && (a.ldq % 8) == 0 && (a.k_ts % 8) == 0 && (a.v_ts % 8) == 0 &&
+                    (a.k_hs % 8) == 0 && (a.v_hs % 8) == 0 && (a.kv_bstride % 8) == 0 && (a.q_bstride % 8) == 0;
+    int variant = a.variant;
+    if (variant == 0) variant = can_mfma ? 2 : 1;
+    if (variant == 2 && !can_mfma) return hipErrorInvalidValue;
+    if (variant == 1) {
+        if (a.d > 128) return hipErrorInvalidValue;
+        dim3 grid(a.S, a.nh, a.batch);
+        if (dtype == MMD_F32) hipLaunchKernelGGL(attn_simple_kernel<float>, grid, dim3(64), 0, st, p);
+        else hipLaunchKernelGGL(attn_simple_kernel<bf16_t>, grid, dim3(64), 0, st, p);
+        return hipGetLastError();
+    }
+    if (a.d <= 32) return launch_mfma<32>(p, a, st);
+    if (a.d <= 64) return launch_mfma<64>(p, a, st);
+    if (a.d <= 96) return launch_mfma<96>(p, a, st);
+    return launch_mfma<128>(p, a, st);
+}

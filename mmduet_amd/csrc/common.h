@@ -1,0 +1,106 @@
+// common.h -- shared device helpers and the internal launcher interface of libmmduet_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include "../../include/mmduet.h"
+
+typedef uint16_t bf16_t;   // raw bfloat16 storage
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(2))) short s16x2_t;
+
+#define WAVE 64
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {            // round-to-nearest-even (v_cvt_pk_bf16_f32)
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(bf16_t, b);
+}
+template <typename T> __device__ __forceinline__ float to_f(T v);
+template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f<bf16_t>(bf16_t v) { return bf2f(v); }
+template <typename T> __device__ __forceinline__ T from_f(float v);
+template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f<bf16_t>(float v) { return f2bf(v); }
+// round a float through the storage type (the rounding points of eager bf16 execution)
+template <typename T> __device__ __forceinline__ float rnd(float v) { return to_f<T>(from_f<T>(v)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+    const float k = 0.7978845608028654f;   // sqrt(2/pi)
+    return 0.5f * x * (1.0f + tanhf(k * (x + 0.044715f * x * x * x)));
+}
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+static inline size_t dtype_size(int dt) { return dt == MMD_F32 ? 4 : 2; }
+
+// ---- epilogues of the GEMM family ------------------------------------------------------------------------------
+enum { EPI_NONE = 0, EPI_GELU_TANH = 1, EPI_GELU_ERF = 2, EPI_RESID = 3, EPI_SWIGLU = 4 };
+enum { GEMM_AUTO = 0, GEMM_GENERIC = 1, GEMM_SKINNY = 2, GEMM_LARGE = 3 };
+
+struct GemmArgs {
+    const void* X; int64_t ldx;      // [M,K]
+    const void* W; int64_t ldw;      // [N,K]  (nn.Linear layout)
+    const void* bias;                // [N] or null (ctx dtype)
+    const void* R; int64_t ldr;      // residual [M,N] (EPI_RESID)
+    void* Y; int64_t ldy;            // [M,N] (or [M,N/2] for SWIGLU); ctx dtype, or fp32 if out_f32
+    int M, N, K;
+    int epi; int out_f32;
+    int variant;
+    float* splitk_ws; size_t splitk_ws_bytes;   // fp32 partial slabs
+};
+
+// launchers (dtype = mmd_dtype).  All return hipError_t of the launch.
+hipError_t launch_gemm(int dtype, const GemmArgs& a, hipStream_t st, int* kind_out);
+hipError_t launch_rmsnorm(int dtype, const void* x, const void* w, void* y, int M, int H, float eps, hipStream_t st);
+hipError_t launch_layernorm(int dtype, const void* x, const void* w, const void* b, void* y, int M, int H, float eps, hipStream_t st);
+hipError_t launch_add_rows(int dtype, void* x, const void* add, int M, int H, int period, hipStream_t st);   // x[m,:] += add[m % period,:]
+hipError_t launch_rope_append(int dtype, const void* qkv, int S, int nh, int nkv, int d, const float* inv_freq_dev, int64_t pos0, void* q_out,
+                              void* Kc, void* Vc, int64_t cap, hipStream_t st);
+hipError_t launch_embed(int dtype, const void* table, const int64_t* ids, int k, int H, int64_t vocab, void* out, hipStream_t st);
+hipError_t launch_im2col(int dtype, const void* px, int B, int img, int patch, int grid, int Kpad, void* out, hipStream_t st);
+hipError_t launch_pool(int dtype, const void* x, void* y, int B, int grid, int H, int mode, int stride, hipStream_t st);
+hipError_t launch_heads(int dtype, const void* hidden, int64_t ldh, const int32_t* rows_dev, int M, const void* W4, int H, float* out,
+                        hipStream_t st);
+hipError_t launch_argmax_penalty(const float* logits, int V, const int64_t* prev_ids_dev, int n_prev, float penalty, int64_t* out_id,
+                                 hipStream_t st);
+hipError_t launch_convert(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, hipStream_t st);
+hipError_t launch_copy_rows(int dtype, const void* src, int64_t lds_, void* dst, int64_t ldd, int rows, int cols, hipStream_t st);
+hipError_t launch_interleave16(int dtype, const void* a, const void* b, void* out, int rows, int cols, hipStream_t st);
+hipError_t launch_pad_cols(int dtype, const void* src, int rows, int cols, void* dst, int cols_pad, hipStream_t st);
+hipError_t launch_lora_merge(int dtype, void* W, const float* A, const float* B, int out_f, int in_f, int r, float scale, hipStream_t st);
+hipError_t launch_preprocess(int dtype, const uint8_t* frames, int T, int R, int size, const int32_t* coef, const int32_t* bounds, int ksize,
+                             uint8_t* tmp, void* out, hipStream_t st);
+
+struct AttnArgs {
+    const void* q; int64_t ldq;      // [S, nh*d] row stride ldq
+    const void* K; const void* V;    // element (kv head h, token t, e) at K + h*k_hs + t*k_ts + e
+    int64_t k_hs, k_ts, v_hs, v_ts;  // arena: hs = cap*d, ts = d ; fused ViT qkv rows: hs = d, ts = 3C
+    void* out; int64_t ldo;          // [S, nh*d]
+    int S, nh, nkv, d;
+    int64_t n_ctx;                   // keys before this step; total keys = n_ctx + S
+    int causal;
+    int batch; int64_t q_bstride, kv_bstride, o_bstride;   // ViT: batch of independent sequences (elements)
+    float* ws; size_t ws_bytes;      // split-KV partials
+    int variant;
+};
+hipError_t launch_attention(int dtype, const AttnArgs& a, hipStream_t st);

@@ -1,0 +1,723 @@
+// model.hip -- context, weights, KV arena and the forward orchestration behind the C ABI (include/mmduet.h).
+//
+// Host-side control only: every arithmetic step is a HIP kernel from gemm.hip / attn.hip / ops.hip launched on the
+// context's stream.  Reference call chain this file stands in for:
+//   LiveMixin.visual_embed (models/modeling_live.py:26-33) -> mmd_vit_encode
+//   VideoHeadLiveLlavaQwenForCausalLM.forward (models/live_llava/video_head_live_llava_qwen.py:121-205) -> mmd_llm_step +
+//       mmd_video_heads + mmd_lm_head
+//   fast_greedy_generate (models/modeling_live.py:51-77) -> mmd_greedy_generate
+#include "common.h"
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+static thread_local std::string g_create_error;
+
+struct RawTensor { void* p = nullptr; std::vector<int64_t> shape; int64_t numel = 0; };
+
+struct Prof {
+    bool on = false;
+    std::vector<hipEvent_t> pool;
+    struct Pending { hipEvent_t a, b; int kind; };
+    std::vector<Pending> pending;
+    double ms[MMD_K_COUNT] = {0}; int64_t n[MMD_K_COUNT] = {0}; double bytes[MMD_K_COUNT] = {0}; double flops[MMD_K_COUNT] = {0};
+};
+
+struct LlmLayer { void *ln1 = 0, *ln2 = 0, *wqkv = 0, *bqkv = 0, *wo = 0, *wgu = 0, *wdown = 0; };
+struct VitLayer { void *ln1w = 0, *ln1b = 0, *wqkv = 0, *bqkv = 0, *wo = 0, *bo = 0, *ln2w = 0, *ln2b = 0, *w1 = 0, *b1 = 0, *w2 = 0, *b2 = 0; };
+
+struct mmd_ctx {
+    mmd_config cfg;
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    std::string err;
+    std::unordered_map<std::string, RawTensor> raw;
+    std::vector<void*> allocs;
+    int64_t weight_bytes = 0;
+    bool finalized = false;
+    // fused weights
+    std::vector<LlmLayer> L;
+    std::vector<VitLayer> VL;
+    void *embed = 0, *fnorm = 0, *lm_head = 0, *heads4 = 0;
+    void *patch_w = 0, *patch_b = 0, *pos_emb = 0, *post_w = 0, *post_b = 0, *p0w = 0, *p0b = 0, *p2w = 0, *p2b = 0;
+    int vit_kpad = 0, vit_ipad = 0, vit_tokens = 0, vit_grid = 0, qkv_w = 0;
+    float* inv_freq = nullptr; bool inv_freq_user = false;
+    // workspaces
+    void *v_col = 0, *v_h = 0, *v_xn = 0, *v_qkv = 0, *v_attn = 0, *v_mlp = 0, *v_p1 = 0, *v_p2 = 0;
+    void *l_h = 0, *l_xn = 0, *l_qkv = 0, *l_q = 0, *l_attn = 0, *l_act = 0, *l_hid = 0;
+    float* splitk_ws = 0; size_t splitk_bytes = 0;
+    float* attn_ws = 0; size_t attn_bytes = 0;
+    float* logits_ws = 0;              // [V] fp32 for generation
+    float* heads_dev = 0;              // [max_step_tokens,4]
+    int32_t* rows_dev = 0;
+    int64_t* tok_dev = 0;              // sampled token id
+    int64_t* prev_dev = 0; int prev_cap = 0;
+    void* gen_embed = 0;               // [1,H]
+    // pinned staging
+    float* heads_host = 0; int32_t* rows_host = 0; int64_t* tok_host = 0;
+    // preprocess tables
+    int pp_R = 0; int32_t* pp_coef = 0; int32_t* pp_bounds = 0; int pp_ksize = 0; uint8_t* pp_tmp = 0; size_t pp_tmp_bytes = 0;
+    int last_vit_B = 0;
+    Prof prof;
+};
+
+struct mmd_stream {
+    mmd_ctx* ctx;
+    void* K = nullptr; void* V = nullptr;      // [layers][nkv][cap][d]
+    int64_t cap = 0, len = 0;
+};
+
+#define FAIL(ctx, code, ...) do { char _b[512]; snprintf(_b, sizeof(_b), __VA_ARGS__); (ctx)->err = _b; return (code); } while (0)
+#define HIPCHK(ctx, expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { FAIL(ctx, MMD_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); } } while (0)
+
+static size_t es(const mmd_ctx* c) { return dtype_size(c->cfg.dtype); }
+
+static int dev_alloc(mmd_ctx* c, void** out, size_t bytes, bool zero = true) {
+    if (bytes == 0) bytes = 16;
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) FAIL(c, MMD_ENOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    if (zero) { e = hipMemsetAsync(p, 0, bytes, c->stream); if (e != hipSuccess) FAIL(c, MMD_EHIP, "memset failed"); }
+    c->allocs.push_back(p);
+    *out = p;
+    return MMD_OK;
+}
+static void dev_free(mmd_ctx* c, void* p) {
+    if (!p) return;
+    for (size_t i = 0; i < c->allocs.size(); ++i) if (c->allocs[i] == p) { c->allocs[i] = c->allocs.back(); c->allocs.pop_back(); break; }
+    hipFree(p);
+}
+
+// ---- profiling ---------------------------------------------------------------------------------------------------
+struct ProfScope {
+    mmd_ctx* c; int kind; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(mmd_ctx* c_, int kind_, double bytes, double flops) : c(c_), kind(kind_) {
+        if (!c->prof.on) return;
+        auto get = [&]() { hipEvent_t e; if (!c->prof.pool.empty()) { e = c->prof.pool.back(); c->prof.pool.pop_back(); } else hipEventCreate(&e); return e; };
+        a = get(); b = get();
+        c->prof.bytes[kind] += bytes; c->prof.flops[kind] += flops; c->prof.n[kind] += 1;
+        hipEventRecord(a, c->stream);
+    }
+    ~ProfScope() {
+        if (!a) return;
+        hipEventRecord(b, c->stream);
+        c->prof.pending.push_back({a, b, kind});
+    }
+};
+static void prof_drain(mmd_ctx* c) {
+    if (c->prof.pending.empty()) return;
+    hipStreamSynchronize(c->stream);
+    for (auto& p : c->prof.pending) {
+        float ms = 0; hipEventElapsedTime(&ms, p.a, p.b);
+        c->prof.ms[p.kind] += ms;
+        c->prof.pool.push_back(p.a); c->prof.pool.push_back(p.b);
+    }
+    c->prof.pending.clear();
+}
+
+// ---- GEMM wrapper --------------------------------------------------------------------------------------------------
+static int gemm(mmd_ctx* c, const void* X, int64_t ldx, const void* W, int64_t ldw, const void* bias, const void* R, int64_t ldr, void* Y,
+                int64_t ldy, int M, int N, int K, int epi, int out_f32 = 0, int variant = GEMM_AUTO) {
+    GemmArgs a;
+    a.X = X; a.ldx = ldx; a.W = W; a.ldw = ldw; a.bias = bias; a.R = R; a.ldr = ldr; a.Y = Y; a.ldy = ldy;
+    a.M = M; a.N = N; a.K = K; a.epi = epi; a.out_f32 = out_f32; a.variant = variant;
+    a.splitk_ws = c->splitk_ws; a.splitk_ws_bytes = c->splitk_bytes;
+    int kind = (variant == GEMM_SKINNY || (variant == GEMM_AUTO && M <= 64)) ? MMD_K_GEMM_SKINNY : MMD_K_GEMM_TILE;
+    double e = (double)es(c);
+    double bytes = ((double)M * K + (double)N * K) * e + (double)M * (epi == EPI_SWIGLU ? N / 2 : N) * (out_f32 ? 4.0 : e);
+    ProfScope ps(c, kind, bytes, 2.0 * M * N * K);
+    HIPCHK(c, launch_gemm(c->cfg.dtype, a, c->stream, nullptr));
+    return MMD_OK;
+}
+
+// ---- create / destroy ------------------------------------------------------------------------------------------------
+extern "C" int mmd_create(const mmd_config* cfg, int device, mmd_ctx** out) {
+    if (!cfg || !out) { g_create_error = "null argument"; return MMD_EINVAL; }
+    if (cfg->struct_size != (int32_t)sizeof(mmd_config)) { g_create_error = "mmd_config size mismatch (ABI)"; return MMD_EINVAL; }
+    if (cfg->dtype != MMD_F32 && cfg->dtype != MMD_BF16) { g_create_error = "unsupported dtype"; return MMD_EINVAL; }
+    if (cfg->num_heads % cfg->num_kv_heads != 0 || cfg->head_dim % 2 != 0 || cfg->head_dim > 128) { g_create_error = "unsupported head configuration"; return MMD_EINVAL; }
+    if (cfg->vit_hidden % cfg->vit_heads != 0 || cfg->vit_hidden / cfg->vit_heads > 128) { g_create_error = "unsupported ViT head configuration"; return MMD_EINVAL; }
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) { g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e); return MMD_EHIP; }
+    mmd_ctx* c = new mmd_ctx();
+    c->cfg = *cfg; c->device = device;
+    e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e); delete c; return MMD_EHIP; }
+    c->stream = c->own_stream;
+    c->vit_grid = cfg->vit_image / cfg->vit_patch;
+    c->vit_tokens = c->vit_grid * c->vit_grid;
+    c->vit_kpad = (int)round_up(3 * cfg->vit_patch * cfg->vit_patch, 32);
+    c->vit_ipad = (int)round_up(cfg->vit_intermediate, 64);
+    c->qkv_w = (cfg->num_heads + 2 * cfg->num_kv_heads) * cfg->head_dim;
+    *out = c;
+    return MMD_OK;
+}
+
+extern "C" void mmd_destroy(mmd_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    prof_drain(c);
+    for (auto e : c->prof.pool) hipEventDestroy(e);
+    for (void* p : c->allocs) hipFree(p);
+    if (c->heads_host) hipHostFree(c->heads_host);
+    if (c->rows_host) hipHostFree(c->rows_host);
+    if (c->tok_host) hipHostFree(c->tok_host);
+    hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+extern "C" const char* mmd_last_error(const mmd_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+extern "C" int mmd_set_stream(mmd_ctx* c, void* s) { if (!c) return MMD_EINVAL; c->stream = s ? (hipStream_t)s : c->own_stream; return MMD_OK; }
+extern "C" void* mmd_get_stream(mmd_ctx* c) { return c ? (void*)c->stream : nullptr; }
+extern "C" int mmd_synchronize(mmd_ctx* c) { if (!c) return MMD_EINVAL; HIPCHK(c, hipStreamSynchronize(c->stream)); return MMD_OK; }
+extern "C" int64_t mmd_weight_bytes(const mmd_ctx* c) { return c ? c->weight_bytes : 0; }
+
+// ---- weights ---------------------------------------------------------------------------------------------------------
+static std::string canon_name(const char* name) {
+    std::string n(name);
+    const std::string a = "model.vision_tower.vision_tower.vision_model.", b = "model.vision_tower.vision_tower.";
+    if (n.compare(0, a.size(), a) == 0) return "vit." + n.substr(a.size());
+    if (n.compare(0, b.size(), b) == 0) return "vit." + n.substr(b.size());
+    return n;
+}
+
+extern "C" int mmd_load_tensor(mmd_ctx* c, const char* name, const void* data, int src_dtype, const int64_t* shape, int rank, int on_device) {
+    if (!c || !name || !data || rank < 1 || rank > 4) return MMD_EINVAL;
+    if (c->finalized) FAIL(c, MMD_EINVAL, "weights already finalized");
+    if (src_dtype != MMD_F32 && src_dtype != MMD_BF16) FAIL(c, MMD_EINVAL, "unsupported source dtype %d for %s", src_dtype, name);
+    hipSetDevice(c->device);
+    RawTensor t;
+    t.numel = 1;
+    for (int i = 0; i < rank; ++i) { t.shape.push_back(shape[i]); t.numel *= shape[i]; }
+    int rc = dev_alloc(c, &t.p, (size_t)t.numel * es(c), false);
+    if (rc) return rc;
+    const void* src = data;
+    void* staging = nullptr;
+    if (!on_device) {
+        size_t sb = (size_t)t.numel * dtype_size(src_dtype);
+        if (src_dtype == c->cfg.dtype) {
+            HIPCHK(c, hipMemcpyAsync(t.p, data, sb, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            src = nullptr;
+        } else {
+            HIPCHK(c, hipMalloc(&staging, sb));
+            HIPCHK(c, hipMemcpyAsync(staging, data, sb, hipMemcpyHostToDevice, c->stream));
+            src = staging;
+        }
+    }
+    if (src) {
+        HIPCHK(c, launch_convert(src, src_dtype, t.p, c->cfg.dtype, t.numel, c->stream));
+        if (staging) { HIPCHK(c, hipStreamSynchronize(c->stream)); hipFree(staging); }
+    }
+    std::string key = canon_name(name);
+    auto it = c->raw.find(key);
+    if (it != c->raw.end()) dev_free(c, it->second.p);
+    c->raw[key] = t;
+    return MMD_OK;
+}
+
+extern "C" int mmd_merge_lora(mmd_ctx* c, const char* weight_name, const float* A_host, const float* B_host, int r, float scale) {
+    if (!c || !weight_name || !A_host || !B_host || r <= 0) return MMD_EINVAL;
+    auto it = c->raw.find(canon_name(weight_name));
+    if (it == c->raw.end()) FAIL(c, MMD_ENOENT, "mmd_merge_lora: no tensor %s", weight_name);
+    RawTensor& t = it->second;
+    if (t.shape.size() != 2) FAIL(c, MMD_EINVAL, "mmd_merge_lora: %s is not a matrix", weight_name);
+    int out_f = (int)t.shape[0], in_f = (int)t.shape[1];
+    float *A = nullptr, *B = nullptr;
+    HIPCHK(c, hipMalloc((void**)&A, sizeof(float) * r * in_f));
+    HIPCHK(c, hipMalloc((void**)&B, sizeof(float) * out_f * r));
+    HIPCHK(c, hipMemcpyAsync(A, A_host, sizeof(float) * r * in_f, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(B, B_host, sizeof(float) * out_f * r, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, launch_lora_merge(c->cfg.dtype, t.p, A, B, out_f, in_f, r, scale, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipFree(A); hipFree(B);
+    return MMD_OK;
+}
+
+extern "C" int mmd_set_rope_inv_freq(mmd_ctx* c, const float* host, int n) {
+    if (!c || !host || n != c->cfg.head_dim / 2) return MMD_EINVAL;
+    if (!c->inv_freq) { int rc = dev_alloc(c, (void**)&c->inv_freq, sizeof(float) * n); if (rc) return rc; }
+    HIPCHK(c, hipMemcpyAsync(c->inv_freq, host, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->inv_freq_user = true;
+    return MMD_OK;
+}
+
+static int take(mmd_ctx* c, const std::string& name, std::vector<int64_t> shape, RawTensor* out) {
+    auto it = c->raw.find(name);
+    if (it == c->raw.end()) FAIL(c, MMD_ENOENT, "missing weight tensor '%s'", name.c_str());
+    int64_t n = 1; for (auto s : shape) n *= s;
+    if (it->second.numel != n) FAIL(c, MMD_EINVAL, "weight '%s' has %lld elements, expected %lld", name.c_str(), (long long)it->second.numel, (long long)n);
+    *out = it->second;
+    c->raw.erase(it);
+    return MMD_OK;
+}
+#define TAKE(var, name, ...) RawTensor var; { int _rc = take(c, name, __VA_ARGS__, &var); if (_rc) return _rc; }
+
+static int alloc_workspaces(mmd_ctx* c);
+
+extern "C" int mmd_finalize_weights(mmd_ctx* c) {
+    if (!c) return MMD_EINVAL;
+    if (c->finalized) return MMD_OK;
+    hipSetDevice(c->device);
+    const mmd_config& g = c->cfg;
+    const int dt = g.dtype; const size_t e = es(c);
+    const int H = g.hidden_size, I = g.intermediate_size, V = g.vocab_size, d = g.head_dim, nh = g.num_heads, nkv = g.num_kv_heads;
+    hipStream_t st = c->stream;
+    { TAKE(t, "model.embed_tokens.weight", {V, H}); c->embed = t.p; }
+    { TAKE(t, "model.norm.weight", {H}); c->fnorm = t.p; }
+    { TAKE(t, "lm_head.weight", {V, H}); c->lm_head = t.p; }
+    {
+        TAKE(a, "informative_head.weight", {2, H}); TAKE(b, "relevance_head.weight", {2, H});
+        int rc = dev_alloc(c, &c->heads4, 4 * H * e); if (rc) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->heads4, a.p, 2 * H * e, hipMemcpyDeviceToDevice, st));
+        HIPCHK(c, hipMemcpyAsync((char*)c->heads4 + 2 * H * e, b.p, 2 * H * e, hipMemcpyDeviceToDevice, st));
+        HIPCHK(c, hipStreamSynchronize(st)); dev_free(c, a.p); dev_free(c, b.p);
+    }
+    c->L.resize(g.num_layers);
+    for (int i = 0; i < g.num_layers; ++i) {
+        std::string p = "model.layers." + std::to_string(i) + ".";
+        LlmLayer& L = c->L[i];
+        { TAKE(t, p + "input_layernorm.weight", {H}); L.ln1 = t.p; }
+        { TAKE(t, p + "post_attention_layernorm.weight", {H}); L.ln2 = t.p; }
+        TAKE(wq, p + "self_attn.q_proj.weight", {nh * d, H}); TAKE(wk, p + "self_attn.k_proj.weight", {nkv * d, H}); TAKE(wv, p + "self_attn.v_proj.weight", {nkv * d, H});
+        TAKE(bq, p + "self_attn.q_proj.bias", {nh * d}); TAKE(bk, p + "self_attn.k_proj.bias", {nkv * d}); TAKE(bv, p + "self_attn.v_proj.bias", {nkv * d});
+        int rc = dev_alloc(c, &L.wqkv, (size_t)c->qkv_w * H * e, false); if (rc) return rc;
+        rc = dev_alloc(c, &L.bqkv, (size_t)c->qkv_w * e, false); if (rc) return rc;
+        size_t oq = (size_t)nh * d, ok = (size_t)nkv * d;
+        HIPCHK(c, hipMemcpyAsync(L.wqkv, wq.p, oq * H * e, hipMemcpyDeviceToDevice, st));
+        HIPCHK(c, hipMemcpyAsync((char*)L.wqkv + oq * H * e, wk.p, ok * H * e, hipMemcpyDeviceToDevice, st));
+        HIPCHK(c, hipMemcpyAsync((char*)L.wqkv + (oq + ok) * H * e, wv.p, ok * H * e, hipMemcpyDeviceToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(L.bqkv, bq.p, oq * e, hipMemcpyDeviceToDevice, st));
+        HIPCHK(c, hipMemcpyAsync((char*)L.bqkv + oq * e, bk.p, ok * e, hipMemcpyDeviceToDevice, st));
+        HIPCHK(c, hipMemcpyAsync((char*)L.bqkv + (oq + ok) * e, bv.p, ok * e, hipMemcpyDeviceToDevice, st));
+        { TAKE(t, p + "self_attn.o_proj.weight", {H, nh * d}); L.wo = t.p; }
+        TAKE(wg, p + "mlp.gate_proj.weight", {I, H}); TAKE(wu, p + "mlp.up_proj.weight", {I, H});
+        int64_t Ipad = round_up(I, 16);
+        rc = dev_alloc(c, &L.wgu, (size_t)2 * Ipad * H * e, false); if (rc) return rc;
+        HIPCHK(c, launch_interleave16(dt, wg.p, wu.p, L.wgu, I, H, st));
+        if (Ipad != I) FAIL(c, MMD_EINVAL, "intermediate_size must be a multiple of 16 (got %d)", I);
+        { TAKE(t, p + "mlp.down_proj.weight", {H, I}); L.wdown = t.p; }
+        HIPCHK(c, hipStreamSynchronize(st));
+        dev_free(c, wq.p); dev_free(c, wk.p); dev_free(c, wv.p); dev_free(c, bq.p); dev_free(c, bk.p); dev_free(c, bv.p); dev_free(c, wg.p); dev_free(c, wu.p);
+    }
+    // vision tower
+    const int C = g.vit_hidden, CI = g.vit_intermediate, P = g.vit_patch, KP = 3 * P * P;
+    {
+        TAKE(w, "vit.embeddings.patch_embedding.weight", {C, 3, P, P});
+        int rc = dev_alloc(c, &c->patch_w, (size_t)C * c->vit_kpad * e, false); if (rc) return rc;
+        HIPCHK(c, launch_pad_cols(dt, w.p, C, KP, c->patch_w, c->vit_kpad, st));
+        HIPCHK(c, hipStreamSynchronize(st)); dev_free(c, w.p);
+    }
+    { TAKE(t, "vit.embeddings.patch_embedding.bias", {C}); c->patch_b = t.p; }
+    { TAKE(t, "vit.embeddings.position_embedding.weight", {c->vit_tokens, C}); c->pos_emb = t.p; }
+    c->VL.resize(g.vit_layers);
+    for (int i = 0; i < g.vit_layers; ++i) {
+        std::string p = "vit.encoder.layers." + std::to_string(i) + ".";
+        VitLayer& L = c->VL[i];
+        { TAKE(t, p + "layer_norm1.weight", {C}); L.ln1w = t.p; } { TAKE(t, p + "layer_norm1.bias", {C}); L.ln1b = t.p; }
+        { TAKE(t, p + "layer_norm2.weight", {C}); L.ln2w = t.p; } { TAKE(t, p + "layer_norm2.bias", {C}); L.ln2b = t.p; }
+        TAKE(wq, p + "self_attn.q_proj.weight", {C, C}); TAKE(wk, p + "self_attn.k_proj.weight", {C, C}); TAKE(wv, p + "self_attn.v_proj.weight", {C, C});
+        TAKE(bq, p + "self_attn.q_proj.bias", {C}); TAKE(bk, p + "self_attn.k_proj.bias", {C}); TAKE(bv, p + "self_attn.v_proj.bias", {C});
+        int rc = dev_alloc(c, &L.wqkv, (size_t)3 * C * C * e, false); if (rc) return rc;
+        rc = dev_alloc(c, &L.bqkv, (size_t)3 * C * e, false); if (rc) return rc;
+        RawTensor* ws[3] = {&wq, &wk, &wv}; RawTensor* bs[3] = {&bq, &bk, &bv};
+        for (int j = 0; j < 3; ++j) {
+            HIPCHK(c, hipMemcpyAsync((char*)L.wqkv + (size_t)j * C * C * e, ws[j]->p, (size_t)C * C * e, hipMemcpyDeviceToDevice, st));
+            HIPCHK(c, hipMemcpyAsync((char*)L.bqkv + (size_t)j * C * e, bs[j]->p, (size_t)C * e, hipMemcpyDeviceToDevice, st));
+        }
+        { TAKE(t, p + "self_attn.out_proj.weight", {C, C}); L.wo = t.p; } { TAKE(t, p + "self_attn.out_proj.bias", {C}); L.bo = t.p; }
+        TAKE(w1, p + "mlp.fc1.weight", {CI, C}); TAKE(b1, p + "mlp.fc1.bias", {CI}); TAKE(w2, p + "mlp.fc2.weight", {C, CI});
+        { TAKE(t, p + "mlp.fc2.bias", {C}); L.b2 = t.p; }
+        // fc1 rows / fc2 columns zero-padded to vit_ipad: gelu(0) = 0 keeps the result exact and K tile-aligned
+        rc = dev_alloc(c, &L.w1, (size_t)c->vit_ipad * C * e, true); if (rc) return rc;
+        rc = dev_alloc(c, &L.b1, (size_t)c->vit_ipad * e, true); if (rc) return rc;
+        rc = dev_alloc(c, &L.w2, (size_t)C * c->vit_ipad * e, false); if (rc) return rc;
+        HIPCHK(c, hipMemcpyAsync(L.w1, w1.p, (size_t)CI * C * e, hipMemcpyDeviceToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(L.b1, b1.p, (size_t)CI * e, hipMemcpyDeviceToDevice, st));
+        HIPCHK(c, launch_pad_cols(dt, w2.p, C, CI, L.w2, c->vit_ipad, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        dev_free(c, wq.p); dev_free(c, wk.p); dev_free(c, wv.p); dev_free(c, bq.p); dev_free(c, bk.p); dev_free(c, bv.p);
+        dev_free(c, w1.p); dev_free(c, b1.p); dev_free(c, w2.p);
+    }
+    if (g.vit_post_layernorm) {
+        { TAKE(t, "vit.post_layernorm.weight", {C}); c->post_w = t.p; } { TAKE(t, "vit.post_layernorm.bias", {C}); c->post_b = t.p; }
+    }
+    { TAKE(t, "model.mm_projector.0.weight", {H, C}); c->p0w = t.p; } { TAKE(t, "model.mm_projector.0.bias", {H}); c->p0b = t.p; }
+    { TAKE(t, "model.mm_projector.2.weight", {H, H}); c->p2w = t.p; } { TAKE(t, "model.mm_projector.2.bias", {H}); c->p2b = t.p; }
+    // tensors that are on the checkpoint but not on the path (post_layernorm when unused, pooling head, ...) are dropped
+    for (auto& kv : c->raw) dev_free(c, kv.second.p);
+    c->raw.clear();
+    if (!c->inv_freq_user) {
+        int n = d / 2;
+        std::vector<float> t(n);
+        for (int i = 0; i < n; ++i) t[i] = (float)(1.0 / std::pow((double)g.rope_theta, (double)(2 * i) / (double)d));
+        if (!c->inv_freq) { int rc = dev_alloc(c, (void**)&c->inv_freq, sizeof(float) * n); if (rc) return rc; }
+        HIPCHK(c, hipMemcpyAsync(c->inv_freq, t.data(), sizeof(float) * n, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+    }
+    size_t wb = 0; { size_t fr = 0, tot = 0; (void)fr; (void)tot; }
+    wb = ((size_t)2 * V * H + (size_t)g.num_layers * ((size_t)c->qkv_w * H + (size_t)H * nh * d + (size_t)3 * I * H) +
+          (size_t)g.vit_layers * ((size_t)4 * C * C + (size_t)2 * c->vit_ipad * C) + (size_t)C * c->vit_kpad + (size_t)H * C + (size_t)H * H) * e;
+    c->weight_bytes = (int64_t)wb;
+    int rc = alloc_workspaces(c);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(st));
+    c->finalized = true;
+    return MMD_OK;
+}
+
+static int alloc_workspaces(mmd_ctx* c) {
+    const mmd_config& g = c->cfg; const size_t e = es(c);
+    const int C = g.vit_hidden, H = g.hidden_size;
+    int64_t Mv = round_up((int64_t)g.max_vit_batch * c->vit_tokens, 128);
+    int rc;
+#define WS(ptr, bytes) rc = dev_alloc(c, (void**)&(ptr), (bytes)); if (rc) return rc;
+    WS(c->v_col, (size_t)Mv * c->vit_kpad * e); WS(c->v_h, (size_t)Mv * C * e); WS(c->v_xn, (size_t)Mv * C * e);
+    WS(c->v_qkv, (size_t)Mv * 3 * C * e); WS(c->v_attn, (size_t)Mv * C * e); WS(c->v_mlp, (size_t)Mv * c->vit_ipad * e);
+    WS(c->v_p1, (size_t)Mv * H * e); WS(c->v_p2, (size_t)Mv * H * e);
+    int64_t S = round_up(g.max_step_tokens, 128);
+    WS(c->l_h, (size_t)S * H * e); WS(c->l_xn, (size_t)S * H * e); WS(c->l_qkv, (size_t)S * c->qkv_w * e);
+    WS(c->l_q, (size_t)S * g.num_heads * g.head_dim * e); WS(c->l_attn, (size_t)S * g.num_heads * g.head_dim * e);
+    WS(c->l_act, (size_t)S * g.intermediate_size * e); WS(c->l_hid, (size_t)S * H * e);
+    c->splitk_bytes = (size_t)64 << 20; WS(c->splitk_ws, c->splitk_bytes);
+    c->attn_bytes = (size_t)128 << 20; WS(c->attn_ws, c->attn_bytes);
+    WS(c->logits_ws, (size_t)g.vocab_size * sizeof(float));
+    WS(c->heads_dev, (size_t)S * 4 * sizeof(float)); WS(c->rows_dev, (size_t)S * sizeof(int32_t));
+    WS(c->tok_dev, 64); c->prev_cap = 16384; WS(c->prev_dev, (size_t)c->prev_cap * sizeof(int64_t));
+    WS(c->gen_embed, (size_t)H * e);
+#undef WS
+    HIPCHK(c, hipHostMalloc((void**)&c->heads_host, (size_t)S * 4 * sizeof(float)));
+    HIPCHK(c, hipHostMalloc((void**)&c->rows_host, (size_t)S * sizeof(int32_t)));
+    HIPCHK(c, hipHostMalloc((void**)&c->tok_host, 64));
+    return MMD_OK;
+}
+
+#define NEED_FINAL(c) do { if (!(c)) return MMD_EINVAL; if (!(c)->finalized) FAIL(c, MMD_EINVAL, "weights not finalized"); hipSetDevice((c)->device); } while (0)
+
+// ---- vision ----------------------------------------------------------------------------------------------------------
+extern "C" int mmd_vit_encode(mmd_ctx* c, const void* px, int B, void* out) {
+    NEED_FINAL(c);
+    const mmd_config& g = c->cfg; const int dt = g.dtype; hipStream_t st = c->stream;
+    if (B <= 0) return MMD_OK;
+    if (B > g.max_vit_batch) FAIL(c, MMD_ERANGE, "vit batch %d exceeds max_vit_batch %d", B, g.max_vit_batch);
+    const int C = g.vit_hidden, H = g.hidden_size, T = c->vit_tokens, M = B * T, hd = C / g.vit_heads;
+    { ProfScope ps(c, MMD_K_OTHER, 0, 0); HIPCHK(c, launch_im2col(dt, px, B, g.vit_image, g.vit_patch, c->vit_grid, c->vit_kpad, c->v_col, st)); }
+    int rc = gemm(c, c->v_col, c->vit_kpad, c->patch_w, c->vit_kpad, c->patch_b, nullptr, 0, c->v_h, C, M, C, c->vit_kpad, EPI_NONE); if (rc) return rc;
+    { ProfScope ps(c, MMD_K_OTHER, 0, 0); HIPCHK(c, launch_add_rows(dt, c->v_h, c->pos_emb, M, C, T, st)); }
+    for (int i = 0; i < g.vit_layers; ++i) {
+        VitLayer& L = c->VL[i];
+        { ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * M * C * es(c), 0); HIPCHK(c, launch_layernorm(dt, c->v_h, L.ln1w, L.ln1b, c->v_xn, M, C, g.vit_ln_eps, st)); }
+        rc = gemm(c, c->v_xn, C, L.wqkv, C, L.bqkv, nullptr, 0, c->v_qkv, 3 * C, M, 3 * C, C, EPI_NONE); if (rc) return rc;
+        {
+            AttnArgs a; memset(&a, 0, sizeof(a));
+            a.q = c->v_qkv; a.ldq = 3 * C; a.K = (char*)c->v_qkv + (size_t)C * es(c); a.V = (char*)c->v_qkv + (size_t)2 * C * es(c);
+            a.k_hs = hd; a.k_ts = 3 * C; a.v_hs = hd; a.v_ts = 3 * C; a.out = c->v_attn; a.ldo = C;
+            a.S = T; a.nh = g.vit_heads; a.nkv = g.vit_heads; a.d = hd; a.n_ctx = 0; a.causal = 0;
+            a.batch = B; a.q_bstride = (int64_t)T * 3 * C; a.kv_bstride = (int64_t)T * 3 * C; a.o_bstride = (int64_t)T * C;
+            a.ws = c->attn_ws; a.ws_bytes = c->attn_bytes; a.variant = 0;
+            ProfScope ps(c, MMD_K_ATTN_VIT, 4.0 * M * C * es(c), 4.0 * B * (double)T * T * C);
+            HIPCHK(c, launch_attention(dt, a, st));
+        }
+        rc = gemm(c, c->v_attn, C, L.wo, C, L.bo, c->v_h, C, c->v_h, C, M, C, C, EPI_RESID); if (rc) return rc;
+        { ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * M * C * es(c), 0); HIPCHK(c, launch_layernorm(dt, c->v_h, L.ln2w, L.ln2b, c->v_xn, M, C, g.vit_ln_eps, st)); }
+        rc = gemm(c, c->v_xn, C, L.w1, C, L.b1, nullptr, 0, c->v_mlp, c->vit_ipad, M, c->vit_ipad, C, EPI_GELU_TANH); if (rc) return rc;
+        rc = gemm(c, c->v_mlp, c->vit_ipad, L.w2, c->vit_ipad, L.b2, c->v_h, C, c->v_h, C, M, C, c->vit_ipad, EPI_RESID); if (rc) return rc;
+    }
+    if (g.vit_post_layernorm) { HIPCHK(c, launch_layernorm(dt, c->v_h, c->post_w, c->post_b, c->v_h, M, C, g.vit_ln_eps, st)); }
+    rc = gemm(c, c->v_h, C, c->p0w, C, c->p0b, nullptr, 0, c->v_p1, H, M, H, C, EPI_GELU_ERF); if (rc) return rc;
+    rc = gemm(c, c->v_p1, H, c->p2w, H, c->p2b, nullptr, 0, c->v_p2, H, M, H, H, EPI_NONE); if (rc) return rc;
+    { ProfScope ps(c, MMD_K_OTHER, 0, 0); HIPCHK(c, launch_pool(dt, c->v_p2, out, B, c->vit_grid, H, g.pool_mode, g.pool_stride, st)); }
+    c->last_vit_B = B;
+    return MMD_OK;
+}
+
+extern "C" int mmd_vit_debug_tap(mmd_ctx* c, int stage, void* out, int64_t out_elems) {
+    NEED_FINAL(c);
+    int64_t M = (int64_t)c->last_vit_B * c->vit_tokens;
+    int64_t n = M * (stage == 0 ? c->cfg.vit_hidden : c->cfg.hidden_size);
+    if (stage < 0 || stage > 1 || out_elems < n) FAIL(c, MMD_EINVAL, "bad tap request");
+    HIPCHK(c, hipMemcpyAsync(out, stage == 0 ? c->v_h : c->v_p2, (size_t)n * es(c), hipMemcpyDeviceToDevice, c->stream));
+    return MMD_OK;
+}
+
+// Pillow's bicubic tap tables (src/libImaging/Resample.c precompute_coeffs + normalize_coeffs_8bpc)
+static double bicubic_filter(double x) {
+    const double a = -0.5;
+    if (x < 0) x = -x;
+    if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
+    if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
+    return 0.0;
+}
+static void pil_coeffs(int in_size, int out_size, std::vector<int32_t>& coef, std::vector<int32_t>& bounds, int& ksize) {
+    double scale = (double)in_size / out_size, filterscale = scale < 1.0 ? 1.0 : scale;
+    double support = 2.0 * filterscale;
+    ksize = (int)ceil(support) * 2 + 1;
+    coef.assign((size_t)out_size * ksize, 0); bounds.assign((size_t)out_size * 2, 0);
+    std::vector<double> k(ksize);
+    for (int xx = 0; xx < out_size; ++xx) {
+        double center = (xx + 0.5) * scale, ww = 0.0, ss = 1.0 / filterscale;
+        int xmin = (int)(center - support + 0.5); if (xmin < 0) xmin = 0;
+        int xmax = (int)(center + support + 0.5); if (xmax > in_size) xmax = in_size;
+        xmax -= xmin;
+        for (int x = 0; x < ksize; ++x) k[x] = 0.0;
+        for (int x = 0; x < xmax; ++x) { double w = bicubic_filter((x + xmin - center + 0.5) * ss); k[x] = w; ww += w; }
+        for (int x = 0; x < xmax; ++x) if (ww != 0.0) k[x] /= ww;
+        for (int x = 0; x < ksize; ++x) coef[(size_t)xx * ksize + x] = k[x] < 0 ? (int32_t)(-0.5 + k[x] * (1 << 22)) : (int32_t)(0.5 + k[x] * (1 << 22));
+        bounds[2 * xx] = xmin; bounds[2 * xx + 1] = xmax;
+    }
+}
+
+extern "C" int mmd_preprocess_frames(mmd_ctx* c, const uint8_t* frames, int T, int R, void* pixel_values) {
+    if (!c || !frames || !pixel_values) return MMD_EINVAL;
+    hipSetDevice(c->device);
+    if (T <= 0) return MMD_OK;
+    const int size = c->cfg.vit_image;
+    if (R != size && c->pp_R != R) {
+        std::vector<int32_t> coef, bounds; int ks;
+        pil_coeffs(R, size, coef, bounds, ks);
+        if (c->pp_coef) { dev_free(c, c->pp_coef); dev_free(c, c->pp_bounds); }
+        int rc = dev_alloc(c, (void**)&c->pp_coef, coef.size() * 4); if (rc) return rc;
+        rc = dev_alloc(c, (void**)&c->pp_bounds, bounds.size() * 4); if (rc) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->pp_coef, coef.data(), coef.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->pp_bounds, bounds.data(), bounds.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->pp_R = R; c->pp_ksize = ks;
+    }
+    size_t need = (size_t)T * 3 * R * size;
+    if (R != size && need > c->pp_tmp_bytes) {
+        if (c->pp_tmp) dev_free(c, c->pp_tmp);
+        int rc = dev_alloc(c, (void**)&c->pp_tmp, need, false); if (rc) return rc;
+        c->pp_tmp_bytes = need;
+    }
+    ProfScope ps(c, MMD_K_OTHER, 0, 0);
+    HIPCHK(c, launch_preprocess(c->cfg.dtype, frames, T, R, size, c->pp_coef, c->pp_bounds, c->pp_ksize, c->pp_tmp, pixel_values, c->stream));
+    return MMD_OK;
+}
+
+// ---- language ----------------------------------------------------------------------------------------------------------
+extern "C" int mmd_embed_tokens(mmd_ctx* c, const int64_t* ids, int k, void* out) {
+    NEED_FINAL(c);
+    ProfScope ps(c, MMD_K_OTHER, 0, 0);
+    HIPCHK(c, launch_embed(c->cfg.dtype, c->embed, ids, k, c->cfg.hidden_size, c->cfg.vocab_size, out, c->stream));
+    return MMD_OK;
+}
+
+static size_t kv_layer_elems(const mmd_ctx* c, int64_t cap) { return (size_t)c->cfg.num_kv_heads * cap * c->cfg.head_dim; }
+
+extern "C" int mmd_stream_create(mmd_ctx* c, int64_t initial_tokens, mmd_stream** out) {
+    if (!c || !out) return MMD_EINVAL;
+    hipSetDevice(c->device);
+    if (initial_tokens < 256) initial_tokens = 256;
+    initial_tokens = round_up(initial_tokens, 64);
+    mmd_stream* s = new mmd_stream();
+    s->ctx = c; s->cap = initial_tokens; s->len = 0;
+    size_t bytes = kv_layer_elems(c, s->cap) * c->cfg.num_layers * es(c);
+    hipError_t e1 = hipMalloc(&s->K, bytes), e2 = hipMalloc(&s->V, bytes);
+    if (e1 != hipSuccess || e2 != hipSuccess) { if (s->K) hipFree(s->K); if (s->V) hipFree(s->V); delete s; FAIL(c, MMD_ENOMEM, "KV arena of %lld tokens (%zu bytes x2) does not fit", (long long)initial_tokens, bytes); }
+    *out = s;
+    return MMD_OK;
+}
+extern "C" void mmd_stream_destroy(mmd_stream* s) {
+    if (!s) return;
+    hipSetDevice(s->ctx->device);
+    hipStreamSynchronize(s->ctx->stream);
+    hipFree(s->K); hipFree(s->V);
+    delete s;
+}
+extern "C" int64_t mmd_kv_len(const mmd_stream* s) { return s ? s->len : -1; }
+extern "C" int64_t mmd_kv_capacity(const mmd_stream* s) { return s ? s->cap : -1; }
+extern "C" int mmd_kv_truncate(mmd_stream* s, int64_t n) {
+    if (!s) return MMD_EINVAL;
+    if (n < 0 || n > s->len) FAIL(s->ctx, MMD_ERANGE, "kv_truncate(%lld) outside [0, %lld]", (long long)n, (long long)s->len);
+    s->len = n;
+    return MMD_OK;
+}
+
+static int kv_reserve(mmd_ctx* c, mmd_stream* s, int64_t need) {
+    if (need <= s->cap) return MMD_OK;
+    int64_t ncap = s->cap * 2; while (ncap < need) ncap *= 2;
+    size_t e = es(c);
+    size_t bytes = kv_layer_elems(c, ncap) * c->cfg.num_layers * e;
+    void *nK = nullptr, *nV = nullptr;
+    if (hipMalloc(&nK, bytes) != hipSuccess || hipMalloc(&nV, bytes) != hipSuccess) { if (nK) hipFree(nK); FAIL(c, MMD_ENOMEM, "cannot grow KV arena to %lld tokens", (long long)ncap); }
+    size_t rows = (size_t)c->cfg.num_layers * c->cfg.num_kv_heads;
+    size_t w = (size_t)s->len * c->cfg.head_dim * e;
+    if (w) {
+        HIPCHK(c, hipMemcpy2DAsync(nK, (size_t)ncap * c->cfg.head_dim * e, s->K, (size_t)s->cap * c->cfg.head_dim * e, w, rows, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpy2DAsync(nV, (size_t)ncap * c->cfg.head_dim * e, s->V, (size_t)s->cap * c->cfg.head_dim * e, w, rows, hipMemcpyDeviceToDevice, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipFree(s->K); hipFree(s->V);
+    s->K = nK; s->V = nV; s->cap = ncap;
+    return MMD_OK;
+}
+
+extern "C" int mmd_llm_step(mmd_ctx* c, mmd_stream* s, const void* embeds, int S, void* hidden_out) {
+    NEED_FINAL(c);
+    if (!s || s->ctx != c) FAIL(c, MMD_EINVAL, "stream does not belong to this context");
+    if (S <= 0) return MMD_OK;
+    const mmd_config& g = c->cfg; const int dt = g.dtype; const size_t e = es(c); hipStream_t st = c->stream;
+    if (S > g.max_step_tokens) FAIL(c, MMD_ERANGE, "step of %d tokens exceeds max_step_tokens %d", S, g.max_step_tokens);
+    int rc = kv_reserve(c, s, s->len + S); if (rc) return rc;
+    const int H = g.hidden_size, I = g.intermediate_size, nh = g.num_heads, nkv = g.num_kv_heads, d = g.head_dim;
+    const int64_t n = s->len;
+    HIPCHK(c, hipMemcpyAsync(c->l_h, embeds, (size_t)S * H * e, hipMemcpyDeviceToDevice, st));
+    const size_t layer_elems = kv_layer_elems(c, s->cap);
+    for (int i = 0; i < g.num_layers; ++i) {
+        LlmLayer& L = c->L[i];
+        void* Kl = (char*)s->K + (size_t)i * layer_elems * e;
+        void* Vl = (char*)s->V + (size_t)i * layer_elems * e;
+        { ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * S * H * e, 0); HIPCHK(c, launch_rmsnorm(dt, c->l_h, L.ln1, c->l_xn, S, H, g.rms_norm_eps, st)); }
+        rc = gemm(c, c->l_xn, H, L.wqkv, H, L.bqkv, nullptr, 0, c->l_qkv, c->qkv_w, S, c->qkv_w, H, EPI_NONE); if (rc) return rc;
+        { ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * S * c->qkv_w * e, 0);
+          HIPCHK(c, launch_rope_append(dt, c->l_qkv, S, nh, nkv, d, c->inv_freq, n, c->l_q, Kl, Vl, s->cap, st)); }
+        {
+            AttnArgs a; memset(&a, 0, sizeof(a));
+            a.q = c->l_q; a.ldq = (int64_t)nh * d; a.K = Kl; a.V = Vl; a.k_hs = s->cap * d; a.k_ts = d; a.v_hs = s->cap * d; a.v_ts = d;
+            a.out = c->l_attn; a.ldo = (int64_t)nh * d; a.S = S; a.nh = nh; a.nkv = nkv; a.d = d; a.n_ctx = n; a.causal = 1;
+            a.batch = 1; a.ws = c->attn_ws; a.ws_bytes = c->attn_bytes; a.variant = 0;
+            double kvb = 2.0 * (double)(n + S) * nkv * d * e;
+            ProfScope ps(c, MMD_K_ATTN_LLM, kvb + 2.0 * S * nh * d * e, 4.0 * S * (double)(n + S) * nh * d);
+            HIPCHK(c, launch_attention(dt, a, st));
+        }
+        rc = gemm(c, c->l_attn, (int64_t)nh * d, L.wo, (int64_t)nh * d, nullptr, c->l_h, H, c->l_h, H, S, H, nh * d, EPI_RESID); if (rc) return rc;
+        { ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * S * H * e, 0); HIPCHK(c, launch_rmsnorm(dt, c->l_h, L.ln2, c->l_xn, S, H, g.rms_norm_eps, st)); }
+        rc = gemm(c, c->l_xn, H, L.wgu, H, nullptr, nullptr, 0, c->l_act, I, S, 2 * I, H, EPI_SWIGLU); if (rc) return rc;
+        rc = gemm(c, c->l_act, I, L.wdown, I, nullptr, c->l_h, H, c->l_h, H, S, H, I, EPI_RESID); if (rc) return rc;
+    }
+    { ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * S * H * e, 0); HIPCHK(c, launch_rmsnorm(dt, c->l_h, c->fnorm, c->l_hid, S, H, g.rms_norm_eps, st)); }
+    if (hidden_out) HIPCHK(c, hipMemcpyAsync(hidden_out, c->l_hid, (size_t)S * H * e, hipMemcpyDeviceToDevice, st));
+    s->len = n + S;
+    return MMD_OK;
+}
+
+extern "C" int mmd_video_heads(mmd_ctx* c, const void* hidden, int M, float* out) {
+    NEED_FINAL(c);
+    ProfScope ps(c, MMD_K_OTHER, 0, 0);
+    HIPCHK(c, launch_heads(c->cfg.dtype, hidden, c->cfg.hidden_size, nullptr, M, c->heads4, c->cfg.hidden_size, out, c->stream));
+    return MMD_OK;
+}
+
+extern "C" int mmd_lm_head(mmd_ctx* c, const void* hidden, int M, float* logits) {
+    NEED_FINAL(c);
+    const int H = c->cfg.hidden_size, V = c->cfg.vocab_size;
+    return gemm(c, hidden, H, c->lm_head, H, nullptr, nullptr, 0, logits, V, M, V, H, EPI_NONE, 1);
+}
+
+extern "C" int mmd_frame_step(mmd_ctx* c, mmd_stream* s, const void* embeds, int S, const int32_t* rows_host, int n_rows, float* out_host) {
+    NEED_FINAL(c);
+    if (n_rows < 0 || n_rows > S) FAIL(c, MMD_EINVAL, "bad head row count");
+    int rc = mmd_llm_step(c, s, embeds, S, nullptr); if (rc) return rc;
+    if (n_rows == 0) return MMD_OK;
+    for (int i = 0; i < n_rows; ++i) { if (rows_host[i] < 0 || rows_host[i] >= S) FAIL(c, MMD_ERANGE, "head row %d outside the step", rows_host[i]); c->rows_host[i] = rows_host[i]; }
+    hipStream_t st = c->stream;
+    HIPCHK(c, hipMemcpyAsync(c->rows_dev, c->rows_host, sizeof(int32_t) * n_rows, hipMemcpyHostToDevice, st));
+    { ProfScope ps(c, MMD_K_OTHER, 0, 0);
+      HIPCHK(c, launch_heads(c->cfg.dtype, c->l_hid, c->cfg.hidden_size, c->rows_dev, n_rows, c->heads4, c->cfg.hidden_size, c->heads_dev, st)); }
+    HIPCHK(c, hipMemcpyAsync(c->heads_host, c->heads_dev, sizeof(float) * 4 * n_rows, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    memcpy(out_host, c->heads_host, sizeof(float) * 4 * n_rows);
+    return MMD_OK;
+}
+
+extern "C" int mmd_greedy_generate(mmd_ctx* c, mmd_stream* s, const void* prompt_embeds, int S, int64_t eos_id, float rep_penalty,
+                                   int64_t* prev_ids_host, int* n_prev, int prev_cap, int64_t* out_ids_host, int max_new, int* n_out) {
+    NEED_FINAL(c);
+    if (!n_out || !out_ids_host || max_new <= 0) FAIL(c, MMD_EINVAL, "bad generate arguments");
+    const mmd_config& g = c->cfg; hipStream_t st = c->stream; const int H = g.hidden_size; const size_t e = es(c);
+    const bool pen = rep_penalty > 0.f;
+    int np = (pen && n_prev) ? *n_prev : 0;
+    if (np > c->prev_cap) FAIL(c, MMD_ERANGE, "repetition-penalty list too long");
+    if (np > 0) HIPCHK(c, hipMemcpyAsync(c->prev_dev, prev_ids_host, sizeof(int64_t) * np, hipMemcpyHostToDevice, st));
+    const void* x = prompt_embeds; int xs = S;
+    int produced = 0;
+    for (int i = 0; i < max_new; ++i) {
+        int rc = mmd_llm_step(c, s, x, xs, nullptr); if (rc) return rc;
+        const void* last = (const char*)c->l_hid + (size_t)(xs - 1) * H * e;
+        rc = gemm(c, last, H, c->lm_head, H, nullptr, nullptr, 0, c->logits_ws, g.vocab_size, 1, g.vocab_size, H, EPI_NONE, 1); if (rc) return rc;
+        { ProfScope ps(c, MMD_K_OTHER, 0, 0);
+          HIPCHK(c, launch_argmax_penalty(c->logits_ws, g.vocab_size, c->prev_dev, pen ? np : 0, pen ? rep_penalty : 1.f, c->tok_dev, st)); }
+        HIPCHK(c, hipMemcpyAsync(c->tok_host, c->tok_dev, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        int64_t tok = c->tok_host[0];
+        out_ids_host[produced++] = tok;
+        if (tok == eos_id) break;
+        if (pen) {
+            if (np < c->prev_cap) HIPCHK(c, hipMemcpyAsync(c->prev_dev + np, c->tok_dev, sizeof(int64_t), hipMemcpyDeviceToDevice, st));
+            if (prev_ids_host && np < prev_cap) prev_ids_host[np] = tok;
+            ++np;
+        }
+        if (i + 1 < max_new) {
+            HIPCHK(c, launch_embed(g.dtype, c->embed, c->tok_dev, 1, H, g.vocab_size, c->gen_embed, st));
+            x = c->gen_embed; xs = 1;
+        }
+    }
+    *n_out = produced;
+    if (pen && n_prev) *n_prev = np;
+    return MMD_OK;
+}
+
+// ---- measurement -------------------------------------------------------------------------------------------------------
+extern "C" int mmd_prof_enable(mmd_ctx* c, int on) { if (!c) return MMD_EINVAL; if (!on) prof_drain(c); c->prof.on = on != 0; return MMD_OK; }
+extern "C" int mmd_prof_reset(mmd_ctx* c) {
+    if (!c) return MMD_EINVAL;
+    prof_drain(c);
+    for (int i = 0; i < MMD_K_COUNT; ++i) { c->prof.ms[i] = 0; c->prof.n[i] = 0; c->prof.bytes[i] = 0; c->prof.flops[i] = 0; }
+    return MMD_OK;
+}
+extern "C" int mmd_prof_read(mmd_ctx* c, double* ms, int64_t* n, double* bytes, double* flops) {
+    if (!c) return MMD_EINVAL;
+    prof_drain(c);
+    for (int i = 0; i < MMD_K_COUNT; ++i) { if (ms) ms[i] = c->prof.ms[i]; if (n) n[i] = c->prof.n[i]; if (bytes) bytes[i] = c->prof.bytes[i]; if (flops) flops[i] = c->prof.flops[i]; }
+    return MMD_OK;
+}
+
+// ---- raw operator entry points (parity tests) ---------------------------------------------------------------------------
+extern "C" int mmd_op_gemm(mmd_ctx* c, const void* X, const void* W, const void* bias, const void* R, void* Y, int M, int N, int K, int epi,
+                           int out_f32, int variant) {
+    if (!c) return MMD_EINVAL;
+    hipSetDevice(c->device);
+    if (!c->splitk_ws) { c->splitk_bytes = (size_t)64 << 20; int rc = dev_alloc(c, (void**)&c->splitk_ws, c->splitk_bytes); if (rc) return rc; }
+    int NO = epi == EPI_SWIGLU ? N / 2 : N;
+    return gemm(c, X, K, W, K, bias, R, NO, Y, NO, M, N, K, epi, out_f32, variant);
+}
+extern "C" int mmd_op_rmsnorm(mmd_ctx* c, const void* x, const void* w, void* y, int M, int H, float eps) {
+    if (!c) return MMD_EINVAL; hipSetDevice(c->device);
+    HIPCHK(c, launch_rmsnorm(c->cfg.dtype, x, w, y, M, H, eps, c->stream)); return MMD_OK;
+}
+extern "C" int mmd_op_layernorm(mmd_ctx* c, const void* x, const void* w, const void* b, void* y, int M, int H, float eps) {
+    if (!c) return MMD_EINVAL; hipSetDevice(c->device);
+    HIPCHK(c, launch_layernorm(c->cfg.dtype, x, w, b, y, M, H, eps, c->stream)); return MMD_OK;
+}
+extern "C" int mmd_op_rope_append(mmd_ctx* c, void* qkv, int S, int nh, int nkv, int d, float theta, int64_t pos0, void* q_out, void* Kc, void* Vc, int64_t cap) {
+    if (!c) return MMD_EINVAL; hipSetDevice(c->device);
+    std::vector<float> t(d / 2);
+    for (int i = 0; i < d / 2; ++i) t[i] = (float)(1.0 / std::pow((double)theta, (double)(2 * i) / (double)d));
+    float* dev = nullptr;
+    HIPCHK(c, hipMalloc((void**)&dev, sizeof(float) * (d / 2)));
+    HIPCHK(c, hipMemcpyAsync(dev, t.data(), sizeof(float) * (d / 2), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, launch_rope_append(c->cfg.dtype, qkv, S, nh, nkv, d, dev, pos0, q_out, Kc, Vc, cap, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipFree(dev);
+    return MMD_OK;
+}
+extern "C" int mmd_op_attention(mmd_ctx* c, const void* q, const void* Kc, const void* Vc, void* out, int S, int nh, int nkv, int d, int64_t n_ctx,
+                                int64_t cap, int causal, int variant) {
+    if (!c) return MMD_EINVAL; hipSetDevice(c->device);
+    if (!c->attn_ws) { c->attn_bytes = (size_t)128 << 20; int rc = dev_alloc(c, (void**)&c->attn_ws, c->attn_bytes); if (rc) return rc; }
+    AttnArgs a; memset(&a, 0, sizeof(a));
+    a.q = q; a.ldq = (int64_t)nh * d; a.K = Kc; a.V = Vc; a.k_hs = cap * d; a.k_ts = d; a.v_hs = cap * d; a.v_ts = d; a.out = out; a.ldo = (int64_t)nh * d;
+    a.S = S; a.nh = nh; a.nkv = nkv; a.d = d; a.n_ctx = n_ctx; a.causal = causal; a.batch = 1; a.ws = c->attn_ws; a.ws_bytes = c->attn_bytes; a.variant = variant;
+    HIPCHK(c, launch_attention(c->cfg.dtype, a, c->stream));
+    return MMD_OK;
+}
+extern "C" int mmd_op_pool(mmd_ctx* c, const void* x, void* y, int B, int grid, int H, int mode, int stride) {
+    if (!c) return MMD_EINVAL; hipSetDevice(c->device);
+    HIPCHK(c, launch_pool(c->cfg.dtype, x, y, B, grid, H, mode, stride, c->stream)); return MMD_OK;
+}

@@ -1,0 +1,432 @@
+// ops.hip -- the HBM-bound operators of the path: norms, RoPE + KV append, embedding gather, patch im2col, pooling,
+// response heads, greedy sampling, layout helpers.  wave64 shuffles for reductions, 16-byte vector accesses.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------------------------
+// RMSNorm -- Qwen2RMSNorm.forward (transformers qwen2/modeling_qwen2.py:248-253): fp32 statistics,
+// y = w * cast(x * rsqrt(mean(x^2) + eps)).  One wave per row.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void rmsnorm_kernel(const T* __restrict__ x, const T* __restrict__ w, T* __restrict__ y, int M, int H, float eps) {
+    int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const T* xr = x + (long long)row * H;
+    T* yr = y + (long long)row * H;
+    float ss = 0.f;
+    if constexpr (sizeof(T) == 2) {
+        if ((H & 7) == 0) {
+            for (int c = lane * 8; c < H; c += 512) {
+                s16x8_t v = *reinterpret_cast<const s16x8_t*>(xr + c);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { float f = bf2f((bf16_t)v[e]); ss += f * f; }
+            }
+        } else for (int c = lane; c < H; c += 64) { float f = to_f<T>(xr[c]); ss += f * f; }
+    } else for (int c = lane; c < H; c += 64) { float f = to_f<T>(xr[c]); ss += f * f; }
+    ss = wave_sum(ss);
+    float inv = rsqrtf(ss / (float)H + eps);
+    if constexpr (sizeof(T) == 2) {
+        if ((H & 7) == 0) {
+            for (int c = lane * 8; c < H; c += 512) {
+                s16x8_t v = *reinterpret_cast<const s16x8_t*>(xr + c);
+                s16x8_t g = *reinterpret_cast<const s16x8_t*>(w + c);
+                s16x8_t o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (short)f2bf(bf2f((bf16_t)g[e]) * bf2f(f2bf(bf2f((bf16_t)v[e]) * inv)));
+                *reinterpret_cast<s16x8_t*>(yr + c) = o;
+            }
+            return;
+        }
+    }
+    for (int c = lane; c < H; c += 64) yr[c] = from_f<T>(to_f<T>(w[c]) * rnd<T>(to_f<T>(xr[c]) * inv));
+}
+
+hipError_t launch_rmsnorm(int dtype, const void* x, const void* w, void* y, int M, int H, float eps, hipStream_t st) {
+    if (M <= 0) return hipSuccess;
+    dim3 grid(cdiv(M, 4)), block(256);
+    if (dtype == MMD_F32) hipLaunchKernelGGL(rmsnorm_kernel<float>, grid, block, 0, st, (const float*)x, (const float*)w, (float*)y, M, H, eps);
+    else hipLaunchKernelGGL(rmsnorm_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, M, H, eps);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// LayerNorm -- nn.LayerNorm of SiglipEncoderLayer (siglip/modeling_siglip.py:329-331): fp32 mean / biased variance.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void layernorm_kernel(const T* __restrict__ x, const T* __restrict__ w, const T* __restrict__ b, T* __restrict__ y, int M, int H, float eps) {
+    int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const T* xr = x + (long long)row * H;
+    T* yr = y + (long long)row * H;
+    float s = 0.f;
+    for (int c = lane; c < H; c += 64) s += to_f<T>(xr[c]);
+    float mu = wave_sum(s) / (float)H;
+    float v = 0.f;
+    for (int c = lane; c < H; c += 64) { float d = to_f<T>(xr[c]) - mu; v += d * d; }
+    float inv = rsqrtf(wave_sum(v) / (float)H + eps);
+    for (int c = lane; c < H; c += 64) yr[c] = from_f<T>((to_f<T>(xr[c]) - mu) * inv * to_f<T>(w[c]) + to_f<T>(b[c]));
+}
+
+hipError_t launch_layernorm(int dtype, const void* x, const void* w, const void* b, void* y, int M, int H, float eps, hipStream_t st) {
+    if (M <= 0) return hipSuccess;
+    dim3 grid(cdiv(M, 4)), block(256);
+    if (dtype == MMD_F32) hipLaunchKernelGGL(layernorm_kernel<float>, grid, block, 0, st, (const float*)x, (const float*)w, (const float*)b, (float*)y, M, H, eps);
+    else hipLaunchKernelGGL(layernorm_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)y, M, H, eps);
+    return hipGetLastError();
+}
+
+// x[m, :] += add[m % period, :]   (learned position embedding, siglip/modeling_siglip.py:184)
+template <typename T>
+__global__ void add_rows_kernel(T* __restrict__ x, const T* __restrict__ add, long long total, int H, int period) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    long long m = i / H; int c = (int)(i % H);
+    x[i] = from_f<T>(to_f<T>(x[i]) + to_f<T>(add[(m % period) * H + c]));
+}
+hipError_t launch_add_rows(int dtype, void* x, const void* add, int M, int H, int period, hipStream_t st) {
+    long long total = (long long)M * H;
+    if (total <= 0) return hipSuccess;
+    dim3 grid(cdiv(total, 256)), block(256);
+    if (dtype == MMD_F32) hipLaunchKernelGGL(add_rows_kernel<float>, grid, block, 0, st, (float*)x, (const float*)add, total, H, period);
+    else hipLaunchKernelGGL(add_rows_kernel<bf16_t>, grid, block, 0, st, (bf16_t*)x, (const bf16_t*)add, total, H, period);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// RoPE + KV append -- Qwen2RotaryEmbedding + apply_rotary_pos_emb + cache update (qwen2/modeling_qwen2.py:84-135,
+// 218-222).  cos/sin are computed in fp32 from position = pos0 + s, then rounded to the storage type; the rotate-half
+// form q*cos + rotate_half(q)*sin is evaluated with the reference's rounding (each product, then the sum).
+// Input: fused qkv rows [S][(nh + 2 nkv) d].  Output: q_out [S][nh d]; K/V arena [nkv][cap][d] at token pos0 + s.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void rope_append_kernel(const T* __restrict__ qkv, int S, int nh, int nkv, int d, const float* __restrict__ inv_freq_tab, long long pos0,
+                                   T* __restrict__ q_out, T* __restrict__ Kc, T* __restrict__ Vc, long long cap) {
+    int s = blockIdx.x;
+    int head = blockIdx.y;                 // 0..nh-1 q heads, nh..nh+nkv-1 k heads, then v heads
+    int half = d >> 1;
+    int row_w = (nh + 2 * nkv) * d;
+    const T* src = qkv + (long long)s * row_w + (long long)head * d;
+    long long pos = pos0 + s;
+    if (head >= nh + nkv) {               // V: plain copy into the arena
+        int kvh = head - nh - nkv;
+        T* dst = Vc + ((long long)kvh * cap + pos) * d;
+        for (int i = threadIdx.x; i < d; i += blockDim.x) dst[i] = src[i];
+        return;
+    }
+    T* dst = head < nh ? q_out + (long long)s * nh * d + (long long)head * d : Kc + ((long long)(head - nh) * cap + pos) * d;
+    for (int i = threadIdx.x; i < half; i += blockDim.x) {
+        float ang = (float)pos * inv_freq_tab[i];       // fp32 product, like the reference's fp32 outer product
+        float c = rnd<T>(cosf(ang)), sn = rnd<T>(sinf(ang));
+        float x1 = to_f<T>(src[i]), x2 = to_f<T>(src[i + half]);
+        // out[i] = x1*cos + (-x2)*sin ; out[i+half] = x2*cos + x1*sin
+        float o1 = rnd<T>(x1 * c) + rnd<T>(-x2 * sn);
+        float o2 = rnd<T>(x2 * c) + rnd<T>(x1 * sn);
+        dst[i] = from_f<T>(o1);
+        dst[i + half] = from_f<T>(o2);
+    }
+}
+
+hipError_t launch_rope_append(int dtype, const void* qkv, int S, int nh, int nkv, int d, const float* l2, int64_t pos0, void* q_out,
+                              void* Kc, void* Vc, int64_t cap, hipStream_t st) {
+    if (S <= 0) return hipSuccess;
+    dim3 grid(S, nh + 2 * nkv), block(64);
+    if (dtype == MMD_F32) hipLaunchKernelGGL(rope_append_kernel<float>, grid, block, 0, st, (const float*)qkv, S, nh, nkv, d, l2, (long long)pos0, (float*)q_out, (float*)Kc, (float*)Vc, (long long)cap);
+    else hipLaunchKernelGGL(rope_append_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)qkv, S, nh, nkv, d, l2, (long long)pos0, (bf16_t*)q_out, (bf16_t*)Kc, (bf16_t*)Vc, (long long)cap);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// embedding gather -- nn.Embedding (qwen2/modeling_qwen2.py:322); ids clamped like joint_embed (modeling_live.py:44)
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void embed_kernel(const T* __restrict__ table, const int64_t* __restrict__ ids, int H, long long vocab, T* __restrict__ out) {
+    long long id = ids[blockIdx.x];
+    if (id < 0) id = 0;
+    if (id >= vocab) id = vocab - 1;
+    const T* src = table + id * H;
+    T* dst = out + (long long)blockIdx.x * H;
+    for (int c = threadIdx.x; c < H; c += blockDim.x) dst[c] = src[c];
+}
+hipError_t launch_embed(int dtype, const void* table, const int64_t* ids, int k, int H, int64_t vocab, void* out, hipStream_t st) {
+    if (k <= 0) return hipSuccess;
+    if (dtype == MMD_F32) hipLaunchKernelGGL(embed_kernel<float>, dim3(k), dim3(256), 0, st, (const float*)table, ids, H, (long long)vocab, (float*)out);
+    else hipLaunchKernelGGL(embed_kernel<bf16_t>, dim3(k), dim3(256), 0, st, (const bf16_t*)table, ids, H, (long long)vocab, (bf16_t*)out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// patch im2col -- SiglipVisionEmbeddings conv(k = stride = patch) as a GEMM operand (siglip/modeling_siglip.py:124-179):
+// row (b, gy, gx), column (c, ky, kx) in conv-weight flatten order, zero-padded to Kpad.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void im2col_kernel(const T* __restrict__ px, int img, int patch, int grid, int Kpad, T* __restrict__ out) {
+    int row = blockIdx.x;                              // b*grid*grid + gy*grid + gx
+    int b = row / (grid * grid), rem = row % (grid * grid), gy = rem / grid, gx = rem % grid;
+    int K = 3 * patch * patch;
+    for (int k = threadIdx.x; k < Kpad; k += blockDim.x) {
+        T v = 0;
+        if (k < K) {
+            int c = k / (patch * patch), r2 = k % (patch * patch), ky = r2 / patch, kx = r2 % patch;
+            v = px[(((long long)b * 3 + c) * img + gy * patch + ky) * img + gx * patch + kx];
+        }
+        out[(long long)row * Kpad + k] = v;
+    }
+}
+hipError_t launch_im2col(int dtype, const void* px, int B, int img, int patch, int grid, int Kpad, void* out, hipStream_t st) {
+    int rows = B * grid * grid;
+    if (rows <= 0) return hipSuccess;
+    if (dtype == MMD_F32) hipLaunchKernelGGL(im2col_kernel<float>, dim3(rows), dim3(256), 0, st, (const float*)px, img, patch, grid, Kpad, (float*)out);
+    else hipLaunchKernelGGL(im2col_kernel<bf16_t>, dim3(rows), dim3(256), 0, st, (const bf16_t*)px, img, patch, grid, Kpad, (bf16_t*)out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// post_projector_pooling (models/live_llava/video_head_live_llava_qwen.py:100-119) on token-major [B, g*g, H]:
+// bilinear = F.interpolate(size=ceil(g/stride), align_corners=False); average/max = pool2d(stride).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bilinear_tap(int o, int n_in, int n_out, int& i0, int& i1, float& lam) {
+    float scale = (float)n_in / (float)n_out;
+    float src = ((float)o + 0.5f) * scale - 0.5f;
+    if (src < 0.f) src = 0.f;
+    i0 = (int)floorf(src);
+    if (i0 > n_in - 1) i0 = n_in - 1;
+    i1 = i0 + 1 < n_in ? i0 + 1 : n_in - 1;
+    lam = src - (float)i0;
+}
+template <typename T>
+__global__ void pool_kernel(const T* __restrict__ x, T* __restrict__ y, int g, int H, int mode, int stride, int out) {
+    int b = blockIdx.z, oy = blockIdx.y / out, ox = blockIdx.y % out;
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= H) return;
+    const T* xb = x + (long long)b * g * g * H;
+    float r;
+    if (mode == MMD_POOL_BILINEAR) {
+        int y0, y1, x0, x1; float ly, lx;
+        bilinear_tap(oy, g, out, y0, y1, ly);
+        bilinear_tap(ox, g, out, x0, x1, lx);
+        float a = to_f<T>(xb[((long long)y0 * g + x0) * H + c]), bq = to_f<T>(xb[((long long)y0 * g + x1) * H + c]);
+        float cq = to_f<T>(xb[((long long)y1 * g + x0) * H + c]), dq = to_f<T>(xb[((long long)y1 * g + x1) * H + c]);
+        float top = a * (1.f - lx) + bq * lx, bot = cq * (1.f - lx) + dq * lx;
+        r = top * (1.f - ly) + bot * ly;
+    } else {
+        float acc = mode == MMD_POOL_MAX ? -INFINITY : 0.f;
+        for (int dy = 0; dy < stride; ++dy)
+            for (int dx = 0; dx < stride; ++dx) {
+                float v = to_f<T>(xb[((long long)(oy * stride + dy) * g + ox * stride + dx) * H + c]);
+                acc = mode == MMD_POOL_MAX ? fmaxf(acc, v) : acc + v;
+            }
+        r = mode == MMD_POOL_MAX ? acc : acc / (float)(stride * stride);
+    }
+    y[(((long long)b * out + oy) * out + ox) * H + c] = from_f<T>(r);
+}
+hipError_t launch_pool(int dtype, const void* x, void* y, int B, int grid, int H, int mode, int stride, hipStream_t st) {
+    int out = mode == MMD_POOL_BILINEAR ? (grid + stride - 1) / stride : grid / stride;
+    if (B <= 0 || out <= 0) return hipSuccess;
+    dim3 g(cdiv(H, 256), out * out, B), block(256);
+    if (dtype == MMD_F32) hipLaunchKernelGGL(pool_kernel<float>, g, block, 0, st, (const float*)x, (float*)y, grid, H, mode, stride, out);
+    else hipLaunchKernelGGL(pool_kernel<bf16_t>, g, block, 0, st, (const bf16_t*)x, (bf16_t*)y, grid, H, mode, stride, out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// informative_head / relevance_head (models/live_llava/video_head_live_llava_qwen.py:77-78,160-161): [4,H] x selected rows,
+// output rounded through the storage type (the reference's GEMM output dtype) then widened: `.float()`.
+// One wave per (row, head output).
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void heads_kernel(const T* __restrict__ hidden, long long ldh, const int32_t* __restrict__ rows, const T* __restrict__ W4, int H, float* __restrict__ out) {
+    int m = blockIdx.x, o = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int row = rows ? rows[m] : m;
+    const T* h = hidden + (long long)row * ldh;
+    const T* w = W4 + (long long)o * H;
+    float s = 0.f;
+    for (int c = lane; c < H; c += 64) s += to_f<T>(h[c]) * to_f<T>(w[c]);
+    s = wave_sum(s);
+    if (lane == 0) out[m * 4 + o] = rnd<T>(s);
+}
+hipError_t launch_heads(int dtype, const void* hidden, int64_t ldh, const int32_t* rows_dev, int M, const void* W4, int H, float* out, hipStream_t st) {
+    if (M <= 0) return hipSuccess;
+    if (dtype == MMD_F32) hipLaunchKernelGGL(heads_kernel<float>, dim3(M), dim3(256), 0, st, (const float*)hidden, (long long)ldh, rows_dev, (const float*)W4, H, out);
+    else hipLaunchKernelGGL(heads_kernel<bf16_t>, dim3(M), dim3(256), 0, st, (const bf16_t*)hidden, (long long)ldh, rows_dev, (const bf16_t*)W4, H, out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// greedy sampling: RepetitionPenaltyLogitsProcessor (score/p if score > 0 else score*p on seen ids, transformers
+// generation/logits_process.py) + argmax (first maximal index, like torch.argmax) -- models/modeling_live.py:60-72.
+// Single block; V up to a few 100k.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void argmax_penalty_kernel(const float* __restrict__ logits, int V, const int64_t* __restrict__ prev, int n_prev, float penalty,
+                                      int64_t* __restrict__ out_id) {
+    __shared__ float sv[16]; __shared__ int si[16];
+    float best = -INFINITY; int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < V; i += blockDim.x) {
+        float v = logits[i];
+        if (n_prev > 0) {
+            bool seen = false;
+            for (int j = 0; j < n_prev; ++j) if (prev[j] == i) { seen = true; break; }
+            if (seen) v = v < 0.f ? v * penalty : v / penalty;
+        }
+        if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float ov = __shfl_xor(best, o, 64); int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sv[w] = best; si[w] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < (int)(blockDim.x >> 6); ++k) if (sv[k] > best || (sv[k] == best && si[k] < bi)) { best = sv[k]; bi = si[k]; }
+        *out_id = bi;
+    }
+}
+hipError_t launch_argmax_penalty(const float* logits, int V, const int64_t* prev_ids_dev, int n_prev, float penalty, int64_t* out_id, hipStream_t st) {
+    hipLaunchKernelGGL(argmax_penalty_kernel, dim3(1), dim3(1024), 0, st, logits, V, prev_ids_dev, n_prev, penalty, out_id);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// layout helpers used at weight-load time
+// ---------------------------------------------------------------------------------------------------------------
+template <typename S, typename D>
+__global__ void convert_kernel(const S* __restrict__ s, D* __restrict__ d, long long n) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) d[i] = from_f<D>(to_f<S>(s[i]));
+}
+hipError_t launch_convert(const void* src, int sdt, void* dst, int ddt, int64_t n, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    if (sdt == MMD_F32 && ddt == MMD_F32) hipLaunchKernelGGL((convert_kernel<float, float>), dim3(blocks), dim3(256), 0, st, (const float*)src, (float*)dst, (long long)n);
+    else if (sdt == MMD_F32) hipLaunchKernelGGL((convert_kernel<float, bf16_t>), dim3(blocks), dim3(256), 0, st, (const float*)src, (bf16_t*)dst, (long long)n);
+    else if (ddt == MMD_F32) hipLaunchKernelGGL((convert_kernel<bf16_t, float>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)src, (float*)dst, (long long)n);
+    else hipLaunchKernelGGL((convert_kernel<bf16_t, bf16_t>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, (long long)n);
+    return hipGetLastError();
+}
+
+template <typename T>
+__global__ void copy_rows_kernel(const T* __restrict__ s, long long lds_, T* __restrict__ d, long long ldd, int rows, int cols) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)rows * cols) return;
+    int r = (int)(i / cols), c = (int)(i % cols);
+    d[(long long)r * ldd + c] = s[(long long)r * lds_ + c];
+}
+hipError_t launch_copy_rows(int dtype, const void* src, int64_t lds_, void* dst, int64_t ldd, int rows, int cols, hipStream_t st) {
+    long long total = (long long)rows * cols;
+    if (total <= 0) return hipSuccess;
+    if (dtype == MMD_F32) hipLaunchKernelGGL(copy_rows_kernel<float>, dim3(cdiv(total, 256)), dim3(256), 0, st, (const float*)src, (long long)lds_, (float*)dst, (long long)ldd, rows, cols);
+    else hipLaunchKernelGGL(copy_rows_kernel<bf16_t>, dim3(cdiv(total, 256)), dim3(256), 0, st, (const bf16_t*)src, (long long)lds_, (bf16_t*)dst, (long long)ldd, rows, cols);
+    return hipGetLastError();
+}
+
+// out rows: [a 0..15, b 0..15, a 16..31, b 16..31, ...]  (gate/up interleave for the SwiGLU epilogue)
+template <typename T>
+__global__ void interleave16_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, int rows, int cols) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2LL * rows * cols) return;
+    long long orow = i / cols; int c = (int)(i % cols);
+    long long blk = orow / 32; int within = (int)(orow % 32);
+    long long srow = blk * 16 + (within & 15);
+    const T* src = within < 16 ? a : b;
+    out[i] = srow < rows ? src[srow * cols + c] : (T)0;
+}
+hipError_t launch_interleave16(int dtype, const void* a, const void* b, void* out, int rows, int cols, hipStream_t st) {
+    long long total = 2LL * rows * cols;
+    if (total <= 0) return hipSuccess;
+    if (dtype == MMD_F32) hipLaunchKernelGGL(interleave16_kernel<float>, dim3(cdiv(total, 256)), dim3(256), 0, st, (const float*)a, (const float*)b, (float*)out, rows, cols);
+    else hipLaunchKernelGGL(interleave16_kernel<bf16_t>, dim3(cdiv(total, 256)), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, rows, cols);
+    return hipGetLastError();
+}
+
+template <typename T>
+__global__ void pad_cols_kernel(const T* __restrict__ s, int rows, int cols, T* __restrict__ d, int cols_pad) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)rows * cols_pad) return;
+    int r = (int)(i / cols_pad), c = (int)(i % cols_pad);
+    d[i] = c < cols ? s[(long long)r * cols + c] : (T)0;
+}
+hipError_t launch_pad_cols(int dtype, const void* src, int rows, int cols, void* dst, int cols_pad, hipStream_t st) {
+    long long total = (long long)rows * cols_pad;
+    if (total <= 0) return hipSuccess;
+    if (dtype == MMD_F32) hipLaunchKernelGGL(pad_cols_kernel<float>, dim3(cdiv(total, 256)), dim3(256), 0, st, (const float*)src, rows, cols, (float*)dst, cols_pad);
+    else hipLaunchKernelGGL(pad_cols_kernel<bf16_t>, dim3(cdiv(total, 256)), dim3(256), 0, st, (const bf16_t*)src, rows, cols, (bf16_t*)dst, cols_pad);
+    return hipGetLastError();
+}
+
+// W[out,in] += scale * B[out,r] . A[r,in] in fp32 (peft LoRA merge; models/modeling_live.py:123)
+template <typename T>
+__global__ void lora_merge_kernel(T* __restrict__ W, const float* __restrict__ A, const float* __restrict__ B, int out_f, int in_f, int r, float scale) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)out_f * in_f) return;
+    int o = (int)(i / in_f), c = (int)(i % in_f);
+    float acc = 0.f;
+    for (int k = 0; k < r; ++k) acc += B[(long long)o * r + k] * A[(long long)k * in_f + c];
+    W[i] = from_f<T>(to_f<T>(W[i]) + scale * acc);
+}
+hipError_t launch_lora_merge(int dtype, void* W, const float* A, const float* B, int out_f, int in_f, int r, float scale, hipStream_t st) {
+    long long total = (long long)out_f * in_f;
+    if (dtype == MMD_F32) hipLaunchKernelGGL(lora_merge_kernel<float>, dim3(cdiv(total, 256)), dim3(256), 0, st, (float*)W, A, B, out_f, in_f, r, scale);
+    else hipLaunchKernelGGL(lora_merge_kernel<bf16_t>, dim3(cdiv(total, 256)), dim3(256), 0, st, (bf16_t*)W, A, B, out_f, in_f, r, scale);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// image preprocess -- LLaVA SigLipImageProcessor.preprocess (test/inference.py:203): Pillow's 8-bit separable bicubic
+// resampler (horizontal pass to a uint8 temp, vertical pass; fixed-point taps with PRECISION_BITS = 22, both passes
+// round with 1 << 21 then clip8), then x * (1/255), (x - 0.5) / 0.5.  Bit-exact with Pillow; tap tables are built on
+// the host (model.cpp) exactly as Pillow's precompute_coeffs / normalize_coeffs_8bpc do.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint8_t clip8_fix(int v) { v >>= 22; return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+
+__global__ void resize_h_kernel(const uint8_t* __restrict__ in, int R, int size, const int32_t* __restrict__ coef, const int32_t* __restrict__ bounds,
+                                int ksize, uint8_t* __restrict__ tmp, long long planes) {
+    // in [planes][R][R] -> tmp [planes][R][size]
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= planes * R * size) return;
+    int xx = (int)(i % size); long long row = i / size;
+    int xmin = bounds[2 * xx], xn = bounds[2 * xx + 1];
+    const uint8_t* src = in + row * R + xmin;
+    const int32_t* k = coef + (long long)xx * ksize;
+    int acc = 1 << 21;
+    for (int x = 0; x < xn; ++x) acc += (int)src[x] * k[x];
+    tmp[i] = clip8_fix(acc);
+}
+template <typename T>
+__global__ void resize_v_norm_kernel(const uint8_t* __restrict__ tmp, int R, int size, const int32_t* __restrict__ coef, const int32_t* __restrict__ bounds,
+                                     int ksize, T* __restrict__ out, long long planes, int identity) {
+    // tmp [planes][R][size] -> out [planes][size][size], normalised
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= planes * size * size) return;
+    int xx = (int)(i % size); int yy = (int)((i / size) % size); long long pl = i / ((long long)size * size);
+    uint8_t px;
+    if (identity) px = tmp[(pl * R + yy) * size + xx];
+    else {
+        int ymin = bounds[2 * yy], yn = bounds[2 * yy + 1];
+        const int32_t* k = coef + (long long)yy * ksize;
+        int acc = 1 << 21;
+        for (int y = 0; y < yn; ++y) acc += (int)tmp[(pl * R + ymin + y) * size + xx] * k[y];
+        px = clip8_fix(acc);
+    }
+    float f = (float)px * (1.0f / 255.0f);          // HF rescale: image.astype(float32) * float32(1/255)
+    f = (f - 0.5f) / 0.5f;
+    out[i] = from_f<T>(f);
+}
+hipError_t launch_preprocess(int dtype, const uint8_t* frames, int T_, int R, int size, const int32_t* coef, const int32_t* bounds, int ksize,
+                             uint8_t* tmp, void* out, hipStream_t st) {
+    long long planes = (long long)T_ * 3;
+    if (planes <= 0) return hipSuccess;
+    int identity = (R == size);
+    const uint8_t* vsrc = frames;
+    if (!identity) {
+        long long n1 = planes * R * size;
+        hipLaunchKernelGGL(resize_h_kernel, dim3(cdiv(n1, 256)), dim3(256), 0, st, frames, R, size, coef, bounds, ksize, tmp, planes);
+        vsrc = tmp;
+    }
+    long long n2 = planes * size * size;
+    if (dtype == MMD_F32) hipLaunchKernelGGL(resize_v_norm_kernel<float>, dim3(cdiv(n2, 256)), dim3(256), 0, st, vsrc, R, size, coef, bounds, ksize, (float*)out, planes, identity);
+    else hipLaunchKernelGGL(resize_v_norm_kernel<bf16_t>, dim3(cdiv(n2, 256)), dim3(256), 0, st, vsrc, R, size, coef, bounds, ksize, (bf16_t*)out, planes, identity);
+    return hipGetLastError();
+}

@@ -1,0 +1,280 @@
+"""Stream driver: the per-frame "when to speak" loop over a HIP-backed LiveLlava model.
+
+Public surface and behaviour mirror the reference's `LiveInferForBenchmark` (test/inference.py:20-313): the same
+attributes (the Gradio demo pokes thresholds directly, demo/app.py:143-150), `reset / set_fps / input_video_stream /
+input_query_stream / inference`, the same prompt-prefix rules, threshold rules and result format.  What differs is
+how the work is scheduled on the GPU:
+
+  * frame embeddings stay in HBM (the reference copies every frame to the host and back, :212,:237);
+  * preprocess runs on the device (mmd_preprocess_frames);
+  * one native call per step returns the head logits of the step (one sync), lm_head runs only when text is generated;
+  * `frames_per_forward = k > 1` feeds k frames in ONE causal forward (M = 49k rows instead of 49, which moves the
+    LLM GEMMs from the weight-bandwidth regime toward the MFMA regime).  Causality makes frame j's scores independent
+    of frames j+1.. in the same forward, so decisions are taken frame by frame on the host; when frame j asks for a
+    response the KV arena is truncated to the end of frame j (O(1)), the response is generated, and frames j+1.. are
+    replayed.  Results equal the one-frame-per-forward schedule up to floating-point reduction order.
+"""
+from __future__ import annotations
+import collections
+import math
+from dataclasses import asdict
+import torch
+
+from .modeling_live import build_model_and_tokenizer, fast_greedy_generate
+from .tokenization_live import chat_ids
+
+VIT_BATCH = 32          # test/inference.py:208
+
+
+class LiveInferForBenchmark:
+    def __init__(self, args, model=None, tokenizer=None) -> None:
+        assert not (args.bf16 and args.fp16), "only one of --bf16 true and --fp16 true can be set"
+        if args.fp16:
+            raise ValueError('fp16 is not offered by the MI355X implementation; use --bf16 true (or fp32)')
+        self.torch_dtype = torch.bfloat16 if args.bf16 else torch.float32
+        if model is None:
+            kw = asdict(args)
+            for k in ('frames_per_forward', 'kv_capacity_tokens', 'max_new_tokens'):
+                kw.pop(k, None)
+            model, tokenizer = build_model_and_tokenizer(is_training=False, set_vision_inside=True, torch_dtype=self.torch_dtype, **kw)
+        self.model, self.tokenizer = model, tokenizer
+        self.model.eval()
+        self.image_processor = self.model.get_vision_tower().image_processor
+        self.device = getattr(self.model, 'device', torch.device('cpu'))
+
+        # visual
+        self.hidden_size = self.model.config.hidden_size
+        if args.frame_fps > 0:
+            self.set_fps(args.frame_fps)
+        self.frame_resolution = self.model.config.frame_resolution
+        self.frame_num_tokens = self.model.config.frame_num_tokens
+        self.frame_v_placeholder = self.model.config.v_placeholder * self.frame_num_tokens
+
+        # generation / decision rule
+        self.system_prompt = args.system_prompt
+        self.max_new_tokens = getattr(args, 'max_new_tokens', 200)
+        self.inplace_output_ids = torch.zeros(1, self.max_new_tokens, device=self.device, dtype=torch.long)
+        self.stream_end_prob_threshold = args.stream_end_prob_threshold
+        self.response_min_interval_frames = args.response_min_interval_frames
+        self.threshold_z = args.threshold_z
+        self.first_n_frames_no_generate = args.first_n_frames_no_generate
+        self.running_list_length = args.running_list_length
+        self.stream_end_score_sum_threshold = args.stream_end_score_sum_threshold
+        self.score_heads = args.score_heads.split(',')
+        self.consecutive_n_frames_threshold = args.consecutive_n_frames_threshold
+        n_set = sum(x is not None for x in (self.threshold_z, self.stream_end_prob_threshold, self.stream_end_score_sum_threshold))
+        if n_set != 1:
+            raise ValueError('only one of --stream_end_prob_threshold, --threshold_z and --stream_end_score_sum_threshold can be set. '
+                             f'However, they are: {self.stream_end_prob_threshold}, {self.threshold_z}, {self.stream_end_score_sum_threshold}')
+        if self.threshold_z is not None and self.first_n_frames_no_generate is None:
+            raise ValueError('--first_n_frames_no_generate must be set when --threshold_z is set')
+        self.remove_assistant_turns = args.remove_assistant_turns
+        self.repetition_penalty = args.repetition_penalty
+        self.frames_per_forward = max(1, int(getattr(args, 'frames_per_forward', 1)))
+
+        self.eos_token_id = self.model.config.eos_token_id
+        dev = self.device
+        self._start_ids = chat_ids(self.tokenizer, [{'role': 'system', 'content': self.system_prompt}]).to(dev)
+        self._added_stream_prompt_ids = chat_ids(self.tokenizer, [{}], add_stream_prompt=True).to(dev)
+        self._added_stream_generation_ids = chat_ids(self.tokenizer, [{}], add_stream_generation_prompt=True).to(dev)
+        self.reset()
+
+    # ------------------------------------------------------------------------------------------------------------
+    def set_fps(self, fps=None, frame_interval=None):
+        assert (fps is None) != (frame_interval is None)
+        if fps is not None:
+            self.frame_fps, self.frame_interval = fps, 1 / fps
+        else:
+            self.frame_interval, self.frame_fps = frame_interval, 1 / frame_interval
+
+    def _no_ids(self):
+        return torch.zeros(1, 0, device=self.device, dtype=torch.long)
+
+    def reset(self):
+        self.query_queue = collections.deque()
+        self.frame_embeds_queue = collections.deque()
+        self.video_time = 0
+        self.frame_idx = 0
+        self.last_role = 'system'
+        self.video_tensor = None
+        self.last_ids = self._no_ids()
+        self.past_key_values = None
+        self.debug_data_list = list()
+        self.generated_token_ids = list()
+        self.num_frames_no_reply = 0
+        self.stream_end_prob_list = list()
+        self.stream_end_score_sum = 0
+        self.consecutive_n_frames = 0
+        self.forward_calls = 0              # LLM forwards issued (diagnostics of the chunked schedule)
+        self.replayed_frames = 0
+
+    # ------------------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def input_video_stream(self, video_frames):
+        """All frames of the video at once (uint8 [T,3,R,R]); queues (time, [frame_num_tokens, hidden]) per frame."""
+        pixel_values = self.image_processor.preprocess(video_frames, return_tensors='pt')['pixel_values']
+        pixel_values = pixel_values.to(self.device).to(self.torch_dtype)
+        for b0 in range(0, len(pixel_values), VIT_BATCH):
+            embeds = self.model.visual_embed(pixel_values[b0:b0 + VIT_BATCH]).split(self.frame_num_tokens)
+            self.frame_embeds_queue.extend(((r + b0) / self.frame_fps, f) for r, f in enumerate(embeds))
+
+    def input_query_stream(self, conversation):
+        for turn in conversation:
+            if turn['role'] == 'user':
+                self.query_queue.append((turn['time'], turn['content']))
+
+    # ------------------------------------------------------------------------------------------------------------
+    def _prefix_ids_for_next_frame(self):
+        """Text that precedes the next frame's tokens (test/inference.py:229-234): the system turn before the very
+        first forward (note: no `stream` header before the first frame, and nothing at all if a t=0 query already
+        filled the cache); last generated token + "\\n<|im_start|>stream\\n" after an assistant turn that stays in
+        context; otherwise nothing."""
+        if not self.past_key_values:
+            return self._start_ids
+        if self.last_role == 'assistant' and not self.remove_assistant_turns:
+            return torch.cat([self.last_ids, self._added_stream_prompt_ids], dim=1)
+        return self._no_ids()
+
+    def _embed(self, ids):
+        return self.model.get_input_embeddings()(ids).view(1, -1, self.hidden_size)
+
+    def _forward_frames(self, frames):
+        """One causal forward over `frames` (list of [frame_num_tokens, hidden]); returns per-frame
+        (informative_score, relevance_score) and the KV length at the end of each frame."""
+        self.last_ids = self._prefix_ids_for_next_frame()
+        prefix = self._embed(self.last_ids)
+        P = prefix.shape[1]
+        x = torch.cat([prefix] + [f.view(1, -1, self.hidden_size).to(prefix.device) for f in frames], dim=1)
+        n0 = len(self.past_key_values) if self.past_key_values else 0
+        nt = self.frame_num_tokens
+        rows = [P + (j + 1) * nt - 1 for j in range(len(frames))]
+        if hasattr(self.model, 'frame_step'):
+            head_logits, cache = self.model.frame_step(x, self.past_key_values, rows)
+        else:       # generic duck-typed model
+            out = self.model(inputs_embeds=x, use_cache=True, past_key_values=self.past_key_values, return_dict=True)
+            head_logits = torch.cat([out.informative_logits[0, rows], out.relevance_logits[0, rows]], dim=-1).float().cpu()
+            cache = out.past_key_values
+        self.forward_calls += 1
+        probs_inf = head_logits[:, 0:2].softmax(dim=-1)[:, 1].tolist()
+        probs_rel = head_logits[:, 2:4].softmax(dim=-1)[:, 1].tolist()
+        ends = [n0 + P + (j + 1) * nt for j in range(len(frames))]
+        return list(zip(probs_inf, probs_rel)), ends, cache
+
+    def _encode_frame(self):
+        """Single-frame step with the reference's return value (test/inference.py:221-246)."""
+        if not self.frame_embeds_queue:
+            return None, None
+        video_time, frame_embeds = self.frame_embeds_queue.popleft()
+        scores, _, cache = self._forward_frames([frame_embeds])
+        self.past_key_values = cache
+        self.frame_idx += 1
+        self.num_frames_no_reply += 1
+        self.last_role = 'stream'
+        return {'informative_score': scores[0][0], 'relevance_score': scores[0][1]}
+
+    def _encode_query(self):
+        """test/inference.py:248-255."""
+        query_time, query = self.query_queue.popleft()
+        self.last_ids = chat_ids(self.tokenizer, [{'role': 'user', 'content': query}],
+                                 add_stream_query_prompt=self.last_role == 'stream', add_stream_prompt=True).to(self.device)
+        outputs = self.model(inputs_embeds=self._embed(self.last_ids), past_key_values=self.past_key_values, use_cache=True, return_dict=True)
+        self.past_key_values = outputs.past_key_values
+        self.forward_calls += 1
+        # the reference takes argmax of the last logits here and overwrites it before any use (:254); skipped (lm_head is lazy)
+        self.last_ids = self._no_ids()
+        self.last_role = 'user'
+
+    def _generate_response(self):
+        """test/inference.py:257-274."""
+        self.last_ids = self._added_stream_generation_ids
+        output_ids, past_key_values, self.generated_token_ids = fast_greedy_generate(
+            model=self.model, inputs_embeds=self._embed(self.last_ids), past_key_values=self.past_key_values,
+            eos_token_id=self.eos_token_id, inplace_output_ids=self.inplace_output_ids,
+            repetition_penalty=self.repetition_penalty, generated_token_ids=self.generated_token_ids)
+        self.last_generated_ids = output_ids[0].tolist()
+        if not self.remove_assistant_turns:
+            self.past_key_values = past_key_values
+            self.last_ids = output_ids[:, -1:].clone()
+        else:
+            self.last_ids = self._no_ids()          # the generated turn's KV is dropped: we keep the older handle
+        response = self.tokenizer.decode(output_ids[0], skip_special_tokens=True, clean_up_tokenization_spaces=True)
+        self.num_frames_no_reply = 0
+        self.last_role = 'assistant'
+        return response
+
+    # ------------------------------------------------------------------------------------------------------------
+    def _decide(self, video_scores):
+        """Threshold rule of test/inference.py:289-299; returns need_response."""
+        stream_end_score = sum(v for k, v in video_scores.items() if k in self.score_heads)
+        self.stream_end_prob_list.append(stream_end_score)
+        self.stream_end_score_sum += stream_end_score
+        if isinstance(self.running_list_length, int) and self.running_list_length > 0:
+            self.stream_end_prob_list = self.stream_end_prob_list[-self.running_list_length:]
+        need = False
+        if self.stream_end_score_sum_threshold is not None and self.stream_end_score_sum > self.stream_end_score_sum_threshold:
+            need = True
+            self.stream_end_score_sum = 0
+        if self.stream_end_prob_threshold is not None and stream_end_score > self.stream_end_prob_threshold:
+            need = True
+        return need
+
+    def _chunk_size(self):
+        """Frames that may share the next forward: up to frames_per_forward, never across a pending user query
+        (a query due at frame j must be encoded before frame j, test/inference.py:281-282)."""
+        k = min(self.frames_per_forward, len(self.frame_embeds_queue))
+        if self.query_queue:
+            q_time = self.query_queue[0][0]
+            for j in range(1, k):
+                if self.video_time + j / self.frame_fps >= q_time:
+                    return j
+        return k
+
+    @torch.no_grad()
+    def inference(self):
+        model_response_list = [{'time': q[0], 'content': q[1], 'role': 'user'} for q in self.query_queue]
+        self.response_token_ids = []
+        while self.frame_embeds_queue:
+            # 1. a user query due at the current time goes in first
+            if self.query_queue and self.video_time >= self.query_queue[0][0]:
+                self._encode_query()
+            # 2. one forward over the next chunk of frames
+            k = self._chunk_size()
+            chunk = [self.frame_embeds_queue.popleft() for _ in range(k)]
+            scores, ends, cache = self._forward_frames([f for _, f in chunk])
+            arena_handle = cache
+            for j in range(k):
+                self.frame_idx += 1
+                self.num_frames_no_reply += 1
+                self.last_role = 'stream'
+                video_scores = {'informative_score': scores[j][0], 'relevance_score': scores[j][1]}
+                self.debug_data_list.append(dict(time=self.video_time, **video_scores))
+                # 3./4. decide, respond
+                if self._decide(video_scores):
+                    # context = everything up to the end of frame j; later frames of the chunk are replayed
+                    self.past_key_values = cache if j == k - 1 else self.model.cache_prefix(arena_handle, ends[j])
+                    for item in reversed(chunk[j + 1:]):
+                        self.frame_embeds_queue.appendleft(item)
+                    self.replayed_frames += k - 1 - j
+                    response = self._generate_response()
+                    self.response_token_ids.append(self.last_generated_ids)
+                    model_response_list.append({'time': self.video_time, 'content': response, 'role': 'assistant'})
+                    self.num_frames_no_reply = 0
+                    self.consecutive_n_frames = 0
+                    self.video_time += 1 / self.frame_fps
+                    break
+                # 5. advance the clock
+                self.video_time += 1 / self.frame_fps
+            else:
+                self.past_key_values = cache
+        return sorted(model_response_list, key=lambda x: x['time'])
+
+
+def round_numbers(data, n):
+    """test/inference.py:322-329."""
+    if isinstance(data, list):
+        return [round_numbers(d, n) for d in data]
+    if isinstance(data, dict):
+        return {k: round_numbers(v, n) for k, v in data.items()}
+    if isinstance(data, float):
+        return round(data, n)
+    return data

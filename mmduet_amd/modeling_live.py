@@ -1,0 +1,544 @@
+"""HIP-backed LiveLlava model with the reference's Python surface.
+
+Mirrors (names, argument meaning, error behaviour) the pieces of the reference the stream driver touches:
+  VideoHeadLiveLlavaQwenForCausalLM   models/live_llava/video_head_live_llava_qwen.py:67-242
+  VideoHeadCausalLMOutputWithPast     models/live_llava/video_head_live_llava_qwen.py:48-58
+  LiveMixin.visual_embed / joint_embed   models/modeling_live.py:26-48
+  fast_greedy_generate                models/modeling_live.py:51-77
+  build_live / build_model_and_tokenizer   models/modeling_live.py:80-129, models/__init__.py:8-13
+All arithmetic runs in libmmduet_hip.so (include/mmduet.h); torch only provides device buffers and the stream.
+"""
+from __future__ import annotations
+import ctypes as C
+import threading
+import weakref
+from typing import Optional
+import torch
+
+from . import _lib
+from ._lib import lib, check, MmdConfig, MMD_BF16, MMD_F32, POOL_MODES
+from .configuration_live import VideoHeadLiveLlavaQwenConfig
+from .tokenization_live import build_live_tokenizer_and_update_config
+
+_TORCH2MMD = {torch.float32: MMD_F32, torch.bfloat16: MMD_BF16}
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# KV cache handles
+# ----------------------------------------------------------------------------------------------------------------
+class _KVArena:
+    """Owns one native KV arena (mmd_stream): contiguous per-layer K/V with O(1) append / truncate."""
+
+    def __init__(self, model, initial_tokens):
+        self.model = model
+        h = C.c_void_p()
+        check(lib().mmd_stream_create(model._ctx, int(initial_tokens), C.byref(h)), model._ctx, 'mmd_stream_create')
+        self.h = h
+        self.handles = weakref.WeakSet()
+
+    def length(self):
+        return int(lib().mmd_kv_len(self.h))
+
+    def truncate(self, n):
+        if n < self.length():
+            for hd in list(self.handles):
+                if hd.length > n:
+                    hd.stale = True
+            check(lib().mmd_kv_truncate(self.h, int(n)), self.model._ctx, 'mmd_kv_truncate')
+
+    def __del__(self):
+        try:
+            if self.h and self.model._ctx:
+                lib().mmd_stream_destroy(self.h)
+        except Exception:
+            pass
+        self.h = None
+
+
+class KVCacheHandle:
+    """`past_key_values` as callers see it: an opaque (arena, length) pair.
+
+    Semantics the reference driver relies on:
+      * falsy when empty (`if not self.past_key_values`, test/inference.py:229);
+      * functional: a handle held before `fast_greedy_generate` still denotes the pre-generation context
+        afterwards (remove_assistant_turns, test/inference.py:265-269).  Continuing from an older handle truncates
+        the arena back to its length in O(1); handles that pointed beyond that become stale and raise if used.
+    """
+    __slots__ = ('arena', 'length', 'stale', '__weakref__')
+
+    def __init__(self, arena: _KVArena, length: int):
+        self.arena, self.length, self.stale = arena, int(length), False
+        arena.handles.add(self)
+
+    def __len__(self):
+        return self.length
+
+    def __bool__(self):
+        return self.length > 0
+
+    def get_seq_length(self, layer_idx=0):
+        return self.length
+
+
+class VideoHeadCausalLMOutputWithPast:
+    """Output of the model call.  `.logits` (lm_head) is computed lazily and, unless
+    `config.all_position_logits` is set, only for the LAST position ([1,1,V]): the streaming loop reads nothing else
+    (`outputs.logits[:, -1:]`), and the reference's all-position lm_head is 53 GFLOP + 30 MB per frame of waste."""
+
+    def __init__(self, model, hidden, cache):
+        self._model, self._hidden = model, hidden          # hidden: [S, H] post-final-norm
+        self.past_key_values = cache
+        self.loss = 0.0
+        self.lm_loss = 0.0
+        self.video_loss = 0.0
+        self.attentions = None
+        self._logits = None
+        self._heads = None
+
+    @property
+    def hidden_states(self):
+        return self._hidden[None]
+
+    @property
+    def logits(self):
+        if self._logits is None:
+            rows = self._hidden if self._model.config.all_position_logits else self._hidden[-1:]
+            self._logits = self._model.lm_head(rows)[None]
+        return self._logits
+
+    def _video_heads(self):
+        if self._heads is None:
+            self._heads = self._model.video_heads(self._hidden)
+        return self._heads
+
+    @property
+    def informative_logits(self):
+        return self._video_heads()[None, :, 0:2]
+
+    @property
+    def relevance_logits(self):
+        return self._video_heads()[None, :, 2:4]
+
+
+# ----------------------------------------------------------------------------------------------------------------
+class _Embedding:
+    """`model.get_input_embeddings()`: callable on LongTensor [..., k] (k may be 0, test/inference.py:234)."""
+
+    def __init__(self, model):
+        self._m = model
+
+    def __call__(self, ids):
+        m = self._m
+        ids = ids.to(device=m.device, dtype=torch.long).contiguous()
+        out = torch.empty(*ids.shape, m.config.hidden_size, dtype=m.dtype, device=m.device)
+        k = ids.numel()
+        if k:
+            with m._lock:
+                m._bind_stream()
+                check(lib().mmd_embed_tokens(m._ctx, _ptr(ids), k, _ptr(out)), m._ctx, 'mmd_embed_tokens')
+        return out
+
+
+class SigLipImageProcessor:
+    """`model.get_vision_tower().image_processor` (LLaVA SigLipImageProcessor, used at test/inference.py:203).
+    preprocess = bicubic resize to the tower resolution (bit-exact with Pillow), 1/255, (x-.5)/.5 -- executed by the
+    HIP kernel behind mmd_preprocess_frames; the result stays on the device in the model dtype, so the driver's
+    `.to('cuda').to(dtype)` are no-ops."""
+
+    def __init__(self, model):
+        self._m = model
+        s = model.config.vit_image_size
+        self.size = (s, s)
+        self.image_mean = self.image_std = (0.5, 0.5, 0.5)
+        self.rescale_factor = 1 / 255
+
+    def preprocess(self, images, return_tensors='pt'):
+        m = self._m
+        if isinstance(images, (list, tuple)):
+            images = torch.stack([torch.as_tensor(i) for i in images])
+        images = torch.as_tensor(images)
+        if images.dtype != torch.uint8 or images.ndim != 4 or images.shape[1] != 3 or images.shape[2] != images.shape[3]:
+            raise ValueError(f'expected uint8 frames [T,3,R,R], got {tuple(images.shape)} {images.dtype}')
+        fr = images.to(m.device).contiguous()
+        T, _, R, _ = fr.shape
+        out = torch.empty(T, 3, self.size[0], self.size[1], dtype=m.dtype, device=m.device)
+        if T:
+            with m._lock:
+                m._bind_stream()
+                check(lib().mmd_preprocess_frames(m._ctx, _ptr(fr), T, R, _ptr(out)), m._ctx, 'mmd_preprocess_frames')
+        return {'pixel_values': out}
+
+
+class _VisionTower:
+    def __init__(self, model):
+        self.image_processor = SigLipImageProcessor(model)
+        self.num_patches_per_side = model.config.vit_grid
+        self.hidden_size = model.config.vit_hidden_size
+
+    def parameters(self):
+        return iter(())
+
+
+class VideoHeadLiveLlavaQwenForCausalLM:
+    config_class = VideoHeadLiveLlavaQwenConfig
+
+    def __init__(self, config: VideoHeadLiveLlavaQwenConfig, torch_dtype=torch.bfloat16, device=None,
+                 max_vit_batch=32, max_step_tokens=1024, kv_initial_tokens=32768):
+        if torch_dtype not in _TORCH2MMD:
+            raise ValueError(f'torch_dtype must be bfloat16 or float32 on this implementation, got {torch_dtype}')
+        if not torch.cuda.is_available():
+            raise _lib.MmduetError('no HIP device visible: this implementation runs on MI355X only (no CPU fallback)')
+        L = lib()
+        self.config = config
+        if not hasattr(config, 'all_position_logits'):
+            config.all_position_logits = False
+        self.dtype = torch_dtype
+        self.device = torch.device(device if device is not None else f'cuda:{torch.cuda.current_device()}')
+        self.vocab_size = config.vocab_size
+        self.kv_initial_tokens = kv_initial_tokens
+        self.max_vit_batch, self.max_step_tokens = max_vit_batch, max_step_tokens
+        c = MmdConfig()
+        c.struct_size = C.sizeof(MmdConfig)
+        c.dtype = _TORCH2MMD[torch_dtype]
+        c.vocab_size, c.hidden_size, c.intermediate_size = config.vocab_size, config.hidden_size, config.intermediate_size
+        c.num_layers, c.num_heads, c.num_kv_heads, c.head_dim = config.num_hidden_layers, config.num_attention_heads, config.num_key_value_heads, config.head_dim
+        c.rope_theta, c.rms_norm_eps = float(config.rope_theta), float(config.rms_norm_eps)
+        c.vit_hidden, c.vit_intermediate, c.vit_layers, c.vit_heads = config.vit_hidden_size, config.vit_intermediate_size, config.vit_layers_run, config.vit_num_attention_heads
+        c.vit_image, c.vit_patch, c.vit_ln_eps = config.vit_image_size, config.vit_patch_size, float(config.vit_layer_norm_eps)
+        c.vit_post_layernorm = int(bool(config.vit_post_layernorm))
+        if config.mm_spatial_pool_mode not in POOL_MODES:
+            raise ValueError(f'Unexpected mm_spatial_pool_mode: {config.mm_spatial_pool_mode}')
+        c.pool_mode, c.pool_stride = POOL_MODES[config.mm_spatial_pool_mode], config.video_pooling_stride
+        g = config.vit_grid
+        out_side = -(-g // config.video_pooling_stride) if config.mm_spatial_pool_mode == 'bilinear' else g // config.video_pooling_stride
+        self.tokens_per_frame = out_side * out_side
+        c.frame_num_tokens = self.tokens_per_frame
+        c.max_vit_batch, c.max_step_tokens = max_vit_batch, max_step_tokens
+        self._cfg_struct = c
+        self._ctx = None
+        h = C.c_void_p()
+        check(L.mmd_create(C.byref(c), self.device.index or 0, C.byref(h)), None, 'mmd_create')
+        self._ctx = h
+        self._lock = threading.RLock()      # the Gradio demo calls the model from two threads (demo/app.py:84-85)
+        self._embed = _Embedding(self)
+        self._tower = _VisionTower(self)
+        self._finalized = False
+        self.lm_loss_weight = self.video_loss_weight = 1
+        # RoPE table with the reference's own expression (transformers qwen2/modeling_qwen2.py:84-85)
+        d = config.head_dim
+        inv = (1.0 / (float(config.rope_theta) ** (torch.arange(0, d, 2, dtype=torch.float) / d))).contiguous()
+        check(L.mmd_set_rope_inv_freq(self._ctx, C.c_void_p(inv.data_ptr()), d // 2), self._ctx, 'mmd_set_rope_inv_freq')
+
+    # ---- lifecycle ----------------------------------------------------------------------------------------------
+    def __del__(self):
+        try:
+            if self._ctx:
+                lib().mmd_destroy(self._ctx)
+        except Exception:
+            pass
+        self._ctx = None
+
+    def _bind_stream(self):
+        lib().mmd_set_stream(self._ctx, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+
+    def eval(self):
+        return self
+
+    def requires_grad_(self, flag=False):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def parameters(self):
+        return iter(())
+
+    # ---- weights ------------------------------------------------------------------------------------------------
+    def load_tensor(self, name: str, t: torch.Tensor):
+        if t.dtype not in _TORCH2MMD:
+            t = t.float()
+        t = t.contiguous()
+        shape = (C.c_int64 * t.ndim)(*t.shape)
+        on_dev = 1 if t.is_cuda else 0
+        with self._lock:
+            self._bind_stream()
+            check(lib().mmd_load_tensor(self._ctx, name.encode(), _ptr(t), _TORCH2MMD[t.dtype], shape, t.ndim, on_dev), self._ctx, f'load {name}')
+            if on_dev:
+                torch.cuda.current_stream(self.device).synchronize()
+
+    def merge_lora(self, weight_name: str, A: torch.Tensor, B: torch.Tensor, scale: float):
+        A = A.float().cpu().contiguous(); B = B.float().cpu().contiguous()
+        with self._lock:
+            self._bind_stream()
+            check(lib().mmd_merge_lora(self._ctx, weight_name.encode(), _ptr(A), _ptr(B), A.shape[0], float(scale)), self._ctx, f'lora {weight_name}')
+
+    def load_state_dict(self, named_tensors, strict=True):
+        for name, t in (named_tensors.items() if hasattr(named_tensors, 'items') else named_tensors):
+            self.load_tensor(name, t)
+        self.finalize()
+        return self
+
+    def finalize(self):
+        with self._lock:
+            self._bind_stream()
+            check(lib().mmd_finalize_weights(self._ctx), self._ctx, 'mmd_finalize_weights')
+        self._finalized = True
+
+    def weight_bytes(self):
+        return int(lib().mmd_weight_bytes(self._ctx))
+
+    # ---- reference surface ------------------------------------------------------------------------------------------
+    def get_model(self):
+        return self
+
+    def get_vision_tower(self):
+        return self._tower
+
+    def get_input_embeddings(self):
+        return self._embed
+
+    def set_vision_inside(self):
+        """models/modeling_live.py:14-20: the tower is always inside this model."""
+        return None
+
+    def visual_embed(self, frames: torch.Tensor):
+        """models/modeling_live.py:26-33 -> [B*frame_num_tokens, hidden] in the model dtype."""
+        frames = frames.to(device=self.device, dtype=self.dtype).contiguous()
+        B = frames.shape[0]
+        out = torch.empty(B * self.tokens_per_frame, self.config.hidden_size, dtype=self.dtype, device=self.device)
+        with self._lock:
+            self._bind_stream()
+            for b0 in range(0, B, self.max_vit_batch):
+                b1 = min(B, b0 + self.max_vit_batch)
+                check(lib().mmd_vit_encode(self._ctx, _ptr(frames[b0:b1]), b1 - b0, _ptr(out[b0 * self.tokens_per_frame:])), self._ctx, 'mmd_vit_encode')
+        return out
+
+    def vit_debug_tap(self, stage: int, B: int):
+        n = B * self.config.vit_grid ** 2
+        width = self.config.vit_hidden_size if stage == 0 else self.config.hidden_size
+        out = torch.empty(n, width, dtype=self.dtype, device=self.device)
+        with self._lock:
+            self._bind_stream()
+            check(lib().mmd_vit_debug_tap(self._ctx, stage, _ptr(out), out.numel()), self._ctx, 'mmd_vit_debug_tap')
+        return out
+
+    def joint_embed(self, input_ids: torch.Tensor = None, frames: torch.Tensor = None):
+        """models/modeling_live.py:35-48."""
+        if frames is None:
+            return self._embed(input_ids)
+        if input_ids is None:
+            return self.visual_embed(frames)
+        input_ids = input_ids.to(self.device)
+        e = self._embed(input_ids.clamp(max=self.vocab_size - 1))
+        mask = input_ids == self.config.v_placeholder_id
+        if mask.any():
+            e[mask] = self.visual_embed(frames).to(e.dtype)
+        return e
+
+    # ---- cache plumbing ---------------------------------------------------------------------------------------------
+    def _resolve_cache(self, past_key_values):
+        if past_key_values is None or (isinstance(past_key_values, KVCacheHandle) and past_key_values.arena is None):
+            return _KVArena(self, self.kv_initial_tokens), 0
+        if not isinstance(past_key_values, KVCacheHandle) or past_key_values.arena.model is not self:
+            raise TypeError('past_key_values must be a KVCacheHandle produced by this model (or None)')
+        if past_key_values.stale:
+            raise RuntimeError('stale KV handle: the context it denoted was overwritten by a later forward from an older handle')
+        arena = past_key_values.arena
+        arena.truncate(past_key_values.length)
+        return arena, past_key_values.length
+
+    def cache_prefix(self, handle: KVCacheHandle, length: int):
+        """Handle denoting the first `length` tokens of `handle`'s context (speculative multi-frame chunks)."""
+        if length > handle.length:
+            raise ValueError('prefix longer than the context')
+        return KVCacheHandle(handle.arena, length)
+
+    def new_cache(self, initial_tokens=None):
+        return KVCacheHandle(_KVArena(self, initial_tokens or self.kv_initial_tokens), 0)
+
+    # ---- forward ----------------------------------------------------------------------------------------------------
+    def __call__(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None,
+                 labels=None, use_cache=None, output_attentions=None, output_hidden_states=None, frames=None,
+                 return_dict=None, **kwargs):
+        """models/live_llava/video_head_live_llava_qwen.py:121-205 (inference branch: labels must be None)."""
+        if labels is not None:
+            raise NotImplementedError('training losses are out of scope of the inference implementation')
+        if inputs_embeds is None:
+            inputs_embeds = self.joint_embed(input_ids, frames)
+        if inputs_embeds.ndim != 3 or inputs_embeds.shape[0] != 1:
+            raise ValueError(f'inputs_embeds must be [1, S, hidden] (streaming is batch 1), got {tuple(inputs_embeds.shape)}')
+        x = inputs_embeds[0].to(device=self.device, dtype=self.dtype).contiguous()
+        S = x.shape[0]
+        hidden = torch.empty(S, self.config.hidden_size, dtype=self.dtype, device=self.device)
+        with self._lock:
+            arena, n = self._resolve_cache(past_key_values)
+            self._bind_stream()
+            for s0 in range(0, S, self.max_step_tokens):
+                s1 = min(S, s0 + self.max_step_tokens)
+                check(lib().mmd_llm_step(self._ctx, arena.h, _ptr(x[s0:s1]), s1 - s0, _ptr(hidden[s0:s1])), self._ctx, 'mmd_llm_step')
+            cache = KVCacheHandle(arena, n + S)
+        out = VideoHeadCausalLMOutputWithPast(self, hidden, cache)
+        if return_dict is False:
+            return (out.loss, out.logits, cache)
+        return out
+
+    forward = __call__
+
+    def lm_head(self, hidden_rows: torch.Tensor):
+        M = hidden_rows.shape[0]
+        hidden_rows = hidden_rows.contiguous()
+        out = torch.empty(M, self.config.vocab_size, dtype=torch.float32, device=self.device)
+        if M:
+            with self._lock:
+                self._bind_stream()
+                check(lib().mmd_lm_head(self._ctx, _ptr(hidden_rows), M, _ptr(out)), self._ctx, 'mmd_lm_head')
+        return out
+
+    def video_heads(self, hidden_rows: torch.Tensor):
+        """-> [M,4] fp32 = informative(2) | relevance(2)."""
+        M = hidden_rows.shape[0]
+        hidden_rows = hidden_rows.contiguous()
+        out = torch.empty(M, 4, dtype=torch.float32, device=self.device)
+        if M:
+            with self._lock:
+                self._bind_stream()
+                check(lib().mmd_video_heads(self._ctx, _ptr(hidden_rows), M, _ptr(out)), self._ctx, 'mmd_video_heads')
+        return out
+
+    # ---- fused fast paths used by mmduet_amd.inference (same results as __call__ + heads) -------------------------
+    def frame_step(self, inputs_embeds: torch.Tensor, past_key_values, head_rows):
+        """One LLM step over `inputs_embeds` [S,H] and the 4 video-head logits at `head_rows` (list of row indices).
+        Returns (numpy-like list [[inf0, inf1, rel0, rel1], ...] as a float32 CPU tensor, new handle)."""
+        x = inputs_embeds.reshape(-1, self.config.hidden_size).to(device=self.device, dtype=self.dtype).contiguous()
+        S = x.shape[0]
+        if S > self.max_step_tokens:
+            raise ValueError(f'step of {S} tokens exceeds max_step_tokens={self.max_step_tokens}')
+        rows = (C.c_int32 * len(head_rows))(*[int(r) for r in head_rows])
+        res = (C.c_float * (4 * len(head_rows)))()
+        with self._lock:
+            arena, n = self._resolve_cache(past_key_values)
+            self._bind_stream()
+            check(lib().mmd_frame_step(self._ctx, arena.h, _ptr(x), S, rows, len(head_rows), res), self._ctx, 'mmd_frame_step')
+            cache = KVCacheHandle(arena, n + S)
+        return torch.tensor(list(res), dtype=torch.float32).view(-1, 4), cache
+
+    def greedy_generate(self, inputs_embeds, past_key_values, eos_token_id, max_new_tokens, repetition_penalty=None,
+                        generated_token_ids=None):
+        x = inputs_embeds.reshape(-1, self.config.hidden_size).to(device=self.device, dtype=self.dtype).contiguous()
+        S = x.shape[0]
+        pen = float(repetition_penalty) if repetition_penalty is not None else 0.0
+        prev = list(generated_token_ids) if (generated_token_ids is not None and pen > 0) else []
+        cap = len(prev) + max_new_tokens + 1
+        prev_arr = (C.c_int64 * cap)(*prev)
+        n_prev = C.c_int(len(prev))
+        out_ids = (C.c_int64 * max_new_tokens)()
+        n_out = C.c_int(0)
+        with self._lock:
+            arena, n = self._resolve_cache(past_key_values)
+            self._bind_stream()
+            check(lib().mmd_greedy_generate(self._ctx, arena.h, _ptr(x), S, int(eos_token_id if eos_token_id is not None else -1), pen, prev_arr,
+                                            C.byref(n_prev), cap, out_ids, int(max_new_tokens), C.byref(n_out)), self._ctx, 'mmd_greedy_generate')
+            cache = KVCacheHandle(arena, arena.length())
+        ids = [int(out_ids[i]) for i in range(n_out.value)]
+        if generated_token_ids is not None and pen > 0:
+            generated_token_ids[:] = [int(prev_arr[i]) for i in range(n_prev.value)]
+        return ids, cache
+
+    # ---- measurement --------------------------------------------------------------------------------------------------
+    def prof_enable(self, on=True):
+        check(lib().mmd_prof_enable(self._ctx, int(on)), self._ctx)
+
+    def prof_reset(self):
+        check(lib().mmd_prof_reset(self._ctx), self._ctx)
+
+    def prof_read(self):
+        n = len(_lib.K_NAMES)
+        ms, cnt, by, fl = (C.c_double * n)(), (C.c_int64 * n)(), (C.c_double * n)(), (C.c_double * n)()
+        check(lib().mmd_prof_read(self._ctx, ms, cnt, by, fl), self._ctx)
+        return {k: dict(ms=ms[i], launches=cnt[i], bytes=by[i], flops=fl[i]) for i, k in enumerate(_lib.K_NAMES)}
+
+
+# ----------------------------------------------------------------------------------------------------------------
+def fast_greedy_generate(*, model, inputs_embeds: torch.Tensor, past_key_values, eos_token_id: int, inplace_output_ids: torch.Tensor,
+                         repetition_penalty=None, generated_token_ids=None):
+    """models/modeling_live.py:51-77, same signature and return triple.  The token loop runs natively
+    (mmd_greedy_generate): argmax (+ HF repetition penalty over `generated_token_ids`) on the device, EOS written but
+    neither fed back nor penalised."""
+    if repetition_penalty is not None:
+        assert isinstance(repetition_penalty, float)
+    if generated_token_ids is None:
+        generated_token_ids = list()
+    max_new = inplace_output_ids.size(1)
+    if not hasattr(model, 'greedy_generate') or getattr(model, 'python_generate_loop', False):
+        return _greedy_generate_by_calls(model, inputs_embeds, past_key_values, eos_token_id, inplace_output_ids,
+                                         repetition_penalty, generated_token_ids)
+    ids, cache = model.greedy_generate(inputs_embeds, past_key_values, eos_token_id, max_new, repetition_penalty, generated_token_ids)
+    n = len(ids)
+    inplace_output_ids[:, :n] = torch.tensor(ids, dtype=inplace_output_ids.dtype, device=inplace_output_ids.device)
+    return inplace_output_ids[:, :n], cache, generated_token_ids
+
+
+def _greedy_generate_by_calls(model, x, cache, eos_token_id, out_ids, penalty, seen):
+    """Token loop through the public model call (any duck-typed model; also the cross-check of the native loop)."""
+    n = 0
+    for n in range(out_ids.size(1)):
+        res = model(inputs_embeds=x, past_key_values=cache, use_cache=True, return_dict=True)
+        cache = res.past_key_values
+        scores = res.logits[0, -1].float().clone()
+        if penalty is not None and seen:
+            idx = torch.as_tensor(seen, dtype=torch.long, device=scores.device)
+            picked = scores[idx]
+            scores[idx] = torch.where(picked < 0, picked * penalty, picked / penalty)
+        tok = int(scores.argmax(-1))
+        if penalty is not None and tok != eos_token_id:
+            seen.append(tok)
+        out_ids[:, n] = tok
+        if tok == eos_token_id:
+            break
+        x = model.get_input_embeddings()(torch.tensor([[tok]], device=out_ids.device))
+    return out_ids[:, :n + 1], cache, seen
+
+
+def build_live(*, is_training: bool, config_class=VideoHeadLiveLlavaQwenConfig, model_class=VideoHeadLiveLlavaQwenForCausalLM,
+               llm_pretrained: str = None, lora_pretrained: str = None, finetune_modules=None, lora_modules: str = None,
+               lora_r: int = None, lora_alpha: int = None, set_vision_inside: bool = False,
+               attn_implementation: str = 'flash_attention_2', torch_dtype='auto', **kwargs):
+    """models/modeling_live.py:80-129 for inference.  `llm_pretrained` is a local checkpoint directory / hub id of a
+    LLaVA-OneVision-Qwen2 checkpoint, or 'synthetic:<seed>' for seeded random weights at the configured shape."""
+    from .weights import load_pretrained_into, load_lora_into, synthetic_weights
+    if is_training:
+        raise NotImplementedError('training is out of scope of the MI355X inference implementation')
+    if torch_dtype == 'auto' or torch_dtype is None:
+        torch_dtype = torch.bfloat16
+    runtime = {k: kwargs.pop(k) for k in ('max_vit_batch', 'max_step_tokens', 'kv_initial_tokens') if k in kwargs}
+    if llm_pretrained.startswith('synthetic'):
+        config = config_class(**kwargs)
+    else:
+        config = config_class.from_pretrained(llm_pretrained, **kwargs)
+    model = model_class(config, torch_dtype=torch_dtype, **runtime)
+    tokenizer = build_live_tokenizer_and_update_config(llm_pretrained, model.config)
+    if llm_pretrained.startswith('synthetic'):
+        seed = int(llm_pretrained.split(':')[1]) if ':' in llm_pretrained and llm_pretrained.split(':')[1].isdigit() else 0
+        for name, t in synthetic_weights(config, seed=seed, device=model.device, dtype=torch_dtype):
+            model.load_tensor(name, t)
+    else:
+        load_pretrained_into(model, llm_pretrained)
+    if lora_pretrained:
+        load_lora_into(model, lora_pretrained)
+    else:
+        import warnings
+        warnings.warn(f'!!! Fail to load lora from checkpoint: {lora_pretrained}. Return a new initialized model.')
+    model.finalize()
+    return model, tokenizer
+
+
+def build_model_and_tokenizer(is_training, **kwargs):
+    """models/__init__.py:8-13."""
+    llm_pretrained = kwargs.get('llm_pretrained', None)
+    if llm_pretrained is not None and ('llava' in llm_pretrained or llm_pretrained.startswith('synthetic')):
+        return build_live(is_training=is_training, **kwargs)
+    raise NotImplementedError(f'Not support {llm_pretrained}')

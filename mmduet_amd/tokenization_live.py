@@ -98,8 +98,9 @@ def build_live_tokenizer_and_update_config(llm_pretrained: str, model_config):
         raise NotImplementedError(f'Not support {llm_pretrained}')
     tokenizer.add_special_tokens({'additional_special_tokens': [model_config.v_placeholder]})
     tokenizer.bos_token, tokenizer.eos_token = '<|im_start|>', '<|im_end|>'
-    model_config.update(dict(v_placeholder_id=tokenizer.convert_tokens_to_ids(model_config.v_placeholder),
-                             eos_token_id=tokenizer.eos_token_id))
+    for key, val in dict(v_placeholder_id=tokenizer.convert_tokens_to_ids(model_config.v_placeholder),
+                         eos_token_id=tokenizer.eos_token_id).items():
+        setattr(model_config, key, val)
     tokenizer.chat_template = duet_chat_template(model_config.v_placeholder, model_config.frame_num_tokens)
     tokenizer.get_learn_ranges = partial(get_learn_ranges, chat_template_offsets=transition_lengths(tokenizer),
                                          model_config=model_config)

@@ -464,6 +464,9 @@ class OracleModel:
     def visual_embed(self, frames):
         return visual_embed(self.w, self.cfg, frames.to(self.dtype))
 
+    def cache_prefix(self, handle, length):
+        return KVHandle([k[:, :length] for k in handle.k], [v[:, :length] for v in handle.v])
+
     def joint_embed(self, input_ids=None, frames=None):
         """models/modeling_live.py:35-48."""
         if frames is None:
