@@ -52,12 +52,13 @@ def test_demo_driver_single_frame_steps():
     name = 'prob_keep_pen'
     case = META['cases'][name]
     model, _, _ = oracle_model('A')
-    model.config.eos_token_id = META['eos_token_id']
     opts = case['opts']
     args = make_args(frame_fps=case['fps'], system_prompt=META['system_prompt'], max_new_tokens=12,
                      stream_end_prob_threshold=opts['stream_end_prob_threshold'], score_heads=opts['score_heads'],
                      repetition_penalty=opts['repetition_penalty'])
-    d = LiveInferForDemo(args, model=model, tokenizer=tokenizer_for(model.config))
+    tok = tokenizer_for(model.config)
+    model.config.eos_token_id = META['eos_token_id']          # the fixture's synthetic "eos" (after the tokenizer set its own)
+    d = LiveInferForDemo(args, model=model, tokenizer=tok)
     d.input_video_stream(stream_frames(name))
     d.encode_given_query(case['conversation'][0]['content'])      # the fixture's query is due at t=0
     outs = []

@@ -18,5 +18,5 @@ def test_decode_roundtrip_and_specials():
     cfg = VideoHeadLiveLlavaQwenConfig(frame_num_tokens=2, v_placeholder='<image>')
     tok = build_live_tokenizer_and_update_config('synthetic:x', cfg)
     ids = chat_ids(tok, [{'role': 'user', 'content': 'héllo wörld'}], add_stream_prompt=True)[0]
-    assert tok.decode(ids, skip_special_tokens=True) == 'user\nhéllo wörld\nstream\n'
+    assert tok.decode(ids, skip_special_tokens=True) == '\nuser\nhéllo wörld\nstream\n'
     assert tok.bos_token == '<|im_start|>' and tok.eos_token == '<|im_end|>'
