@@ -60,7 +60,8 @@ typedef struct mmd_stream mmd_stream;
 int mmd_create(const mmd_config* cfg, int device, mmd_ctx** out);
 void mmd_destroy(mmd_ctx* ctx);
 const char* mmd_last_error(const mmd_ctx* ctx);          /* ctx may be NULL: error of the last failed mmd_create */
-int mmd_set_stream(mmd_ctx* ctx, void* hip_stream);      /* hipStream_t; NULL = the context's own stream */
+int mmd_set_stream(mmd_ctx* ctx, void* hip_stream);      /* hipStream_t used verbatim: NULL = the null stream (torch's default stream).
+                                                            Until called, the context runs on a stream of its own. */
 void* mmd_get_stream(mmd_ctx* ctx);
 int mmd_synchronize(mmd_ctx* ctx);
 

@@ -172,7 +172,7 @@ extern "C" void mmd_destroy(mmd_ctx* c) {
 }
 
 extern "C" const char* mmd_last_error(const mmd_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
-extern "C" int mmd_set_stream(mmd_ctx* c, void* s) { if (!c) return MMD_EINVAL; c->stream = s ? (hipStream_t)s : c->own_stream; return MMD_OK; }
+extern "C" int mmd_set_stream(mmd_ctx* c, void* s) { if (!c) return MMD_EINVAL; c->stream = (hipStream_t)s; return MMD_OK; }   // 0 = the (legacy) null stream, as torch's default stream
 extern "C" void* mmd_get_stream(mmd_ctx* c) { return c ? (void*)c->stream : nullptr; }
 extern "C" int mmd_synchronize(mmd_ctx* c) { if (!c) return MMD_EINVAL; HIPCHK(c, hipStreamSynchronize(c->stream)); return MMD_OK; }
 extern "C" int64_t mmd_weight_bytes(const mmd_ctx* c) { return c ? c->weight_bytes : 0; }

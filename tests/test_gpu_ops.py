@@ -1,0 +1,172 @@
+"""Parity of the HIP operators (called through the C ABI) against the oracle / plain fp32 torch math.
+Tolerances: fp32 kernels 1e-4-class (accumulation order only); bf16 kernels are compared with the same math on
+bf16-rounded inputs and may differ by bf16 output rounding (2^-8 relative) plus accumulation order."""
+import math
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+from oracle import duet_oracle as O
+from conftest import load_npz
+
+DT = [torch.float32, torch.bfloat16]
+
+
+@pytest.fixture(scope='module', params=DT, ids=['f32', 'bf16'])
+def ops(request):
+    from rawops import RawOps
+    return RawOps(request.param)
+
+
+def rt(x, dtype):          # round-trip through the storage type
+    return x.to(dtype).float()
+
+
+def assert_close(got, ref, dtype, scale=1.0, what=''):
+    got = got.float().cpu(); ref = ref.float().cpu()
+    tol = (2e-5 if dtype == torch.float32 else 1.2e-2) * scale
+    err = (got - ref).abs().max().item()
+    den = ref.abs().max().item() + 1e-6
+    assert err <= tol * max(1.0, den), f'{what}: max abs err {err:.3e} (ref max {den:.3e}, tol {tol:.1e})'
+
+
+GEMM_SHAPES = [(49, 64, 64), (7, 130, 72), (200, 96, 588), (64, 256, 512), (300, 384, 256), (1, 512, 64), (129, 160, 4352)]
+
+
+@pytest.mark.parametrize('M,N,K', GEMM_SHAPES)
+@pytest.mark.parametrize('variant', [1, 2, 3])
+def test_gemm_bias(ops, M, N, K, variant):
+    g = torch.Generator().manual_seed(M * 7 + N)
+    X = torch.randn(M, K, generator=g); W = torch.randn(N, K, generator=g) / math.sqrt(K); b = torch.randn(N, generator=g)
+    Y = ops.gemm(X, W, b, variant=variant)
+    ref = F.linear(rt(X, ops.dtype), rt(W, ops.dtype), rt(b, ops.dtype))
+    assert_close(Y, ref, ops.dtype, what=f'gemm {M}x{N}x{K} v{variant}')
+
+
+@pytest.mark.parametrize('epi', ['gelu_tanh', 'gelu_erf', 'resid', 'swiglu'])
+@pytest.mark.parametrize('variant', [1, 2, 3])
+def test_gemm_epilogues(ops, epi, variant):
+    g = torch.Generator().manual_seed(11)
+    M, N, K = 70, 192, 136
+    X = torch.randn(M, K, generator=g); W = torch.randn(N, K, generator=g) / math.sqrt(K); b = 0.1 * torch.randn(N, generator=g)
+    R = torch.randn(M, N, generator=g)
+    Xr, Wr, br, Rr = (rt(t, ops.dtype) for t in (X, W, b, R))
+    if epi == 'swiglu':
+        gate, up = Wr[:N // 2], Wr[N // 2:]
+        # interleave rows in blocks of 16: [g0..15, u0..15, g16..31, ...] (the layout mmd_finalize_weights builds)
+        Wi = torch.stack([gate.view(-1, 16, K), up.view(-1, 16, K)], 1).reshape(N, K)
+        Y = ops.gemm(X, Wi, None, epi=epi, variant=variant)
+        ref = F.silu(Xr @ gate.T) * (Xr @ up.T)
+    elif epi == 'resid':
+        Y = ops.gemm(X, W, b, R=R, epi=epi, variant=variant)
+        ref = Rr + F.linear(Xr, Wr, br)
+    else:
+        Y = ops.gemm(X, W, b, epi=epi, variant=variant)
+        lin = F.linear(Xr, Wr, br)
+        ref = O.gelu_tanh(lin) if epi == 'gelu_tanh' else O.gelu_erf(lin)
+    assert_close(Y, ref, ops.dtype, scale=2.0, what=f'{epi} v{variant}')
+
+
+def test_gemm_fp32_output_is_rounded_like_reference(ops):
+    """lm_head: the reference computes in the model dtype and then `.float()` (video_head_live_llava_qwen.py:155)."""
+    g = torch.Generator().manual_seed(5)
+    X = torch.randn(3, 64, generator=g); W = torch.randn(100, 64, generator=g) / 8
+    Y = ops.gemm(X, W, out_f32=True)
+    assert Y.dtype == torch.float32
+    assert torch.equal(Y.cpu(), Y.cpu().to(ops.dtype).float())
+    assert_close(Y, rt(X, ops.dtype) @ rt(W, ops.dtype).T, ops.dtype)
+
+
+def test_norms(ops):
+    g = torch.Generator().manual_seed(3)
+    for M, H in ((5, 64), (49, 3584), (33, 1152), (2, 72)):
+        x = torch.randn(M, H, generator=g) * 3; w = 1 + 0.1 * torch.randn(H, generator=g); b = 0.1 * torch.randn(H, generator=g)
+        xr, wr, br = rt(x, ops.dtype).to(ops.dtype), rt(w, ops.dtype).to(ops.dtype), rt(b, ops.dtype).to(ops.dtype)
+        assert_close(ops.rmsnorm(x, w, 1e-6), O.rms_norm(xr, wr, 1e-6), ops.dtype, what='rmsnorm')
+        assert_close(ops.layernorm(x, w, b, 1e-6), O.layer_norm(xr, wr, br, 1e-6), ops.dtype, what='layernorm')
+
+
+@pytest.mark.parametrize('pos0', [0, 1000, 30000])
+def test_rope_and_kv_append(ops, pos0):
+    g = torch.Generator().manual_seed(pos0 + 1)
+    S, nh, nkv, d, theta, cap = 9, 4, 2, 32, 1e6, 30080
+    qkv = torch.randn(S, (nh + 2 * nkv) * d, generator=g)
+    Kc = torch.zeros(nkv, cap, d, device=ops.dev, dtype=ops.dtype); Vc = torch.zeros_like(Kc)
+    q = ops.rope_append(qkv, nh, nkv, d, theta, pos0, Kc, Vc)
+    x = rt(qkv, ops.dtype).to(ops.dtype)
+    cfg = O.OracleConfig(hidden_size=nh * d, num_attention_heads=nh, num_key_value_heads=nkv, rope_theta=theta)
+    cos, sin = O.rope_tables(cfg, torch.arange(pos0, pos0 + S), ops.dtype)
+    qr = O.apply_rope(x[:, :nh * d].view(S, nh, d).transpose(0, 1), cos, sin).transpose(0, 1).reshape(S, nh * d)
+    kr = O.apply_rope(x[:, nh * d:(nh + nkv) * d].view(S, nkv, d).transpose(0, 1), cos, sin)
+    vr = x[:, (nh + nkv) * d:].view(S, nkv, d).transpose(0, 1)
+    # the raw entry point builds theta^(-2i/d) in double; torch's fp32 pow differs by <= 1 ulp, which the angle
+    # pos * inv_freq amplifies by pos (the model path takes torch's table via mmd_set_rope_inv_freq and is exact)
+    sc = 1.0 + pos0 * 2e-3
+    assert_close(q, qr, ops.dtype, scale=sc if ops.dtype == torch.float32 else 1.0, what='rope q')
+    assert_close(Kc[:, pos0:pos0 + S], kr, ops.dtype, scale=sc if ops.dtype == torch.float32 else 1.0, what='rope k')
+    assert torch.equal(Vc[:, pos0:pos0 + S].cpu(), vr)
+    assert Kc[:, :pos0].abs().sum() == 0 and Kc[:, pos0 + S:].abs().sum() == 0
+
+
+def ref_attention(q, K, V, nh, nkv, d, n_ctx, causal, dtype):
+    """Oracle attention math (oracle.duet_oracle.llm_layer) on [S, nh*d] / [nkv, n, d]."""
+    S = q.shape[0]; n_tot = n_ctx + S
+    qh = q.view(S, nh, d).transpose(0, 1).float()
+    rep = nh // nkv
+    kk = K[:, :n_tot].float()[:, None].expand(nkv, rep, n_tot, d).reshape(nh, n_tot, d)
+    vv = V[:, :n_tot].float()[:, None].expand(nkv, rep, n_tot, d).reshape(nh, n_tot, d)
+    s = qh @ kk.transpose(1, 2) * d ** -0.5
+    if causal:
+        mask = torch.arange(n_tot)[None, :] > (torch.arange(S)[:, None] + n_ctx)
+        s = s.masked_fill(mask[None], float('-inf'))
+    a = torch.softmax(s, -1)
+    return (a @ vv).transpose(0, 1).reshape(S, nh * d)
+
+
+ATTN_CASES = [  # S, nh, nkv, d, n_ctx, causal
+    (1, 4, 2, 16, 0, True), (7, 4, 2, 16, 5, True), (49, 4, 1, 32, 300, True), (130, 4, 2, 16, 41, True),
+    (49, 28, 4, 128, 0, True), (49, 28, 4, 128, 3000, True), (1, 28, 4, 128, 2500, True), (200, 8, 8, 72, 0, False),
+    (16, 2, 2, 24, 0, False), (33, 4, 4, 64, 100, False),
+]
+
+
+@pytest.mark.parametrize('S,nh,nkv,d,n_ctx,causal', ATTN_CASES)
+@pytest.mark.parametrize('variant', [1, 2])
+def test_attention(ops, S, nh, nkv, d, n_ctx, causal, variant):
+    if variant == 2 and ops.dtype != torch.bfloat16:
+        pytest.skip('the MFMA attention kernel is bf16 only')
+    g = torch.Generator().manual_seed(S * 13 + d)
+    cap = n_ctx + S + 37
+    q = torch.randn(S, nh * d, generator=g); K = torch.randn(nkv, cap, d, generator=g); V = torch.randn(nkv, cap, d, generator=g)
+    K[:, n_ctx + S:] = 1e4; V[:, n_ctx + S:] = 1e4          # poison beyond the valid range: must never be read into the result
+    Kc, Vc = K.to(ops.dev, ops.dtype), V.to(ops.dev, ops.dtype)
+    o = ops.attention(q, Kc, Vc, nh, nkv, d, n_ctx, causal, variant)
+    ref = ref_attention(rt(q, ops.dtype), rt(K, ops.dtype), rt(V, ops.dtype), nh, nkv, d, n_ctx, causal, ops.dtype)
+    assert torch.isfinite(o.float()).all()
+    assert_close(o, ref, ops.dtype, scale=1.5, what=f'attention v{variant}')
+
+
+def test_pooling_modes(ops):
+    g = torch.Generator().manual_seed(2)
+    for grid, stride in ((27, 4), (4, 2), (5, 2)):
+        x = torch.randn(2, grid * grid, 40, generator=g)
+        for mode, name in ((0, 'bilinear'), (1, 'average'), (2, 'max')):
+            cfg = O.tiny_config(video_pooling_stride=stride, mm_spatial_pool_mode=name)
+            ref = O.post_projector_pooling(cfg, rt(x, ops.dtype).to(ops.dtype))
+            assert_close(ops.pool(x, grid, mode, stride), ref, ops.dtype, what=f'pool {name} {grid}/{stride}')
+
+
+def test_preprocess_bit_exact_with_pillow(ops):
+    """mmd_preprocess_frames against image_processor outputs recorded from the reference stack (PIL bicubic)."""
+    z = load_npz('preprocess.npz')
+    from helpers import hip_model
+    m, _, _ = hip_model('A', ops.dtype)           # tower resolution 56
+    for tag in ('same', 'up', 'down'):
+        pv = m.get_vision_tower().image_processor.preprocess(torch.from_numpy(z[f'{tag}_frames']))['pixel_values']
+        ref = torch.from_numpy(z[f'{tag}_pixel_values'])
+        if ops.dtype == torch.float32:
+            assert torch.equal(pv.cpu(), ref), (pv.cpu() - ref).abs().max()
+        else:
+            assert torch.equal(pv.cpu(), ref.to(torch.bfloat16))
