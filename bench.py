@@ -1,0 +1,208 @@
+#!/usr/bin/env python
+"""bench.py -- frames/sec of the streaming video-text-duet forward path on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one synthetic video stream per GPU (BASELINE.json configs[1]):
+T 1-fps uint8 frames [T,3,336,336] already resident in HBM -> device preprocess (Pillow-exact bicubic to 384, normalise)
+-> SigLIP tower + projector + bilinear pooling (batches of 32 frames) -> per-frame causal LLaVA-OV-Qwen2-7B steps over the
+growing interleaved KV arena (one user query at t=0) -> informative/relevance head logits -> greedy per-frame response
+decision on the host -> greedy text generation (capped) when a frame fires.  Weights: seeded random init at the true
+shapes, bf16 (no checkpoints exist offline).  With N > 1 every rank runs its own stream (weak scaling) and the per-frame
+scores are all-gathered over RCCL inside the timed region.
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP events on the launch stream) and `cpu_baseline`
+(the oracle on the host cores, bounded sample).
+"""
+import argparse, json, math, os, sys, time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import torch
+
+HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_BF16_PEAK_TF = 2500.0      # dense bf16 MFMA peak
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=2)
+    p.add_argument('--warmup', type=int, default=1)
+    p.add_argument('--frames', type=int, default=300)
+    p.add_argument('--resolution', type=int, default=336)
+    p.add_argument('--frames-per-forward', type=int, default=1)
+    p.add_argument('--responses', type=int, default=4, help='target number of responses per stream (threshold is calibrated)')
+    p.add_argument('--max-new-tokens', type=int, default=32)
+    p.add_argument('--tiny', action='store_true', help='tiny model (plumbing check, not a valid measurement)')
+    p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--no-prof', action='store_true', help='do not bracket the dominant kernel with HIP events in the timed region')
+    p.add_argument('--layers', type=int, default=None, help='debug: override LLM layer count (INVALID as a measurement)')
+    return p.parse_args()
+
+
+def build(args, device):
+    from mmduet_amd.configuration_live import VideoHeadLiveLlavaQwenConfig
+    from mmduet_amd.modeling_live import VideoHeadLiveLlavaQwenForCausalLM
+    from mmduet_amd.tokenization_live import build_live_tokenizer_and_update_config
+    from mmduet_amd.weights import synthetic_weights
+    if args.tiny:
+        cfg = VideoHeadLiveLlavaQwenConfig(vocab_size=512, hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=4,
+                                           num_key_value_heads=2, vit_hidden_size=64, vit_intermediate_size=128, vit_num_hidden_layers=3,
+                                           vit_num_attention_heads=4, vit_image_size=56, vit_patch_size=14, video_pooling_stride=2,
+                                           frame_num_tokens=4, frame_resolution=56, v_placeholder='<image>')
+    else:
+        cfg = VideoHeadLiveLlavaQwenConfig(frame_num_tokens=49, frame_resolution=384, v_placeholder='<image>')
+        if args.layers:
+            cfg.num_hidden_layers = args.layers
+    k = max(1, args.frames_per_forward)
+    step_tokens = max(256, k * cfg.frame_num_tokens + 192)
+    model = VideoHeadLiveLlavaQwenForCausalLM(cfg, torch_dtype=torch.bfloat16, device=device, max_vit_batch=32, max_step_tokens=step_tokens,
+                                              kv_initial_tokens=args.frames * cfg.frame_num_tokens + 4096)
+    tok = build_live_tokenizer_and_update_config('synthetic:bench', cfg)
+    for name, t in synthetic_weights(cfg, seed=0, device=device, dtype=torch.bfloat16, scale='init02'):
+        model.load_tensor(name, t)
+    model.finalize()
+    return model, tok, cfg
+
+
+def make_driver(args, model, tok, threshold):
+    from mmduet_amd.arguments_live import LiveTestArguments
+    from mmduet_amd.inference import LiveInferForBenchmark
+    a = LiveTestArguments(llm_pretrained='synthetic:bench', frame_fps=1.0, bf16=True, stream_end_prob_threshold=threshold,
+                          score_heads='informative_score', max_new_tokens=args.max_new_tokens,
+                          frames_per_forward=args.frames_per_forward,
+                          system_prompt='A multimodal AI assistant is helping users with some activities.')
+    d = LiveInferForBenchmark(a, model=model, tokenizer=tok)
+    d.eos_token_id = -1            # random weights: let every response run to the cap so the work per response is fixed
+    return d
+
+
+def run_stream(driver, frames, query):
+    driver.reset()
+    driver.input_video_stream(frames)
+    driver.input_query_stream([{'role': 'user', 'content': query, 'time': 0.0}])
+    responses = driver.inference()
+    scores = torch.tensor([[x['informative_score'], x['relevance_score']] for x in driver.debug_data_list], dtype=torch.float32)
+    n_resp = sum(r['role'] == 'assistant' for r in responses)
+    return scores, n_resp
+
+
+def cpu_baseline(budget_s=25.0):
+    """The oracle (CPU restatement of the reference path) on the host cores, true layer shapes, bounded sample:
+    1 frame through patch-embed + 2 ViT layers + projector + pooling and one 49-token LLM step through 2 decoder
+    layers (+ final norm + heads), fp32; per-frame cost extrapolated to 26 ViT / 28 LLM layers."""
+    from oracle import duet_oracle as O
+    torch.manual_seed(0)
+    cores = torch.get_num_threads()
+    cfg = O.OracleConfig(num_hidden_layers=2, vit_layers=2, vocab_size=1024)
+    w = {}
+    for name, shape in O.weight_shapes(cfg).items():
+        w[name] = (torch.randn(shape) * 0.02) if len(shape) >= 2 else (torch.ones(shape) if name.endswith('weight') else torch.zeros(shape))
+    px = torch.randn(1, 3, 384, 384)
+    t0 = time.perf_counter(); O.vit_patch_embed(w, cfg, px); t_embed = time.perf_counter() - t0
+    t0 = time.perf_counter(); h = O.vit_forward(w, cfg, px); t_vit2 = time.perf_counter() - t0 - t_embed
+    t0 = time.perf_counter(); e = O.post_projector_pooling(cfg, O.connector(w, h)); t_proj = time.perf_counter() - t0
+    x = e.reshape(-1, cfg.hidden_size)
+    t0 = time.perf_counter(); hid, cache = O.llm_forward(w, cfg, x, None); t_llm2 = time.perf_counter() - t0
+    t0 = time.perf_counter(); hid, cache = O.llm_forward(w, cfg, x, cache); t_llm2 = min(t_llm2, time.perf_counter() - t0)
+    per_frame = t_embed + t_vit2 / 2 * 26 + t_proj + t_llm2 / 2 * 28
+    return dict(value=round(1.0 / per_frame, 4), unit='frames/s', cores=cores, kind='port',
+                sample=('oracle (oracle/duet_oracle.py), fp32, true layer shapes, empty KV: 1 frame x (patch-embed + 2 of 26 ViT layers + '
+                        'projector + pool) + one 49-token step x 2 of 28 decoder layers; per-frame time extrapolated linearly in layer count'),
+                per_frame_s=round(per_frame, 3))
+
+
+def main():
+    args = parse()
+    from mmduet_amd.distributed import init_distributed, gather_scores
+    import torch.distributed as dist
+    rank, world, local = init_distributed()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    device = torch.device('cuda', local)
+    torch.cuda.set_device(device)
+    model, tok, cfg = build(args, device)
+    R = args.resolution if not args.tiny else 48
+    g = torch.Generator().manual_seed(1 + rank)
+    frames = torch.randint(0, 256, (args.frames, 3, R, R), dtype=torch.uint8, generator=g).to(device)     # resident in HBM
+    query = 'Please narrate the video in real time.'[:24]
+
+    # calibration pass (untimed): grounding run -> threshold that makes ~`responses` frames fire
+    cal = make_driver(args, model, tok, 1.0)
+    scores, _ = run_stream(cal, frames, query)
+    inf = sorted(scores[:, 0].tolist(), reverse=True)
+    nresp = min(args.responses, len(inf) - 1)
+    threshold = 1.0 if nresp <= 0 else 0.5 * (inf[nresp - 1] + inf[nresp])
+    driver = make_driver(args, model, tok, threshold)
+
+    def sync():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    n_resp = 0
+    for _ in range(args.warmup):
+        sc, n_resp = run_stream(driver, frames, query)
+        gather_scores([sc])
+    prof_on = not args.no_prof
+    model.prof_reset()
+    model.prof_enable(prof_on)
+    sync()
+    t0 = time.perf_counter()
+    fwd = 0
+    for _ in range(args.steps):
+        sc, n_resp = run_stream(driver, frames, query)
+        allsc, lens = gather_scores([sc])
+        fwd += driver.forward_calls
+    sync()
+    dt = time.perf_counter() - t0
+    model.prof_enable(False)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    prof = model.prof_read()
+
+    if rank == 0:
+        total_frames = world * args.steps * args.frames
+        value = total_frames / dt
+        # dominant kernel class by accumulated time
+        dom = max(prof, key=lambda k: prof[k]['ms']) if prof_on else None
+        roof = None
+        if dom and prof[dom]['launches'] > 0:
+            p = prof[dom]
+            avg_ms = p['ms'] / p['launches']
+            if dom in ('gemm_tile', 'attn_vit'):
+                ach = p['flops'] / p['launches'] / (avg_ms * 1e-3) / 1e12
+                roof = dict(bound='mfma', kernel=dom, achieved=round(ach, 2), peak=MFMA_BF16_PEAK_TF, unit='TFLOP/s', frac=round(ach / MFMA_BF16_PEAK_TF, 4), traffic=None)
+            else:
+                ach = p['bytes'] / p['launches'] / (avg_ms * 1e-3) / 1e9
+                roof = dict(bound='hbm', kernel=dom, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(ach / HBM_PEAK_GBS, 4), traffic=None)
+            roof['avg_launch_us'] = round(avg_ms * 1e3, 2)
+            roof['launches'] = int(p['launches'])
+            roof['per_class_ms'] = {k: round(v['ms'], 1) for k, v in prof.items()}
+        cpu = None if (args.no_cpu_baseline or args.tiny or world > 1) else cpu_baseline()
+        line = {
+            'metric': 'video frames/sec (stream decode, 1fps 336px)', 'value': round(value, 2), 'unit': 'frames/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 2),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': ('tiny-plumbing' if args.tiny else 'llava-onevision-qwen2-7b + siglip-so400m-384') +
+                       f', {args.frames}-frame 1fps {R}px stream per GPU, query at t=0, greedy per-frame response decision',
+                       'frames_per_forward': args.frames_per_forward, 'responses_per_stream': int(n_resp),
+                       'max_new_tokens': args.max_new_tokens, 'threshold': round(threshold, 5), 'llm_forwards_per_step': fwd // max(1, args.steps),
+                       'kv_tokens_end': int(len(driver.past_key_values)), 'weights': 'random init N(0,0.02), true shapes' if not args.tiny else 'tiny',
+                       'parallelism': f'dp{world} (one stream per GPU, RCCL all-gather of scores)',
+                       'layers_override': args.layers},
+            'roofline': roof, 'cpu_baseline': cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
