@@ -140,6 +140,8 @@ int mmd_prof_reset(mmd_ctx* ctx);
  * 1 generic tile, 2 skinny/split-K, 3 large tile. */
 int mmd_op_gemm(mmd_ctx* ctx, const void* X, const void* W, const void* bias, const void* R, void* Y, int M, int N, int K,
                 int epi, int out_f32, int variant);
+/* micro-benchmark of one GEMM shape (HIP events on the context's stream); avg ms per call incl. any split-K reduce */
+int mmd_op_gemm_bench(mmd_ctx* ctx, int M, int N, int K, int epi, int variant, int iters, float* avg_ms_out);
 int mmd_op_rmsnorm(mmd_ctx* ctx, const void* x, const void* w, void* y, int M, int H, float eps);
 int mmd_op_layernorm(mmd_ctx* ctx, const void* x, const void* w, const void* b, void* y, int M, int H, float eps);
 /* q [S, nh*d] (rotated in place), k/v [S, nkv*d] appended rotated/unrotated at pos0.. into Kc/Vc [nkv, cap, d] */
@@ -149,6 +151,7 @@ int mmd_op_rope_append(mmd_ctx* ctx, void* qkv, int S, int nh, int nkv, int d, f
  * out [S, nh*d].  causal = 0 -> full attention over n_ctx + S keys.  variant: 0 auto, 1 simple, 2 mfma. */
 int mmd_op_attention(mmd_ctx* ctx, const void* q, const void* Kc, const void* Vc, void* out, int S, int nh, int nkv, int d,
                      int64_t n_ctx, int64_t cap, int causal, int variant);
+int mmd_op_attention_bench(mmd_ctx* ctx, int S, int nh, int nkv, int d, int64_t n_ctx, int variant, int iters, float* avg_ms_out);
 int mmd_op_pool(mmd_ctx* ctx, const void* x, void* y, int B, int grid, int H, int mode, int stride);
 
 #ifdef __cplusplus

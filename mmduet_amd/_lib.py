@@ -63,10 +63,12 @@ _SIGS = {
     'mmd_prof_read': (_I, [_VP, _VP, _VP, _VP, _VP]),
     'mmd_prof_reset': (_I, [_VP]),
     'mmd_op_gemm': (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _I]),
+    'mmd_op_gemm_bench': (_I, [_VP, _I, _I, _I, _I, _I, _I, C.POINTER(_F)]),
     'mmd_op_rmsnorm': (_I, [_VP, _VP, _VP, _VP, _I, _I, _F]),
     'mmd_op_layernorm': (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _F]),
     'mmd_op_rope_append': (_I, [_VP, _VP, _I, _I, _I, _I, _F, _I64, _VP, _VP, _VP, _I64]),
     'mmd_op_attention': (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I64, _I64, _I, _I]),
+    'mmd_op_attention_bench': (_I, [_VP, _I, _I, _I, _I, _I64, _I, _I, C.POINTER(_F)]),
     'mmd_op_pool': (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _I]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGS)

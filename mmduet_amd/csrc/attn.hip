@@ -21,8 +21,13 @@ struct AttnP {
     long long ldq, ldo, k_hs, k_ts, v_hs, v_ts, q_bs, kv_bs, o_bs;
     long long n_ctx;
     int S, nh, nkv, d, causal, splits, kv_per_split;
+    int v_tr;          // V stored transposed in 64-token blocks: (tok, e) at ((tok>>6)*d + e)*64 + (tok&63) inside the head region
     float scale_log2;
 };
+
+__device__ __forceinline__ long long v_off(const AttnP& p, long long tok, int e) {
+    return p.v_tr ? (((tok >> 6) * p.d + e) << 6) + (tok & 63) : tok * p.v_ts + e;
+}
 
 // ------------------------------------------------------------------------------------------------------------------
 template <typename T>
@@ -42,10 +47,9 @@ __global__ void attn_simple_kernel(AttnP p) {
         float sc = wave_sum(part) * p.scale_log2;
         float mn = fmaxf(m, sc);
         float alpha = exp2f(m - mn), pj = exp2f(sc - mn);
-        const T* vr = V + j * p.v_ts;
         float pr = rnd<T>(pj);
-        o0 = o0 * alpha + (lane < d ? pr * to_f<T>(vr[lane]) : 0.f);
-        o1 = o1 * alpha + (lane + 64 < d ? pr * to_f<T>(vr[lane + 64]) : 0.f);
+        o0 = o0 * alpha + (lane < d ? pr * to_f<T>(V[v_off(p, j, lane)]) : 0.f);
+        o1 = o1 * alpha + (lane + 64 < d ? pr * to_f<T>(V[v_off(p, j, lane + 64)]) : 0.f);
         l = l * alpha + pj;
         m = mn;
     }
@@ -117,7 +121,10 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(AttnP p) {
             s16x8_t kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = {0, 0, 0, 0, 0, 0, 0, 0};
             if (key < kend && c + 8 <= d) {
                 kv = *reinterpret_cast<const s16x8_t*>(Kg + key * p.k_ts + c);
-                vv = *reinterpret_cast<const s16x8_t*>(Vg + key * p.v_ts + c);
+                if (p.v_tr) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) vv[e] = (short)Vg[v_off(p, key, c + e)];
+                } else vv = *reinterpret_cast<const s16x8_t*>(Vg + key * p.v_ts + c);
             }
             *reinterpret_cast<s16x8_t*>(Ks + kr * KLD + c) = kv;
 #pragma unroll
@@ -230,6 +237,247 @@ __global__ void attn_combine_kernel(AttnP p, int nrows_total_all) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// attn_gqa128_kernel: the LLM attention of the streaming loop (head_dim 128, bf16, K arena [kvh][cap][128], V arena
+// transposed in 64-token blocks).  One block = 4 waves x RT row-tiles of 16 "rows" (row = tok*G + g: the G query heads
+// of a kv head are stacked so that a K/V tile is loaded once for all of them -- at S = 49, G = 7 the arithmetic
+// intensity is ~340 flop per KV byte, i.e. this kernel is MFMA-bound, not KV-bandwidth-bound).
+//   * 64-key tiles: K [64][128] and V^T [128][64] are each ONE contiguous 16 KB block of the arena, copied with
+//     16-byte loads through registers into padded LDS images (conflict-free fragment reads); the next tile's global
+//     loads are issued before the current tile's MFMAs (register prefetch) -- one tile of latency hiding.
+//   * S^T = mfma(K, Q): the query row sits in lane&15, so running max / sum / rescale are lane-local (+2 xor-shuffles
+//     across the 4 lanes that share a row); P goes from the S^T accumulators straight into the B operand of
+//     O^T = mfma(V^T, P) (k-slot order {g*4+j, 16+g*4+j} on both operands) -- no LDS round trip for P.
+//   * masking work only on tiles that cross the causal diagonal / the end of the key range.
+//   * long contexts: grid.z splits the keys (flash-decoding); attn_combine128_kernel merges the fp32 partials.
+// ------------------------------------------------------------------------------------------------------------------
+template <int RT>
+__global__ __launch_bounds__(256) void attn_gqa128_kernel(AttnP p) {
+    constexpr int D = 128, KT = 64, KLD = D + 8, VLD = KT + 8;
+    __shared__ __attribute__((aligned(16))) bf16_t Ks[KT * KLD];
+    __shared__ __attribute__((aligned(16))) bf16_t Vt[D * VLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int G = p.nh / p.nkv, kvh = blockIdx.y;
+    const int rows_total = p.S * G;
+    const int row_base = blockIdx.x * (64 * RT) + wave * (16 * RT);
+    const long long n_tot = p.n_ctx + p.S;
+    const bf16_t* Kg = (const bf16_t*)p.K + kvh * p.k_hs;
+    const bf16_t* Vg = (const bf16_t*)p.V + kvh * p.v_hs;
+
+    int my_row[RT], my_tok[RT], my_head[RT]; bool row_ok[RT]; long long my_limit[RT];
+    bf16x8_t qf[RT][4];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        my_row[rt] = row_base + rt * 16 + lr;
+        row_ok[rt] = my_row[rt] < rows_total;
+        my_tok[rt] = row_ok[rt] ? my_row[rt] / G : 0;
+        my_head[rt] = kvh * G + (row_ok[rt] ? my_row[rt] % G : 0);
+        my_limit[rt] = !row_ok[rt] ? 0 : (p.causal ? p.n_ctx + my_tok[rt] + 1 : n_tot);
+        const bf16_t* qrow = (const bf16_t*)p.q + (long long)my_tok[rt] * p.ldq + (long long)my_head[rt] * D;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            s16x8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (row_ok[rt]) v = *reinterpret_cast<const s16x8_t*>(qrow + c * 32 + lq * 8);
+            qf[rt][c] = __builtin_bit_cast(bf16x8_t, v);
+        }
+    }
+    const bool wave_active = row_base < rows_total;                 // wave-uniform
+    // key range of this block / split (multiples of 64 except at the very end)
+    const int blk_first_row = blockIdx.x * (64 * RT);
+    const int blk_last_row = min(blk_first_row + 64 * RT - 1, rows_total - 1);
+    const long long blk_limit = p.causal ? min(n_tot, p.n_ctx + (long long)(blk_last_row / G) + 1) : n_tot;
+    const long long blk_min_limit = p.causal ? p.n_ctx + (long long)(blk_first_row / G) + 1 : n_tot;   // keys below this are visible to every row
+    const long long kbeg = (long long)blockIdx.z * p.kv_per_split;
+    const long long kend = min(blk_limit, kbeg + p.kv_per_split);
+
+    f32x4_t oacc[RT][8];
+    float m_run[RT], l_run[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        m_run[rt] = -INFINITY; l_run[rt] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) oacc[rt][t] = f32x4_t{0, 0, 0, 0};
+    }
+
+    // staging: 2048 16-byte pieces per tile (1024 K + 1024 V^T), 8 per thread
+    s16x8_t pre[8];
+    auto prefetch = [&](long long k0) {
+        const long long blk = k0 >> 6;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int i = tid + 256 * j;                                   // K piece: row i>>4 (key), chunk i&15
+            pre[j] = *reinterpret_cast<const s16x8_t*>(Kg + (k0 + (i >> 4)) * p.k_ts + (i & 15) * 8);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int i = tid + 256 * j;                                   // V^T piece: row i>>3 (dim), chunk i&7 (8 keys)
+            pre[4 + j] = *reinterpret_cast<const s16x8_t*>(Vg + ((blk * D + (i >> 3)) << 6) + (i & 7) * 8);
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { int i = tid + 256 * j; *reinterpret_cast<s16x8_t*>(Ks + (i >> 4) * KLD + (i & 15) * 8) = pre[j]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { int i = tid + 256 * j; *reinterpret_cast<s16x8_t*>(Vt + (i >> 3) * VLD + (i & 7) * 8) = pre[4 + j]; }
+    };
+
+    if (kbeg < kend) prefetch(kbeg);
+    for (long long k0 = kbeg; k0 < kend; k0 += KT) {
+        __syncthreads();
+        commit();
+        __syncthreads();
+        if (k0 + KT < kend) prefetch(k0 + KT);
+        if (!wave_active) continue;
+        const bool need_mask = (k0 + KT > blk_min_limit) || (k0 + KT > kend);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f32x4_t st[RT][2];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) { st[rt][0] = f32x4_t{0, 0, 0, 0}; st[rt][1] = f32x4_t{0, 0, 0, 0}; }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + (h * 32 + t * 16 + lr) * KLD + c * 32 + lq * 8);
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) st[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[rt][c], st[rt][t], 0, 0, 0);
+                }
+            bf16x8_t pf[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                float sv[8];
+                float mx = -INFINITY;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = st[rt][t][r] * p.scale_log2;
+                        if (need_mask) {
+                            long long key = k0 + h * 32 + t * 16 + lq * 4 + r;
+                            if (!(key < my_limit[rt] && key < kend)) v = -INFINITY;
+                        }
+                        sv[t * 4 + r] = v;
+                        mx = fmaxf(mx, v);
+                    }
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                float m_new = fmaxf(m_run[rt], mx);
+                float m_use = m_new == -INFINITY ? 0.f : m_new;
+                float alpha = __builtin_amdgcn_exp2f(m_run[rt] - m_use);
+                float psum = 0.f;
+                s16x8_t pk;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { float pv = __builtin_amdgcn_exp2f(sv[i] - m_use); psum += pv; pk[i] = (short)f2bf(pv); }
+                l_run[rt] = l_run[rt] * alpha + psum;
+                m_run[rt] = m_new;
+                pf[rt] = __builtin_bit_cast(bf16x8_t, pk);
+                if (alpha != 1.0f) {
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) oacc[rt][t] *= alpha;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const bf16_t* vrow = Vt + (t * 16 + lr) * VLD + h * 32;
+                s16x4_t lo = *reinterpret_cast<const s16x4_t*>(vrow + lq * 4);
+                s16x4_t hi = *reinterpret_cast<const s16x4_t*>(vrow + 16 + lq * 4);
+                s16x8_t vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                bf16x8_t vfb = __builtin_bit_cast(bf16x8_t, vf);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) oacc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfb, pf[rt], oacc[rt][t], 0, 0, 0);
+            }
+        }
+    }
+
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        float l = l_run[rt];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        if (!row_ok[rt]) continue;
+        if (p.splits == 1) {
+            bf16_t* orow = (bf16_t*)p.out + (long long)my_tok[rt] * p.ldo + (long long)my_head[rt] * D;
+            float inv = l > 0.f ? 1.0f / l : 0.f;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                s16x4_t o = {(short)f2bf(oacc[rt][t][0] * inv), (short)f2bf(oacc[rt][t][1] * inv), (short)f2bf(oacc[rt][t][2] * inv), (short)f2bf(oacc[rt][t][3] * inv)};
+                *reinterpret_cast<s16x4_t*>(orow + t * 16 + lq * 4) = o;
+            }
+        } else {
+            long long grow = (long long)kvh * rows_total + my_row[rt];
+            long long nrows_all = (long long)gridDim.y * rows_total;
+            float* wo = p.ws_o + ((long long)blockIdx.z * nrows_all + grow) * D;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) *reinterpret_cast<f32x4_t*>(wo + t * 16 + lq * 4) = oacc[rt][t];
+            if (lq == 0) { float* wml = p.ws_ml + ((long long)blockIdx.z * nrows_all + grow) * 2; wml[0] = m_run[rt]; wml[1] = l; }
+        }
+    }
+}
+
+// merge the split partials of attn_gqa128_kernel: one wave per row.  The per-split (m, l) pairs are read one split per
+// lane (a single latency instead of a serial chain), the weights live in registers and are broadcast with shuffles;
+// the 128-dim partial rows are then accumulated with independent, fully coalesced 512-byte loads.
+__global__ __launch_bounds__(256) void attn_combine128_kernel(AttnP p, int nrows_all) {
+    const int grow = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (grow >= nrows_all) return;
+    const int G = p.nh / p.nkv, rows_total = p.S * G;
+    const int row = grow % rows_total, kvh = grow / rows_total;
+    const int tok = row / G, head = kvh * G + row % G;
+    float a0 = 0.f, a1 = 0.f, L = 0.f;
+    float M = -INFINITY;
+    for (int s0 = 0; s0 < p.splits; s0 += 64) {          // running merge over groups of 64 splits (usually one group)
+        const int s = s0 + lane;
+        float ms = -INFINITY, ls = 0.f;
+        if (s < p.splits) { const float* ml = p.ws_ml + ((long long)s * nrows_all + grow) * 2; ms = ml[0]; ls = ml[1]; }
+        float Mn = fmaxf(M, wave_max(ms));
+        float Mu = Mn == -INFINITY ? 0.f : Mn;
+        float resc = __builtin_amdgcn_exp2f(M - Mu);           // M = -inf -> 0
+        float w = __builtin_amdgcn_exp2f(ms - Mu);              // 0 for empty splits
+        a0 *= resc; a1 *= resc;
+        L = L * resc + wave_sum(w * ls);
+        M = Mn;
+        const int cnt = min(64, p.splits - s0);
+        const float* obase = p.ws_o + ((long long)s0 * nrows_all + grow) * 128 + lane * 2;
+#pragma unroll 4
+        for (int j = 0; j < cnt; ++j) {
+            float wj = __shfl(w, j, 64);
+            const float* o = obase + (long long)j * nrows_all * 128;
+            float2 v = *reinterpret_cast<const float2*>(o);
+            a0 += wj * v.x; a1 += wj * v.y;
+        }
+    }
+    float inv = L > 0.f ? 1.0f / L : 0.f;
+    bf16_t* orow = (bf16_t*)p.out + (long long)tok * p.ldo + (long long)head * 128;
+    s16x2_t o = {(short)f2bf(a0 * inv), (short)f2bf(a1 * inv)};
+    *reinterpret_cast<s16x2_t*>(orow + lane * 2) = o;
+}
+
+template <int RT>
+static hipError_t launch_gqa128(AttnP& p, const AttnArgs& a, hipStream_t st) {
+    const int G = a.nh / a.nkv, rows_total = a.S * G;
+    const int qblocks = cdiv(rows_total, 64 * RT);
+    const long long n_tot = a.n_ctx + a.S;
+    const int blocks = qblocks * a.nkv;
+    const int tiles = cdiv(n_tot, 64);
+    int splits = 1;
+    if (blocks < 256 && a.ws) {
+        splits = cdiv(320, blocks);
+        int maxs = tiles / 2; if (maxs < 1) maxs = 1;              // >= 2 key tiles per split
+        if (splits > maxs) splits = maxs;
+        while (splits > 1 && (size_t)splits * a.nkv * rows_total * (128 + 2) * sizeof(float) > a.ws_bytes) --splits;
+    }
+    int per = cdiv(tiles, splits) * 64;
+    splits = cdiv(n_tot, per);
+    p.splits = splits; p.kv_per_split = per;
+    const int nrows_all = a.nkv * rows_total;
+    p.ws_o = a.ws;
+    p.ws_ml = a.ws ? a.ws + (size_t)splits * nrows_all * 128 : nullptr;
+    hipLaunchKernelGGL((attn_gqa128_kernel<RT>), dim3(qblocks, a.nkv, splits), dim3(256), 0, st, p);
+    if (splits > 1) hipLaunchKernelGGL(attn_combine128_kernel, dim3(cdiv(nrows_all, 4)), dim3(256), 0, st, p, nrows_all);
+    return hipGetLastError();
+}
+
 template <int DP>
 static hipError_t launch_mfma(AttnP& p, const AttnArgs& a, hipStream_t st) {
     int G = a.nh / a.nkv;
@@ -266,13 +514,19 @@ hipError_t launch_attention(int dtype, const AttnArgs& a, hipStream_t st) {
     p.k_hs = a.k_hs; p.k_ts = a.k_ts; p.v_hs = a.v_hs; p.v_ts = a.v_ts;
     p.q_bs = a.q_bstride; p.kv_bs = a.kv_bstride; p.o_bs = a.o_bstride;
     p.n_ctx = a.n_ctx; p.S = a.S; p.nh = a.nh; p.nkv = a.nkv; p.d = a.d; p.causal = a.causal;
-    p.splits = 1; p.kv_per_split = 0;
+    p.splits = 1; p.kv_per_split = 0; p.v_tr = a.v_transposed;
     p.scale_log2 = (1.0f / sqrtf((float)a.d)) * 1.4426950408889634f;
     bool can_mfma = dtype == MMD_BF16 && (a.d % 8) == 0 && a.d <= 128 && (a.ldq % 8) == 0 && (a.k_ts % 8) == 0 && (a.v_ts % 8) == 0 &&
                     (a.k_hs % 8) == 0 && (a.v_hs % 8) == 0 && (a.kv_bstride % 8) == 0 && (a.q_bstride % 8) == 0;
     int variant = a.variant;
-    if (variant == 0) variant = can_mfma ? 2 : 1;
+    const bool can_gqa128 = can_mfma && a.d == 128 && a.v_transposed && a.batch == 1 && a.k_ts == 128;
+    if (variant == 0) variant = can_gqa128 ? 3 : (can_mfma ? 2 : 1);
     if (variant == 2 && !can_mfma) return hipErrorInvalidValue;
+    if (variant == 3) {
+        if (!can_gqa128) return hipErrorInvalidValue;
+        const int rows_total = a.S * (a.nh / a.nkv);
+        return rows_total <= 64 ? launch_gqa128<1>(p, a, st) : launch_gqa128<2>(p, a, st);
+    }
     if (variant == 1) {
         if (a.d > 128) return hipErrorInvalidValue;
         dim3 grid(a.S, a.nh, a.batch);

@@ -55,11 +55,12 @@ static inline size_t dtype_size(int dt) { return dt == MMD_F32 ? 4 : 2; }
 
 // ---- epilogues of the GEMM family ------------------------------------------------------------------------------
 enum { EPI_NONE = 0, EPI_GELU_TANH = 1, EPI_GELU_ERF = 2, EPI_RESID = 3, EPI_SWIGLU = 4 };
-enum { GEMM_AUTO = 0, GEMM_GENERIC = 1, GEMM_SKINNY = 2, GEMM_LARGE = 3 };
+enum { GEMM_AUTO = 0, GEMM_GENERIC = 1, GEMM_SKINNY = 2, GEMM_LARGE = 3, GEMM_BIG = 4 };
 
 struct GemmArgs {
     const void* X; int64_t ldx;      // [M,K]
-    const void* W; int64_t ldw;      // [N,K]  (nn.Linear layout)
+    const void* W; int64_t ldw;      // [N,K]  (nn.Linear layout); may be null when only Wp exists
+    const void* Wp = nullptr;        // same matrix, MFMA-fragment-major (launch_pack_w); enables the weight-streaming skinny kernel
     const void* bias;                // [N] or null (ctx dtype)
     const void* R; int64_t ldr;      // residual [M,N] (EPI_RESID)
     void* Y; int64_t ldy;            // [M,N] (or [M,N/2] for SWIGLU); ctx dtype, or fp32 if out_f32
@@ -71,11 +72,13 @@ struct GemmArgs {
 
 // launchers (dtype = mmd_dtype).  All return hipError_t of the launch.
 hipError_t launch_gemm(int dtype, const GemmArgs& a, hipStream_t st, int* kind_out);
+hipError_t launch_pack_w(const void* W, int64_t ldw, int N, int K, void* out, hipStream_t st);   // bf16 only, N%16==0, K%32==0
 hipError_t launch_rmsnorm(int dtype, const void* x, const void* w, void* y, int M, int H, float eps, hipStream_t st);
 hipError_t launch_layernorm(int dtype, const void* x, const void* w, const void* b, void* y, int M, int H, float eps, hipStream_t st);
 hipError_t launch_add_rows(int dtype, void* x, const void* add, int M, int H, int period, hipStream_t st);   // x[m,:] += add[m % period,:]
 hipError_t launch_rope_append(int dtype, const void* qkv, int S, int nh, int nkv, int d, const float* inv_freq_dev, int64_t pos0, void* q_out,
-                              void* Kc, void* Vc, int64_t cap, hipStream_t st);
+                              void* Kc, void* Vc, int64_t cap, int v_transposed, hipStream_t st);
+hipError_t launch_transpose_v(int dtype, const void* src, void* dst, int nkv, int64_t cap, int d, hipStream_t st);
 hipError_t launch_embed(int dtype, const void* table, const int64_t* ids, int k, int H, int64_t vocab, void* out, hipStream_t st);
 hipError_t launch_im2col(int dtype, const void* px, int B, int img, int patch, int grid, int Kpad, void* out, hipStream_t st);
 hipError_t launch_pool(int dtype, const void* x, void* y, int B, int grid, int H, int mode, int stride, hipStream_t st);
@@ -95,6 +98,7 @@ struct AttnArgs {
     const void* q; int64_t ldq;      // [S, nh*d] row stride ldq
     const void* K; const void* V;    // element (kv head h, token t, e) at K + h*k_hs + t*k_ts + e
     int64_t k_hs, k_ts, v_hs, v_ts;  // arena: hs = cap*d, ts = d ; fused ViT qkv rows: hs = d, ts = 3C
+    int v_transposed;                // V arena stored transposed in 64-token blocks (see attn.hip); v_ts unused then
     void* out; int64_t ldo;          // [S, nh*d]
     int S, nh, nkv, d;
     int64_t n_ctx;                   // keys before this step; total keys = n_ctx + S

@@ -226,6 +226,303 @@ __global__ void splitk_reduce_kernel(GemmP p, int splits) {
     store4<T>(p, m, n, v);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Weight-streaming GEMM for M <= 16*MT rows (the per-frame LLM step, M ~ 49, and M = 1 decoding): HBM-bound, every
+// weight byte is read exactly once.
+//   * W is stored MFMA-fragment-major ("packed", pack_w16x32_kernel): tile (nt, kt) = 16 rows x 32 k is one contiguous
+//     1 KiB block whose 16-byte piece `lane` is exactly that lane's A operand.  A wave streams its n-tile along K with
+//     one fully coalesced 1 KiB non-temporal load per MFMA k-step, straight into VGPRs (no LDS round trip for the
+//     operand that is used once).
+//   * X [M,K] (L2-resident, re-read by every block) is staged through LDS once per block in full 256-byte row pieces
+//     and shared by the 4 waves; the LDS image is fragment-ordered with an XOR on the row index so that both the
+//     row-contiguous ds_write_b128 and the fragment ds_read_b128 are bank-conflict-free.
+//   * 4 waves = 4*NT n-tiles per block; K is split over grid.y into fp32 slabs when N alone cannot fill 256 CUs
+//     (deterministic slab reduce, no atomics).
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void pack_w16x32_kernel(const bf16_t* __restrict__ W, long long ldw, int N, int K, bf16_t* __restrict__ out) {
+    // one thread per 16-byte piece: out[((nt*KT + kt)*64 + lane)*8 + e] = W[nt*16 + (lane&15)][kt*32 + (lane>>4)*8 + e]
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int KT = K >> 5;
+    long long pieces = (long long)(N >> 4) * KT * 64;
+    if (i >= pieces) return;
+    int lane = (int)(i & 63);
+    long long tile = i >> 6;
+    int kt = (int)(tile % KT);
+    long long nt = tile / KT;
+    const bf16_t* src = W + (nt * 16 + (lane & 15)) * ldw + kt * 32 + (lane >> 4) * 8;
+    *reinterpret_cast<s16x8_t*>(out + i * 8) = *reinterpret_cast<const s16x8_t*>(src);
+}
+
+hipError_t launch_pack_w(const void* W, int64_t ldw, int N, int K, void* out, hipStream_t st) {
+    long long pieces = (long long)(N >> 4) * (K >> 5) * 64;
+    if (pieces <= 0) return hipSuccess;
+    hipLaunchKernelGGL(pack_w16x32_kernel, dim3(cdiv(pieces, 256)), dim3(256), 0, st, (const bf16_t*)W, (long long)ldw, N, K, (bf16_t*)out);
+    return hipGetLastError();
+}
+
+__device__ __forceinline__ int xs_slot(int ktl, int kq, int r) { return kq * 16 + (r ^ (kq + 4 * (ktl & 1))); }
+
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmP p, int KT, int kt_per_split) {
+    constexpr int KS = 4;                                   // k-tiles (of 32) per pipeline step
+    __shared__ __attribute__((aligned(16))) bf16_t Xs[2][MT * KS * 64 * 8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int ntiles = p.N >> 4;
+    const int nt0 = (blockIdx.x * 4 + wave) * NT;
+    const int kt_beg = blockIdx.y * kt_per_split;
+    const int kt_end = min(KT, kt_beg + kt_per_split);
+    const bf16_t* X = (const bf16_t*)p.X;
+    const bf16_t* Wp = (const bf16_t*)p.W;
+
+    f32x4_t acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0, 0, 0, 0};
+
+    bf16x8_t wc[NT][KS], wn[NT][KS];
+    s16x8_t xr[MT];
+
+    auto load_w = [&](bf16x8_t (&w)[NT][KS], int kt) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                s16x8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (nt0 + j < ntiles && kt + s < kt_end)
+                    v = __builtin_nontemporal_load(reinterpret_cast<const s16x8_t*>(Wp + (((long long)(nt0 + j) * KT + kt + s) * 64 + lane) * 8));
+                w[j][s] = __builtin_bit_cast(bf16x8_t, v);
+            }
+    };
+    auto load_x = [&](int kt) {
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            int i = tid + 256 * j, m = i >> 4, c = i & 15;
+            s16x8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (m < p.M && kt + (c >> 2) < kt_end) v = *reinterpret_cast<const s16x8_t*>(X + (long long)m * p.ldx + kt * 32 + c * 8);
+            xr[j] = v;
+        }
+    };
+    auto write_x = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            int i = tid + 256 * j, m = i >> 4, c = i & 15;
+            int mt = m >> 4, r = m & 15, ktl = c >> 2, kq = c & 3;
+            *reinterpret_cast<s16x8_t*>(&Xs[buf][((mt * KS + ktl) * 64 + xs_slot(ktl, kq, r)) * 8]) = xr[j];
+        }
+    };
+
+    load_w(wc, kt_beg);
+    load_x(kt_beg);
+    write_x(0);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = kt_beg; kt < kt_end; kt += KS) {
+        const bool more = kt + KS < kt_end;
+        if (more) { load_w(wn, kt + KS); load_x(kt + KS); }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            if (kt + s < kt_end) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    bf16x8_t xf = *reinterpret_cast<const bf16x8_t*>(&Xs[cur][((i * KS + s) * 64 + xs_slot(s, lq, lr)) * 8]);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[j][s], xf, acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+        if (more) write_x(cur ^ 1);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) wc[j][s] = wn[j][s];
+        cur ^= 1;
+    }
+
+    if (gridDim.y > 1) {
+        float* ws = p.ws + (long long)blockIdx.y * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                int m = i * 16 + lr, n = (nt0 + j) * 16 + lq * 4;
+                if (m < p.M && nt0 + j < ntiles) *reinterpret_cast<f32x4_t*>(ws + (long long)m * p.N + n) = acc[i][j];
+            }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        int m = i * 16 + lr;
+        if (p.epi == EPI_SWIGLU) {
+            if constexpr (NT >= 2) {
+#pragma unroll
+                for (int j = 0; j < NT; j += 2) {
+                    if (nt0 + j + 1 < ntiles) {
+                        int n = (nt0 + j) * 16 + lq * 4;
+                        float g[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                        float u[4] = {acc[i][j + 1][0], acc[i][j + 1][1], acc[i][j + 1][2], acc[i][j + 1][3]};
+                        store4_swiglu<bf16_t>(p, m, n, g, u);
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                if (nt0 + j < ntiles) {
+                    int n = (nt0 + j) * 16 + lq * 4;
+                    float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                    store4<bf16_t>(p, m, n, v);
+                }
+            }
+        }
+    }
+}
+
+template <int MT>
+static void launch_skinny_mt(const GemmP& p, const GemmArgs& a, hipStream_t st) {
+    const int KT = a.K >> 5, ntiles = a.N >> 4;
+    const int NT = (a.epi == EPI_SWIGLU || ntiles >= 4096) ? 2 : 1;
+    int nblocks = cdiv(ntiles, 4 * NT);
+    int splits = 1;
+    if (nblocks < 512 && a.epi != EPI_SWIGLU && a.splitk_ws) {
+        splits = cdiv(512, nblocks);
+        int maxs = KT / 16; if (maxs < 1) maxs = 1;              // >= 512 k per split
+        if (splits > maxs) splits = maxs;
+        if (splits > 16) splits = 16;
+        while (splits > 1 && (size_t)splits * a.M * a.N * sizeof(float) > a.splitk_ws_bytes) --splits;
+    }
+    int ktper = (int)round_up(cdiv(KT, splits), 4);
+    splits = cdiv(KT, ktper);
+    dim3 grid(nblocks, splits);
+    if (NT == 2) hipLaunchKernelGGL((gemm_skinny_kernel<MT, 2>), grid, dim3(256), 0, st, p, KT, ktper);
+    else hipLaunchKernelGGL((gemm_skinny_kernel<MT, 1>), grid, dim3(256), 0, st, p, KT, ktper);
+    if (splits > 1) {
+        long long work = (long long)a.M * ((a.N + 3) / 4);
+        hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), dim3(cdiv(work, 256)), dim3(256), 0, st, p, splits);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// MFMA-bound GEMM for M >= 128 rows (ViT tower / projector at M = 32 x 729, multi-frame LLM chunks at M = 49k).
+// 128 x BN block tile, 4 waves (2 x 2), BK = 64, two LDS buffers filled by direct-to-LDS DMA (global_load_lds, 16 B per
+// lane) one K-tile ahead of the MFMAs, ONE barrier per K-tile.
+//   * W (packed, fragment-major): each 16x32 fragment tile is a contiguous 1 KiB piece -> one DMA instruction per piece,
+//     the LDS image is already in fragment order (ds_read_b128 at lane*16: conflict-free, no swizzle).
+//   * X (row-major): DMA pieces of 8 rows x 128 B (full cache lines); the 16-byte chunk index is XOR-ed with the row on
+//     the SOURCE address and again on the fragment read (LDS destination of the DMA is lane-linear by construction),
+//     which makes the row-strided fragment reads bank-conflict-free.
+//   * rows beyond M are clamped on load and masked at the store; N % BN == 0 and K % 64 == 0 are dispatch conditions.
+// ------------------------------------------------------------------------------------------------------------------
+template <int BN>
+__global__ __launch_bounds__(256) void gemm_big_kernel(GemmP p, int KT) {
+    constexpr int BM = 128, BK = 64;
+    constexpr int TM = 4, TN = BN / 32;                      // 16x16 tiles per wave (wave tile 64 x BN/2)
+    constexpr int XE = BM * BK, WE = BN * BK;                // elements per buffer image
+    __shared__ __attribute__((aligned(16))) bf16_t lds[2 * (XE + WE)];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * (BN / 2);
+    // XCD-aware tile order: consecutive block ids round-robin over the 8 XCDs; give each XCD a contiguous run of
+    // n-tiles of one m-panel so the X panel stays in that XCD's L2
+    const int nbx = gridDim.x, nby = gridDim.y;
+    int bid = blockIdx.y * nbx + blockIdx.x;
+    const int nblk = nbx * nby;
+    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+    const int m0 = (bid / nbx) * BM, n0 = (bid % nbx) * BN;
+    const bf16_t* X = (const bf16_t*)p.X;
+    const bf16_t* Wp = (const bf16_t*)p.W;
+    const int nsteps = p.K / BK;
+
+    auto stage = [&](int buf, int step) {
+        bf16_t* xs = lds + buf * (XE + WE);
+        bf16_t* ws = xs + XE;
+        const int k0 = step * BK;
+#pragma unroll
+        for (int j = 0; j < BM / 32; ++j) {                  // X: pieces of 8 rows x 64 k
+            const int pi = wave + 4 * j;
+            int row = m0 + pi * 8 + (lane >> 3);
+            row = row < p.M ? row : p.M - 1;
+            const int chunk = (lane & 7) ^ (lane >> 3);
+            const bf16_t* src = X + (long long)row * p.ldx + k0 + chunk * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(xs + pi * 512), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < BN / 32; ++j) {                  // W: (n-tile, k-tile) fragment pieces
+            const int wi = wave + 4 * j;
+            const bf16_t* src = Wp + (((long long)(n0 / 16 + (wi >> 1)) * KT + (k0 >> 5) + (wi & 1)) * 64 + lane) * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(ws + wi * 512), 16, 0, 0);
+        }
+    };
+
+    f32x4_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0, 0, 0, 0};
+
+    stage(0, 0);
+    int cur = 0;
+    for (int t = 0; t < nsteps; ++t) {
+        __syncthreads();                                     // (compiler drains the DMA queue here: vmcnt(0))
+        if (t + 1 < nsteps) stage(cur ^ 1, t + 1);
+        const bf16_t* xs = lds + cur * (XE + WE);
+        const bf16_t* ws = xs + XE;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            bf16x8_t xf[TM], wf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int mt = (wm >> 4) + i;
+                const int c = kt * 4 + lq;
+                xf[i] = *reinterpret_cast<const bf16x8_t*>(xs + (mt * 2 + (lr >> 3)) * 512 + (lr & 7) * 64 + ((c ^ (lr & 7)) * 8));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const bf16x8_t*>(ws + (((wn >> 4) + j) * 2 + kt) * 512 + lane * 8);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+        }
+        cur ^= 1;
+    }
+
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm + i * 16 + lr;
+        if (p.epi == EPI_SWIGLU) {
+#pragma unroll
+            for (int j = 0; j < TN; j += 2) {
+                const int n = n0 + wn + j * 16 + lq * 4;
+                float g[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                float u[4] = {acc[i][j + 1][0], acc[i][j + 1][1], acc[i][j + 1][2], acc[i][j + 1][3]};
+                store4_swiglu<bf16_t>(p, m, n, g, u);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn + j * 16 + lq * 4;
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                store4<bf16_t>(p, m, n, v);
+            }
+        }
+    }
+}
+
+static bool big_packed_ok(int dtype, const GemmArgs& a, int BN) {
+    return dtype == MMD_BF16 && a.Wp != nullptr && a.M > 64 && (a.N % BN) == 0 && (a.K % 64) == 0 && (a.ldx % 8) == 0 &&
+           ((uintptr_t)a.X % 16) == 0;
+}
+
+// packed-W skinny path usable?  bf16, M <= 64, N % 16 == 0, K % 32 == 0, 16-byte aligned rows of X
+static bool skinny_packed_ok(int dtype, const GemmArgs& a) {
+    return dtype == MMD_BF16 && a.Wp != nullptr && a.M <= 64 && (a.N % 16) == 0 && (a.K % 32) == 0 && (a.ldx % 8) == 0 &&
+           ((uintptr_t)a.X % 16) == 0 && (a.epi != EPI_SWIGLU || (a.N % 32) == 0);
+}
+
 template <typename T>
 static hipError_t launch_t(const GemmArgs& a, hipStream_t st, int* kind_out) {
     GemmP p;
@@ -238,6 +535,31 @@ static hipError_t launch_t(const GemmArgs& a, hipStream_t st, int* kind_out) {
     bool skinny = (variant == GEMM_SKINNY) || (variant == GEMM_AUTO && a.M <= 64);
     bool large = (variant == GEMM_LARGE) || (variant == GEMM_AUTO && a.M >= 256 && a.N >= 128);
     if (kind_out) *kind_out = skinny ? MMD_K_GEMM_SKINNY : MMD_K_GEMM_TILE;
+    if constexpr (sizeof(T) == 2) {
+        const bool want_big = variant == GEMM_BIG || (variant == GEMM_AUTO && a.M > 64);
+        if (want_big) {
+            int bn = 0;
+            if (big_packed_ok(MMD_BF16, a, 128) && (long long)cdiv(a.M, 128) * (a.N / 128) >= 224) bn = 128;
+            else if (big_packed_ok(MMD_BF16, a, 64)) bn = 64;
+            if (bn) {
+                p.W = a.Wp;
+                if (kind_out) *kind_out = MMD_K_GEMM_TILE;
+                dim3 grid(a.N / bn, cdiv(a.M, 128));
+                if (bn == 128) hipLaunchKernelGGL((gemm_big_kernel<128>), grid, dim3(256), 0, st, p, a.K >> 5);
+                else hipLaunchKernelGGL((gemm_big_kernel<64>), grid, dim3(256), 0, st, p, a.K >> 5);
+                return hipGetLastError();
+            }
+            if (variant == GEMM_BIG) return hipErrorInvalidValue;
+        }
+        if (skinny && skinny_packed_ok(MMD_BF16, a)) {
+            p.W = a.Wp;
+            if (a.M <= 16) launch_skinny_mt<1>(p, a, st);
+            else if (a.M <= 32) launch_skinny_mt<2>(p, a, st);
+            else launch_skinny_mt<4>(p, a, st);
+            return hipGetLastError();
+        }
+    }
+    if (a.W == nullptr) return hipErrorInvalidValue;       // only the packed copy exists but the shape needs the generic path
     int splits = 1;
     if (skinny) {
         int blocks = cdiv(a.N, 64) * cdiv(a.M, 64);

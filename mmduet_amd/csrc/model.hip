@@ -27,8 +27,10 @@ struct Prof {
     double ms[MMD_K_COUNT] = {0}; int64_t n[MMD_K_COUNT] = {0}; double bytes[MMD_K_COUNT] = {0}; double flops[MMD_K_COUNT] = {0};
 };
 
-struct LlmLayer { void *ln1 = 0, *ln2 = 0, *wqkv = 0, *bqkv = 0, *wo = 0, *wgu = 0, *wdown = 0; };
-struct VitLayer { void *ln1w = 0, *ln1b = 0, *wqkv = 0, *bqkv = 0, *wo = 0, *bo = 0, *ln2w = 0, *ln2b = 0, *w1 = 0, *b1 = 0, *w2 = 0, *b2 = 0; };
+struct LlmLayer { void *ln1 = 0, *ln2 = 0, *wqkv = 0, *bqkv = 0, *wo = 0, *wgu = 0, *wdown = 0;
+                  void *wqkv_p = 0, *wo_p = 0, *wgu_p = 0, *wdown_p = 0; };   // *_p: MFMA-fragment-major copies (skinny GEMM)
+struct VitLayer { void *ln1w = 0, *ln1b = 0, *wqkv = 0, *bqkv = 0, *wo = 0, *bo = 0, *ln2w = 0, *ln2b = 0, *w1 = 0, *b1 = 0, *w2 = 0, *b2 = 0;
+                  void *wqkv_p = 0, *wo_p = 0, *w1_p = 0, *w2_p = 0; };
 
 struct mmd_ctx {
     mmd_config cfg;
@@ -42,8 +44,9 @@ struct mmd_ctx {
     // fused weights
     std::vector<LlmLayer> L;
     std::vector<VitLayer> VL;
-    void *embed = 0, *fnorm = 0, *lm_head = 0, *heads4 = 0;
+    void *embed = 0, *fnorm = 0, *lm_head = 0, *heads4 = 0, *lm_head_p = 0;
     void *patch_w = 0, *patch_b = 0, *pos_emb = 0, *post_w = 0, *post_b = 0, *p0w = 0, *p0b = 0, *p2w = 0, *p2b = 0;
+    void *patch_w_p = 0, *p0w_p = 0, *p2w_p = 0;
     int vit_kpad = 0, vit_ipad = 0, vit_tokens = 0, vit_grid = 0, qkv_w = 0;
     float* inv_freq = nullptr; bool inv_freq_user = false;
     // workspaces
@@ -121,12 +124,12 @@ static void prof_drain(mmd_ctx* c) {
 
 // ---- GEMM wrapper --------------------------------------------------------------------------------------------------
 static int gemm(mmd_ctx* c, const void* X, int64_t ldx, const void* W, int64_t ldw, const void* bias, const void* R, int64_t ldr, void* Y,
-                int64_t ldy, int M, int N, int K, int epi, int out_f32 = 0, int variant = GEMM_AUTO) {
+                int64_t ldy, int M, int N, int K, int epi, int out_f32 = 0, int variant = GEMM_AUTO, const void* Wp = nullptr) {
     GemmArgs a;
-    a.X = X; a.ldx = ldx; a.W = W; a.ldw = ldw; a.bias = bias; a.R = R; a.ldr = ldr; a.Y = Y; a.ldy = ldy;
+    a.X = X; a.ldx = ldx; a.W = W; a.ldw = ldw; a.Wp = Wp; a.bias = bias; a.R = R; a.ldr = ldr; a.Y = Y; a.ldy = ldy;
     a.M = M; a.N = N; a.K = K; a.epi = epi; a.out_f32 = out_f32; a.variant = variant;
     a.splitk_ws = c->splitk_ws; a.splitk_ws_bytes = c->splitk_bytes;
-    int kind = (variant == GEMM_SKINNY || (variant == GEMM_AUTO && M <= 64)) ? MMD_K_GEMM_SKINNY : MMD_K_GEMM_TILE;
+    int kind = (variant == GEMM_SKINNY || (variant != GEMM_BIG && variant != GEMM_LARGE && variant != GEMM_GENERIC && M <= 64)) ? MMD_K_GEMM_SKINNY : MMD_K_GEMM_TILE;
     double e = (double)es(c);
     double bytes = ((double)M * K + (double)N * K) * e + (double)M * (epi == EPI_SWIGLU ? N / 2 : N) * (out_f32 ? 4.0 : e);
     ProfScope ps(c, kind, bytes, 2.0 * M * N * K);
@@ -150,7 +153,7 @@ extern "C" int mmd_create(const mmd_config* cfg, int device, mmd_ctx** out) {
     c->stream = c->own_stream;
     c->vit_grid = cfg->vit_image / cfg->vit_patch;
     c->vit_tokens = c->vit_grid * c->vit_grid;
-    c->vit_kpad = (int)round_up(3 * cfg->vit_patch * cfg->vit_patch, 32);
+    c->vit_kpad = (int)round_up(3 * cfg->vit_patch * cfg->vit_patch, 64);
     c->vit_ipad = (int)round_up(cfg->vit_intermediate, 64);
     c->qkv_w = (cfg->num_heads + 2 * cfg->num_kv_heads) * cfg->head_dim;
     *out = c;
@@ -261,6 +264,15 @@ static int take(mmd_ctx* c, const std::string& name, std::vector<int64_t> shape,
 
 static int alloc_workspaces(mmd_ctx* c);
 
+// MFMA-fragment-major copy of a bf16 weight matrix for the weight-streaming skinny GEMM (null if the shape does not tile)
+static int make_packed(mmd_ctx* c, const void* W, int N, int K, void** out) {
+    *out = nullptr;
+    if (c->cfg.dtype != MMD_BF16 || (N % 16) != 0 || (K % 32) != 0) return MMD_OK;
+    int rc = dev_alloc(c, out, (size_t)N * K * 2, false); if (rc) return rc;
+    HIPCHK(c, launch_pack_w(W, K, N, K, *out, c->stream));
+    return MMD_OK;
+}
+
 extern "C" int mmd_finalize_weights(mmd_ctx* c) {
     if (!c) return MMD_EINVAL;
     if (c->finalized) return MMD_OK;
@@ -271,7 +283,7 @@ extern "C" int mmd_finalize_weights(mmd_ctx* c) {
     hipStream_t st = c->stream;
     { TAKE(t, "model.embed_tokens.weight", {V, H}); c->embed = t.p; }
     { TAKE(t, "model.norm.weight", {H}); c->fnorm = t.p; }
-    { TAKE(t, "lm_head.weight", {V, H}); c->lm_head = t.p; }
+    { TAKE(t, "lm_head.weight", {V, H}); c->lm_head = t.p; int rc = make_packed(c, c->lm_head, V, H, &c->lm_head_p); if (rc) return rc; }
     {
         TAKE(a, "informative_head.weight", {2, H}); TAKE(b, "relevance_head.weight", {2, H});
         int rc = dev_alloc(c, &c->heads4, 4 * H * e); if (rc) return rc;
@@ -303,6 +315,10 @@ extern "C" int mmd_finalize_weights(mmd_ctx* c) {
         HIPCHK(c, launch_interleave16(dt, wg.p, wu.p, L.wgu, I, H, st));
         if (Ipad != I) FAIL(c, MMD_EINVAL, "intermediate_size must be a multiple of 16 (got %d)", I);
         { TAKE(t, p + "mlp.down_proj.weight", {H, I}); L.wdown = t.p; }
+        rc = make_packed(c, L.wqkv, c->qkv_w, H, &L.wqkv_p); if (rc) return rc;
+        rc = make_packed(c, L.wo, H, nh * d, &L.wo_p); if (rc) return rc;
+        rc = make_packed(c, L.wgu, 2 * I, H, &L.wgu_p); if (rc) return rc;
+        rc = make_packed(c, L.wdown, H, I, &L.wdown_p); if (rc) return rc;
         HIPCHK(c, hipStreamSynchronize(st));
         dev_free(c, wq.p); dev_free(c, wk.p); dev_free(c, wv.p); dev_free(c, bq.p); dev_free(c, bk.p); dev_free(c, bv.p); dev_free(c, wg.p); dev_free(c, wu.p);
     }
@@ -312,6 +328,7 @@ extern "C" int mmd_finalize_weights(mmd_ctx* c) {
         TAKE(w, "vit.embeddings.patch_embedding.weight", {C, 3, P, P});
         int rc = dev_alloc(c, &c->patch_w, (size_t)C * c->vit_kpad * e, false); if (rc) return rc;
         HIPCHK(c, launch_pad_cols(dt, w.p, C, KP, c->patch_w, c->vit_kpad, st));
+        rc = make_packed(c, c->patch_w, C, c->vit_kpad, &c->patch_w_p); if (rc) return rc;
         HIPCHK(c, hipStreamSynchronize(st)); dev_free(c, w.p);
     }
     { TAKE(t, "vit.embeddings.patch_embedding.bias", {C}); c->patch_b = t.p; }
@@ -341,6 +358,10 @@ extern "C" int mmd_finalize_weights(mmd_ctx* c) {
         HIPCHK(c, hipMemcpyAsync(L.w1, w1.p, (size_t)CI * C * e, hipMemcpyDeviceToDevice, st));
         HIPCHK(c, hipMemcpyAsync(L.b1, b1.p, (size_t)CI * e, hipMemcpyDeviceToDevice, st));
         HIPCHK(c, launch_pad_cols(dt, w2.p, C, CI, L.w2, c->vit_ipad, st));
+        rc = make_packed(c, L.wqkv, 3 * C, C, &L.wqkv_p); if (rc) return rc;
+        rc = make_packed(c, L.wo, C, C, &L.wo_p); if (rc) return rc;
+        rc = make_packed(c, L.w1, c->vit_ipad, C, &L.w1_p); if (rc) return rc;
+        rc = make_packed(c, L.w2, C, c->vit_ipad, &L.w2_p); if (rc) return rc;
         HIPCHK(c, hipStreamSynchronize(st));
         dev_free(c, wq.p); dev_free(c, wk.p); dev_free(c, wv.p); dev_free(c, bq.p); dev_free(c, bk.p); dev_free(c, bv.p);
         dev_free(c, w1.p); dev_free(c, b1.p); dev_free(c, w2.p);
@@ -350,6 +371,7 @@ extern "C" int mmd_finalize_weights(mmd_ctx* c) {
     }
     { TAKE(t, "model.mm_projector.0.weight", {H, C}); c->p0w = t.p; } { TAKE(t, "model.mm_projector.0.bias", {H}); c->p0b = t.p; }
     { TAKE(t, "model.mm_projector.2.weight", {H, H}); c->p2w = t.p; } { TAKE(t, "model.mm_projector.2.bias", {H}); c->p2b = t.p; }
+    { int rc = make_packed(c, c->p0w, H, C, &c->p0w_p); if (rc) return rc; rc = make_packed(c, c->p2w, H, H, &c->p2w_p); if (rc) return rc; }
     // tensors that are on the checkpoint but not on the path (post_layernorm when unused, pooling head, ...) are dropped
     for (auto& kv : c->raw) dev_free(c, kv.second.p);
     c->raw.clear();
@@ -408,12 +430,12 @@ extern "C" int mmd_vit_encode(mmd_ctx* c, const void* px, int B, void* out) {
     if (B > g.max_vit_batch) FAIL(c, MMD_ERANGE, "vit batch %d exceeds max_vit_batch %d", B, g.max_vit_batch);
     const int C = g.vit_hidden, H = g.hidden_size, T = c->vit_tokens, M = B * T, hd = C / g.vit_heads;
     { ProfScope ps(c, MMD_K_OTHER, 0, 0); HIPCHK(c, launch_im2col(dt, px, B, g.vit_image, g.vit_patch, c->vit_grid, c->vit_kpad, c->v_col, st)); }
-    int rc = gemm(c, c->v_col, c->vit_kpad, c->patch_w, c->vit_kpad, c->patch_b, nullptr, 0, c->v_h, C, M, C, c->vit_kpad, EPI_NONE); if (rc) return rc;
+    int rc = gemm(c, c->v_col, c->vit_kpad, c->patch_w, c->vit_kpad, c->patch_b, nullptr, 0, c->v_h, C, M, C, c->vit_kpad, EPI_NONE, 0, GEMM_AUTO, c->patch_w_p); if (rc) return rc;
     { ProfScope ps(c, MMD_K_OTHER, 0, 0); HIPCHK(c, launch_add_rows(dt, c->v_h, c->pos_emb, M, C, T, st)); }
     for (int i = 0; i < g.vit_layers; ++i) {
         VitLayer& L = c->VL[i];
         { ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * M * C * es(c), 0); HIPCHK(c, launch_layernorm(dt, c->v_h, L.ln1w, L.ln1b, c->v_xn, M, C, g.vit_ln_eps, st)); }
-        rc = gemm(c, c->v_xn, C, L.wqkv, C, L.bqkv, nullptr, 0, c->v_qkv, 3 * C, M, 3 * C, C, EPI_NONE); if (rc) return rc;
+        rc = gemm(c, c->v_xn, C, L.wqkv, C, L.bqkv, nullptr, 0, c->v_qkv, 3 * C, M, 3 * C, C, EPI_NONE, 0, GEMM_AUTO, L.wqkv_p); if (rc) return rc;
         {
             AttnArgs a; memset(&a, 0, sizeof(a));
             a.q = c->v_qkv; a.ldq = 3 * C; a.K = (char*)c->v_qkv + (size_t)C * es(c); a.V = (char*)c->v_qkv + (size_t)2 * C * es(c);
@@ -424,14 +446,14 @@ extern "C" int mmd_vit_encode(mmd_ctx* c, const void* px, int B, void* out) {
             ProfScope ps(c, MMD_K_ATTN_VIT, 4.0 * M * C * es(c), 4.0 * B * (double)T * T * C);
             HIPCHK(c, launch_attention(dt, a, st));
         }
-        rc = gemm(c, c->v_attn, C, L.wo, C, L.bo, c->v_h, C, c->v_h, C, M, C, C, EPI_RESID); if (rc) return rc;
+        rc = gemm(c, c->v_attn, C, L.wo, C, L.bo, c->v_h, C, c->v_h, C, M, C, C, EPI_RESID, 0, GEMM_AUTO, L.wo_p); if (rc) return rc;
         { ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * M * C * es(c), 0); HIPCHK(c, launch_layernorm(dt, c->v_h, L.ln2w, L.ln2b, c->v_xn, M, C, g.vit_ln_eps, st)); }
-        rc = gemm(c, c->v_xn, C, L.w1, C, L.b1, nullptr, 0, c->v_mlp, c->vit_ipad, M, c->vit_ipad, C, EPI_GELU_TANH); if (rc) return rc;
-        rc = gemm(c, c->v_mlp, c->vit_ipad, L.w2, c->vit_ipad, L.b2, c->v_h, C, c->v_h, C, M, C, c->vit_ipad, EPI_RESID); if (rc) return rc;
+        rc = gemm(c, c->v_xn, C, L.w1, C, L.b1, nullptr, 0, c->v_mlp, c->vit_ipad, M, c->vit_ipad, C, EPI_GELU_TANH, 0, GEMM_AUTO, L.w1_p); if (rc) return rc;
+        rc = gemm(c, c->v_mlp, c->vit_ipad, L.w2, c->vit_ipad, L.b2, c->v_h, C, c->v_h, C, M, C, c->vit_ipad, EPI_RESID, 0, GEMM_AUTO, L.w2_p); if (rc) return rc;
     }
     if (g.vit_post_layernorm) { HIPCHK(c, launch_layernorm(dt, c->v_h, c->post_w, c->post_b, c->v_h, M, C, g.vit_ln_eps, st)); }
-    rc = gemm(c, c->v_h, C, c->p0w, C, c->p0b, nullptr, 0, c->v_p1, H, M, H, C, EPI_GELU_ERF); if (rc) return rc;
-    rc = gemm(c, c->v_p1, H, c->p2w, H, c->p2b, nullptr, 0, c->v_p2, H, M, H, H, EPI_NONE); if (rc) return rc;
+    rc = gemm(c, c->v_h, C, c->p0w, C, c->p0b, nullptr, 0, c->v_p1, H, M, H, C, EPI_GELU_ERF, 0, GEMM_AUTO, c->p0w_p); if (rc) return rc;
+    rc = gemm(c, c->v_p1, H, c->p2w, H, c->p2b, nullptr, 0, c->v_p2, H, M, H, H, EPI_NONE, 0, GEMM_AUTO, c->p2w_p); if (rc) return rc;
     { ProfScope ps(c, MMD_K_OTHER, 0, 0); HIPCHK(c, launch_pool(dt, c->v_p2, out, B, c->vit_grid, H, g.pool_mode, g.pool_stride, st)); }
     c->last_vit_B = B;
     return MMD_OK;
@@ -520,6 +542,8 @@ extern "C" int mmd_stream_create(mmd_ctx* c, int64_t initial_tokens, mmd_stream*
     size_t bytes = kv_layer_elems(c, s->cap) * c->cfg.num_layers * es(c);
     hipError_t e1 = hipMalloc(&s->K, bytes), e2 = hipMalloc(&s->V, bytes);
     if (e1 != hipSuccess || e2 != hipSuccess) { if (s->K) hipFree(s->K); if (s->V) hipFree(s->V); delete s; FAIL(c, MMD_ENOMEM, "KV arena of %lld tokens (%zu bytes x2) does not fit", (long long)initial_tokens, bytes); }
+    // key tiles may cover slots beyond the live length (their P is masked to 0): keep those slots finite
+    hipMemsetAsync(s->K, 0, bytes, c->stream); hipMemsetAsync(s->V, 0, bytes, c->stream);
     *out = s;
     return MMD_OK;
 }
@@ -546,8 +570,9 @@ static int kv_reserve(mmd_ctx* c, mmd_stream* s, int64_t need) {
     size_t bytes = kv_layer_elems(c, ncap) * c->cfg.num_layers * e;
     void *nK = nullptr, *nV = nullptr;
     if (hipMalloc(&nK, bytes) != hipSuccess || hipMalloc(&nV, bytes) != hipSuccess) { if (nK) hipFree(nK); FAIL(c, MMD_ENOMEM, "cannot grow KV arena to %lld tokens", (long long)ncap); }
+    hipMemsetAsync(nK, 0, bytes, c->stream); hipMemsetAsync(nV, 0, bytes, c->stream);
     size_t rows = (size_t)c->cfg.num_layers * c->cfg.num_kv_heads;
-    size_t w = (size_t)s->len * c->cfg.head_dim * e;
+    size_t w = (size_t)round_up(s->len, 64) * c->cfg.head_dim * e;        // V is stored in whole 64-token blocks
     if (w) {
         HIPCHK(c, hipMemcpy2DAsync(nK, (size_t)ncap * c->cfg.head_dim * e, s->K, (size_t)s->cap * c->cfg.head_dim * e, w, rows, hipMemcpyDeviceToDevice, c->stream));
         HIPCHK(c, hipMemcpy2DAsync(nV, (size_t)ncap * c->cfg.head_dim * e, s->V, (size_t)s->cap * c->cfg.head_dim * e, w, rows, hipMemcpyDeviceToDevice, c->stream));
@@ -574,22 +599,22 @@ extern "C" int mmd_llm_step(mmd_ctx* c, mmd_stream* s, const void* embeds, int S
         void* Kl = (char*)s->K + (size_t)i * layer_elems * e;
         void* Vl = (char*)s->V + (size_t)i * layer_elems * e;
         { ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * S * H * e, 0); HIPCHK(c, launch_rmsnorm(dt, c->l_h, L.ln1, c->l_xn, S, H, g.rms_norm_eps, st)); }
-        rc = gemm(c, c->l_xn, H, L.wqkv, H, L.bqkv, nullptr, 0, c->l_qkv, c->qkv_w, S, c->qkv_w, H, EPI_NONE); if (rc) return rc;
+        rc = gemm(c, c->l_xn, H, L.wqkv, H, L.bqkv, nullptr, 0, c->l_qkv, c->qkv_w, S, c->qkv_w, H, EPI_NONE, 0, GEMM_AUTO, L.wqkv_p); if (rc) return rc;
         { ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * S * c->qkv_w * e, 0);
-          HIPCHK(c, launch_rope_append(dt, c->l_qkv, S, nh, nkv, d, c->inv_freq, n, c->l_q, Kl, Vl, s->cap, st)); }
+          HIPCHK(c, launch_rope_append(dt, c->l_qkv, S, nh, nkv, d, c->inv_freq, n, c->l_q, Kl, Vl, s->cap, 1, st)); }
         {
             AttnArgs a; memset(&a, 0, sizeof(a));
             a.q = c->l_q; a.ldq = (int64_t)nh * d; a.K = Kl; a.V = Vl; a.k_hs = s->cap * d; a.k_ts = d; a.v_hs = s->cap * d; a.v_ts = d;
-            a.out = c->l_attn; a.ldo = (int64_t)nh * d; a.S = S; a.nh = nh; a.nkv = nkv; a.d = d; a.n_ctx = n; a.causal = 1;
+            a.out = c->l_attn; a.ldo = (int64_t)nh * d; a.S = S; a.nh = nh; a.nkv = nkv; a.d = d; a.n_ctx = n; a.causal = 1; a.v_transposed = 1;
             a.batch = 1; a.ws = c->attn_ws; a.ws_bytes = c->attn_bytes; a.variant = 0;
             double kvb = 2.0 * (double)(n + S) * nkv * d * e;
             ProfScope ps(c, MMD_K_ATTN_LLM, kvb + 2.0 * S * nh * d * e, 4.0 * S * (double)(n + S) * nh * d);
             HIPCHK(c, launch_attention(dt, a, st));
         }
-        rc = gemm(c, c->l_attn, (int64_t)nh * d, L.wo, (int64_t)nh * d, nullptr, c->l_h, H, c->l_h, H, S, H, nh * d, EPI_RESID); if (rc) return rc;
+        rc = gemm(c, c->l_attn, (int64_t)nh * d, L.wo, (int64_t)nh * d, nullptr, c->l_h, H, c->l_h, H, S, H, nh * d, EPI_RESID, 0, GEMM_AUTO, L.wo_p); if (rc) return rc;
         { ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * S * H * e, 0); HIPCHK(c, launch_rmsnorm(dt, c->l_h, L.ln2, c->l_xn, S, H, g.rms_norm_eps, st)); }
-        rc = gemm(c, c->l_xn, H, L.wgu, H, nullptr, nullptr, 0, c->l_act, I, S, 2 * I, H, EPI_SWIGLU); if (rc) return rc;
-        rc = gemm(c, c->l_act, I, L.wdown, I, nullptr, c->l_h, H, c->l_h, H, S, H, I, EPI_RESID); if (rc) return rc;
+        rc = gemm(c, c->l_xn, H, L.wgu, H, nullptr, nullptr, 0, c->l_act, I, S, 2 * I, H, EPI_SWIGLU, 0, GEMM_AUTO, L.wgu_p); if (rc) return rc;
+        rc = gemm(c, c->l_act, I, L.wdown, I, nullptr, c->l_h, H, c->l_h, H, S, H, I, EPI_RESID, 0, GEMM_AUTO, L.wdown_p); if (rc) return rc;
     }
     { ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * S * H * e, 0); HIPCHK(c, launch_rmsnorm(dt, c->l_h, c->fnorm, c->l_hid, S, H, g.rms_norm_eps, st)); }
     if (hidden_out) HIPCHK(c, hipMemcpyAsync(hidden_out, c->l_hid, (size_t)S * H * e, hipMemcpyDeviceToDevice, st));
@@ -607,7 +632,7 @@ extern "C" int mmd_video_heads(mmd_ctx* c, const void* hidden, int M, float* out
 extern "C" int mmd_lm_head(mmd_ctx* c, const void* hidden, int M, float* logits) {
     NEED_FINAL(c);
     const int H = c->cfg.hidden_size, V = c->cfg.vocab_size;
-    return gemm(c, hidden, H, c->lm_head, H, nullptr, nullptr, 0, logits, V, M, V, H, EPI_NONE, 1);
+    return gemm(c, hidden, H, c->lm_head, H, nullptr, nullptr, 0, logits, V, M, V, H, EPI_NONE, 1, GEMM_AUTO, c->lm_head_p);
 }
 
 extern "C" int mmd_frame_step(mmd_ctx* c, mmd_stream* s, const void* embeds, int S, const int32_t* rows_host, int n_rows, float* out_host) {
@@ -640,7 +665,7 @@ extern "C" int mmd_greedy_generate(mmd_ctx* c, mmd_stream* s, const void* prompt
     for (int i = 0; i < max_new; ++i) {
         int rc = mmd_llm_step(c, s, x, xs, nullptr); if (rc) return rc;
         const void* last = (const char*)c->l_hid + (size_t)(xs - 1) * H * e;
-        rc = gemm(c, last, H, c->lm_head, H, nullptr, nullptr, 0, c->logits_ws, g.vocab_size, 1, g.vocab_size, H, EPI_NONE, 1); if (rc) return rc;
+        rc = gemm(c, last, H, c->lm_head, H, nullptr, nullptr, 0, c->logits_ws, g.vocab_size, 1, g.vocab_size, H, EPI_NONE, 1, GEMM_AUTO, c->lm_head_p); if (rc) return rc;
         { ProfScope ps(c, MMD_K_OTHER, 0, 0);
           HIPCHK(c, launch_argmax_penalty(c->logits_ws, g.vocab_size, c->prev_dev, pen ? np : 0, pen ? rep_penalty : 1.f, c->tok_dev, st)); }
         HIPCHK(c, hipMemcpyAsync(c->tok_host, c->tok_dev, sizeof(int64_t), hipMemcpyDeviceToHost, st));
@@ -685,7 +710,40 @@ extern "C" int mmd_op_gemm(mmd_ctx* c, const void* X, const void* W, const void*
     hipSetDevice(c->device);
     if (!c->splitk_ws) { c->splitk_bytes = (size_t)64 << 20; int rc = dev_alloc(c, (void**)&c->splitk_ws, c->splitk_bytes); if (rc) return rc; }
     int NO = epi == EPI_SWIGLU ? N / 2 : N;
-    return gemm(c, X, K, W, K, bias, R, NO, Y, NO, M, N, K, epi, out_f32, variant);
+    void* Wp = nullptr;
+    if (variant == GEMM_SKINNY || variant == GEMM_BIG) { int rc = make_packed(c, W, N, K, &Wp); if (rc) return rc; }
+    int rc = gemm(c, X, K, W, K, bias, R, NO, Y, NO, M, N, K, epi, out_f32, variant, Wp);
+    if (Wp) { hipStreamSynchronize(c->stream); dev_free(c, Wp); }
+    return rc;
+}
+// times one GEMM shape on the context's stream with HIP events (weights packed once, outside the timed region)
+extern "C" int mmd_op_gemm_bench(mmd_ctx* c, int M, int N, int K, int epi, int variant, int iters, float* avg_ms_out) {
+    if (!c || !avg_ms_out || iters <= 0) return MMD_EINVAL;
+    hipSetDevice(c->device);
+    if (!c->splitk_ws) { c->splitk_bytes = (size_t)64 << 20; int rc = dev_alloc(c, (void**)&c->splitk_ws, c->splitk_bytes); if (rc) return rc; }
+    const size_t e = es(c);
+    int NO = epi == EPI_SWIGLU ? N / 2 : N;
+    void *X = nullptr, *W = nullptr, *Y = nullptr, *R = nullptr, *Wp = nullptr;
+    int rc;
+    if ((rc = dev_alloc(c, &X, (size_t)M * K * e)) || (rc = dev_alloc(c, &W, (size_t)N * K * e)) || (rc = dev_alloc(c, &Y, (size_t)M * NO * e)) ||
+        (rc = dev_alloc(c, &R, (size_t)M * NO * e))) return rc;
+    // non-trivial operand bits (zero operands inflate clocks, MI355X guide rule 25): fill with a byte pattern
+    HIPCHK(c, hipMemsetAsync(X, 0x3c, (size_t)M * K * e, c->stream));
+    HIPCHK(c, hipMemsetAsync(W, 0x3b, (size_t)N * K * e, c->stream));
+    if (variant != GEMM_GENERIC && variant != GEMM_LARGE) { rc = make_packed(c, W, N, K, &Wp); if (rc) return rc; }
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    bool was = c->prof.on; c->prof.on = false;
+    for (int i = 0; i < 3; ++i) { rc = gemm(c, X, K, W, K, nullptr, epi == EPI_RESID ? R : nullptr, NO, Y, NO, M, N, K, epi, 0, variant, Wp); if (rc) return rc; }
+    hipEventRecord(a, c->stream);
+    for (int i = 0; i < iters; ++i) gemm(c, X, K, W, K, nullptr, epi == EPI_RESID ? R : nullptr, NO, Y, NO, M, N, K, epi, 0, variant, Wp);
+    hipEventRecord(b, c->stream);
+    hipEventSynchronize(b);
+    float ms = 0; hipEventElapsedTime(&ms, a, b);
+    *avg_ms_out = ms / iters;
+    c->prof.on = was;
+    hipEventDestroy(a); hipEventDestroy(b);
+    dev_free(c, X); dev_free(c, W); dev_free(c, Y); dev_free(c, R); if (Wp) dev_free(c, Wp);
+    return MMD_OK;
 }
 extern "C" int mmd_op_rmsnorm(mmd_ctx* c, const void* x, const void* w, void* y, int M, int H, float eps) {
     if (!c) return MMD_EINVAL; hipSetDevice(c->device);
@@ -702,7 +760,7 @@ extern "C" int mmd_op_rope_append(mmd_ctx* c, void* qkv, int S, int nh, int nkv,
     float* dev = nullptr;
     HIPCHK(c, hipMalloc((void**)&dev, sizeof(float) * (d / 2)));
     HIPCHK(c, hipMemcpyAsync(dev, t.data(), sizeof(float) * (d / 2), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, launch_rope_append(c->cfg.dtype, qkv, S, nh, nkv, d, dev, pos0, q_out, Kc, Vc, cap, c->stream));
+    HIPCHK(c, launch_rope_append(c->cfg.dtype, qkv, S, nh, nkv, d, dev, pos0, q_out, Kc, Vc, cap, 0, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     hipFree(dev);
     return MMD_OK;
@@ -714,7 +772,45 @@ extern "C" int mmd_op_attention(mmd_ctx* c, const void* q, const void* Kc, const
     AttnArgs a; memset(&a, 0, sizeof(a));
     a.q = q; a.ldq = (int64_t)nh * d; a.K = Kc; a.V = Vc; a.k_hs = cap * d; a.k_ts = d; a.v_hs = cap * d; a.v_ts = d; a.out = out; a.ldo = (int64_t)nh * d;
     a.S = S; a.nh = nh; a.nkv = nkv; a.d = d; a.n_ctx = n_ctx; a.causal = causal; a.batch = 1; a.ws = c->attn_ws; a.ws_bytes = c->attn_bytes; a.variant = variant;
-    HIPCHK(c, launch_attention(c->cfg.dtype, a, c->stream));
+    void* vt = nullptr;
+    if (variant == 3) {        // the GQA-128 kernel reads the transposed V arena layout: convert the row-major test input
+        if (cap % 64 != 0) FAIL(c, MMD_EINVAL, "variant 3 needs cap %% 64 == 0");
+        int rc = dev_alloc(c, &vt, (size_t)nkv * cap * d * es(c)); if (rc) return rc;
+        HIPCHK(c, launch_transpose_v(c->cfg.dtype, Vc, vt, nkv, cap, d, c->stream));
+        a.V = vt; a.v_transposed = 1;
+    }
+    hipError_t le = launch_attention(c->cfg.dtype, a, c->stream);
+    if (vt) { hipStreamSynchronize(c->stream); dev_free(c, vt); }
+    HIPCHK(c, le);
+    return MMD_OK;
+}
+// times the LLM attention (incl. the split-KV combine) at a given step size / context length with HIP events
+extern "C" int mmd_op_attention_bench(mmd_ctx* c, int S, int nh, int nkv, int d, int64_t n_ctx, int variant, int iters, float* avg_ms_out) {
+    if (!c || !avg_ms_out || iters <= 0) return MMD_EINVAL;
+    hipSetDevice(c->device);
+    if (!c->attn_ws) { c->attn_bytes = (size_t)128 << 20; int rc = dev_alloc(c, (void**)&c->attn_ws, c->attn_bytes); if (rc) return rc; }
+    const size_t e = es(c);
+    int64_t cap = round_up(n_ctx + S, 64);
+    void *q = nullptr, *K = nullptr, *V = nullptr, *o = nullptr; int rc;
+    if ((rc = dev_alloc(c, &q, (size_t)S * nh * d * e)) || (rc = dev_alloc(c, &K, (size_t)nkv * cap * d * e)) || (rc = dev_alloc(c, &V, (size_t)nkv * cap * d * e)) ||
+        (rc = dev_alloc(c, &o, (size_t)S * nh * d * e))) return rc;
+    HIPCHK(c, hipMemsetAsync(q, 0x3c, (size_t)S * nh * d * e, c->stream));
+    HIPCHK(c, hipMemsetAsync(K, 0x3b, (size_t)nkv * cap * d * e, c->stream));
+    HIPCHK(c, hipMemsetAsync(V, 0x3c, (size_t)nkv * cap * d * e, c->stream));
+    AttnArgs a; memset(&a, 0, sizeof(a));
+    a.q = q; a.ldq = (int64_t)nh * d; a.K = K; a.V = V; a.k_hs = cap * d; a.k_ts = d; a.v_hs = cap * d; a.v_ts = d; a.out = o; a.ldo = (int64_t)nh * d;
+    a.S = S; a.nh = nh; a.nkv = nkv; a.d = d; a.n_ctx = n_ctx; a.causal = 1; a.batch = 1; a.ws = c->attn_ws; a.ws_bytes = c->attn_bytes; a.variant = variant;
+    a.v_transposed = 1;
+    hipEvent_t ea, eb; hipEventCreate(&ea); hipEventCreate(&eb);
+    for (int i = 0; i < 3; ++i) HIPCHK(c, launch_attention(c->cfg.dtype, a, c->stream));
+    hipEventRecord(ea, c->stream);
+    for (int i = 0; i < iters; ++i) launch_attention(c->cfg.dtype, a, c->stream);
+    hipEventRecord(eb, c->stream);
+    hipEventSynchronize(eb);
+    float ms = 0; hipEventElapsedTime(&ms, ea, eb);
+    *avg_ms_out = ms / iters;
+    hipEventDestroy(ea); hipEventDestroy(eb);
+    dev_free(c, q); dev_free(c, K); dev_free(c, V); dev_free(c, o);
     return MMD_OK;
 }
 extern "C" int mmd_op_pool(mmd_ctx* c, const void* x, void* y, int B, int grid, int H, int mode, int stride) {

@@ -101,7 +101,7 @@ hipError_t launch_add_rows(int dtype, void* x, const void* add, int M, int H, in
 // ---------------------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void rope_append_kernel(const T* __restrict__ qkv, int S, int nh, int nkv, int d, const float* __restrict__ inv_freq_tab, long long pos0,
-                                   T* __restrict__ q_out, T* __restrict__ Kc, T* __restrict__ Vc, long long cap) {
+                                   T* __restrict__ q_out, T* __restrict__ Kc, T* __restrict__ Vc, long long cap, int v_tr) {
     int s = blockIdx.x;
     int head = blockIdx.y;                 // 0..nh-1 q heads, nh..nh+nkv-1 k heads, then v heads
     int half = d >> 1;
@@ -110,8 +110,13 @@ __global__ void rope_append_kernel(const T* __restrict__ qkv, int S, int nh, int
     long long pos = pos0 + s;
     if (head >= nh + nkv) {               // V: plain copy into the arena
         int kvh = head - nh - nkv;
-        T* dst = Vc + ((long long)kvh * cap + pos) * d;
-        for (int i = threadIdx.x; i < d; i += blockDim.x) dst[i] = src[i];
+        if (v_tr) {     // transposed 64-token blocks: (tok, e) at ((tok>>6)*d + e)*64 + (tok&63)
+            T* dst = Vc + (long long)kvh * cap * d + ((pos >> 6) * d << 6) + (pos & 63);
+            for (int i = threadIdx.x; i < d; i += blockDim.x) dst[(long long)i << 6] = src[i];
+        } else {
+            T* dst = Vc + ((long long)kvh * cap + pos) * d;
+            for (int i = threadIdx.x; i < d; i += blockDim.x) dst[i] = src[i];
+        }
         return;
     }
     T* dst = head < nh ? q_out + (long long)s * nh * d + (long long)head * d : Kc + ((long long)(head - nh) * cap + pos) * d;
@@ -128,11 +133,27 @@ __global__ void rope_append_kernel(const T* __restrict__ qkv, int S, int nh, int
 }
 
 hipError_t launch_rope_append(int dtype, const void* qkv, int S, int nh, int nkv, int d, const float* l2, int64_t pos0, void* q_out,
-                              void* Kc, void* Vc, int64_t cap, hipStream_t st) {
+                              void* Kc, void* Vc, int64_t cap, int v_tr, hipStream_t st) {
     if (S <= 0) return hipSuccess;
     dim3 grid(S, nh + 2 * nkv), block(64);
-    if (dtype == MMD_F32) hipLaunchKernelGGL(rope_append_kernel<float>, grid, block, 0, st, (const float*)qkv, S, nh, nkv, d, l2, (long long)pos0, (float*)q_out, (float*)Kc, (float*)Vc, (long long)cap);
-    else hipLaunchKernelGGL(rope_append_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)qkv, S, nh, nkv, d, l2, (long long)pos0, (bf16_t*)q_out, (bf16_t*)Kc, (bf16_t*)Vc, (long long)cap);
+    if (dtype == MMD_F32) hipLaunchKernelGGL(rope_append_kernel<float>, grid, block, 0, st, (const float*)qkv, S, nh, nkv, d, l2, (long long)pos0, (float*)q_out, (float*)Kc, (float*)Vc, (long long)cap, v_tr);
+    else hipLaunchKernelGGL(rope_append_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)qkv, S, nh, nkv, d, l2, (long long)pos0, (bf16_t*)q_out, (bf16_t*)Kc, (bf16_t*)Vc, (long long)cap, v_tr);
+    return hipGetLastError();
+}
+
+// V arena layout conversion (parity-test entry points): [nkv][cap][d] row-major -> transposed 64-token blocks
+template <typename T>
+__global__ void transpose_v_kernel(const T* __restrict__ src, T* __restrict__ dst, long long cap, int d, long long total) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int e = (int)(i % d); long long rest = i / d; long long tok = rest % cap; long long h = rest / cap;
+    dst[h * cap * d + ((tok >> 6) * d + e) * 64 + (tok & 63)] = src[i];
+}
+hipError_t launch_transpose_v(int dtype, const void* src, void* dst, int nkv, int64_t cap, int d, hipStream_t st) {
+    long long total = (long long)nkv * cap * d;
+    if (total <= 0) return hipSuccess;
+    if (dtype == MMD_F32) hipLaunchKernelGGL(transpose_v_kernel<float>, dim3(cdiv(total, 256)), dim3(256), 0, st, (const float*)src, (float*)dst, (long long)cap, d, total);
+    else hipLaunchKernelGGL(transpose_v_kernel<bf16_t>, dim3(cdiv(total, 256)), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, (long long)cap, d, total);
     return hipGetLastError();
 }
 

@@ -32,12 +32,18 @@ def assert_close(got, ref, dtype, scale=1.0, what=''):
     assert err <= tol * max(1.0, den), f'{what}: max abs err {err:.3e} (ref max {den:.3e}, tol {tol:.1e})'
 
 
-GEMM_SHAPES = [(49, 64, 64), (7, 130, 72), (200, 96, 588), (64, 256, 512), (300, 384, 256), (1, 512, 64), (129, 160, 4352)]
+GEMM_SHAPES = [(49, 64, 64), (7, 130, 72), (200, 96, 588), (64, 256, 512), (300, 384, 256), (1, 512, 64), (129, 160, 4352), (392, 512, 1152), (729, 256, 640)]
+
+
+def _variant_ok(ops, variant, M, N, K):
+    if variant == 4 and (ops.dtype != torch.bfloat16 or M <= 64 or N % 64 or K % 64):
+        pytest.skip('big-tile kernel: bf16, M > 64, N % 64 == 0, K % 64 == 0')
 
 
 @pytest.mark.parametrize('M,N,K', GEMM_SHAPES)
-@pytest.mark.parametrize('variant', [1, 2, 3])
+@pytest.mark.parametrize('variant', [1, 2, 3, 4])
 def test_gemm_bias(ops, M, N, K, variant):
+    _variant_ok(ops, variant, M, N, K)
     g = torch.Generator().manual_seed(M * 7 + N)
     X = torch.randn(M, K, generator=g); W = torch.randn(N, K, generator=g) / math.sqrt(K); b = torch.randn(N, generator=g)
     Y = ops.gemm(X, W, b, variant=variant)
@@ -46,10 +52,11 @@ def test_gemm_bias(ops, M, N, K, variant):
 
 
 @pytest.mark.parametrize('epi', ['gelu_tanh', 'gelu_erf', 'resid', 'swiglu'])
-@pytest.mark.parametrize('variant', [1, 2, 3])
+@pytest.mark.parametrize('variant', [1, 2, 3, 4])
 def test_gemm_epilogues(ops, epi, variant):
     g = torch.Generator().manual_seed(11)
-    M, N, K = 70, 192, 136
+    M, N, K = (70, 192, 136) if variant != 4 else (200, 256, 192)
+    _variant_ok(ops, variant, M, N, K)
     X = torch.randn(M, K, generator=g); W = torch.randn(N, K, generator=g) / math.sqrt(K); b = 0.1 * torch.randn(N, generator=g)
     R = torch.randn(M, N, generator=g)
     Xr, Wr, br, Rr = (rt(t, ops.dtype) for t in (X, W, b, R))
@@ -127,18 +134,21 @@ def ref_attention(q, K, V, nh, nkv, d, n_ctx, causal, dtype):
 
 ATTN_CASES = [  # S, nh, nkv, d, n_ctx, causal
     (1, 4, 2, 16, 0, True), (7, 4, 2, 16, 5, True), (49, 4, 1, 32, 300, True), (130, 4, 2, 16, 41, True),
-    (49, 28, 4, 128, 0, True), (49, 28, 4, 128, 3000, True), (1, 28, 4, 128, 2500, True), (200, 8, 8, 72, 0, False),
+    (49, 28, 4, 128, 0, True), (49, 28, 4, 128, 3000, True), (1, 28, 4, 128, 2500, True), (3, 28, 4, 128, 70, True), (98, 28, 4, 128, 777, True),
+    (49, 28, 4, 128, 15000, True), (20, 8, 8, 128, 100, False), (200, 8, 8, 72, 0, False),
     (16, 2, 2, 24, 0, False), (33, 4, 4, 64, 100, False),
 ]
 
 
 @pytest.mark.parametrize('S,nh,nkv,d,n_ctx,causal', ATTN_CASES)
-@pytest.mark.parametrize('variant', [1, 2])
+@pytest.mark.parametrize('variant', [1, 2, 3])
 def test_attention(ops, S, nh, nkv, d, n_ctx, causal, variant):
-    if variant == 2 and ops.dtype != torch.bfloat16:
-        pytest.skip('the MFMA attention kernel is bf16 only')
+    if variant >= 2 and ops.dtype != torch.bfloat16:
+        pytest.skip('the MFMA attention kernels are bf16 only')
+    if variant == 3 and d != 128:
+        pytest.skip('the GQA flash kernel is specialised for head_dim 128')
     g = torch.Generator().manual_seed(S * 13 + d)
-    cap = n_ctx + S + 37
+    cap = (n_ctx + S + 37 + 63) // 64 * 64
     q = torch.randn(S, nh * d, generator=g); K = torch.randn(nkv, cap, d, generator=g); V = torch.randn(nkv, cap, d, generator=g)
     K[:, n_ctx + S:] = 1e4; V[:, n_ctx + S:] = 1e4          # poison beyond the valid range: must never be read into the result
     Kc, Vc = K.to(ops.dev, ops.dtype), V.to(ops.dev, ops.dtype)
