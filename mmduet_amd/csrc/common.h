@@ -68,13 +68,21 @@ struct GemmArgs {
     int epi; int out_f32;
     int variant;
     float* splitk_ws; size_t splitk_ws_bytes;   // fp32 partial slabs
+    int* slabs_out = nullptr;                   // if set (packed skinny path only): leave [splits][M][N] fp32 slabs in splitk_ws, no
+                                                // epilogue, and return the split count here; a fused consumer kernel reduces them
 };
+bool gemm_can_slab(int dtype, const GemmArgs& a);
 
 // launchers (dtype = mmd_dtype).  All return hipError_t of the launch.
 hipError_t launch_gemm(int dtype, const GemmArgs& a, hipStream_t st, int* kind_out);
 hipError_t launch_pack_w(const void* W, int64_t ldw, int N, int K, void* out, hipStream_t st);   // bf16 only, N%16==0, K%32==0
 hipError_t launch_rmsnorm(int dtype, const void* x, const void* w, void* y, int M, int H, float eps, hipStream_t st);
 hipError_t launch_layernorm(int dtype, const void* x, const void* w, const void* b, void* y, int M, int H, float eps, hipStream_t st);
+// fused consumers of skinny-GEMM slabs (ops.hip)
+hipError_t launch_slab_resid_rmsnorm(const float* slabs, int splits, int M, int H, const void* resid_in, void* h_out, const void* norm_w, float eps,
+                                     void* xn_out, hipStream_t st);
+hipError_t launch_slab_rope_append(const float* slabs, int splits, const void* bias, int S, int nh, int nkv, int d, const float* inv_freq_dev,
+                                   int64_t pos0, void* q_out, void* Kc, void* Vc, int64_t cap, hipStream_t st);
 hipError_t launch_add_rows(int dtype, void* x, const void* add, int M, int H, int period, hipStream_t st);   // x[m,:] += add[m % period,:]
 hipError_t launch_rope_append(int dtype, const void* qkv, int S, int nh, int nkv, int d, const float* inv_freq_dev, int64_t pos0, void* q_out,
                               void* Kc, void* Vc, int64_t cap, int v_transposed, hipStream_t st);

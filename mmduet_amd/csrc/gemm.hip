@@ -16,6 +16,7 @@ struct GemmP {
     const void* X; const void* W; const void* bias; const void* R; void* Y; float* ws;
     long long ldx, ldw, ldr, ldy;
     int M, N, K, epi, out_f32, kper, vec;
+    int slabs;         // skinny kernel: always leave fp32 slabs in ws (the consumer kernel reduces them)
 };
 
 template <typename T> struct Frag;
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmP p, int KT, int k
         cur ^= 1;
     }
 
-    if (gridDim.y > 1) {
+    if (gridDim.y > 1 || p.slabs) {
         float* ws = p.ws + (long long)blockIdx.y * p.M * p.N;
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -390,7 +391,7 @@ static void launch_skinny_mt(const GemmP& p, const GemmArgs& a, hipStream_t st) 
         splits = cdiv(512, nblocks);
         int maxs = KT / 16; if (maxs < 1) maxs = 1;              // >= 512 k per split
         if (splits > maxs) splits = maxs;
-        if (splits > 16) splits = 16;
+        if (splits > 8) splits = 8;
         while (splits > 1 && (size_t)splits * a.M * a.N * sizeof(float) > a.splitk_ws_bytes) --splits;
     }
     int ktper = (int)round_up(cdiv(KT, splits), 4);
@@ -398,6 +399,7 @@ static void launch_skinny_mt(const GemmP& p, const GemmArgs& a, hipStream_t st) 
     dim3 grid(nblocks, splits);
     if (NT == 2) hipLaunchKernelGGL((gemm_skinny_kernel<MT, 2>), grid, dim3(256), 0, st, p, KT, ktper);
     else hipLaunchKernelGGL((gemm_skinny_kernel<MT, 1>), grid, dim3(256), 0, st, p, KT, ktper);
+    if (a.slabs_out) { *a.slabs_out = splits; return; }
     if (splits > 1) {
         long long work = (long long)a.M * ((a.N + 3) / 4);
         hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), dim3(cdiv(work, 256)), dim3(256), 0, st, p, splits);
@@ -528,7 +530,7 @@ static hipError_t launch_t(const GemmArgs& a, hipStream_t st, int* kind_out) {
     GemmP p;
     p.X = a.X; p.W = a.W; p.bias = a.bias; p.R = a.R; p.Y = a.Y; p.ws = a.splitk_ws;
     p.ldx = a.ldx; p.ldw = a.ldw; p.ldr = a.ldr; p.ldy = a.ldy;
-    p.M = a.M; p.N = a.N; p.K = a.K; p.epi = a.epi; p.out_f32 = a.out_f32;
+    p.M = a.M; p.N = a.N; p.K = a.K; p.epi = a.epi; p.out_f32 = a.out_f32; p.slabs = a.slabs_out ? 1 : 0;
     p.vec = (sizeof(T) == 2 && (a.ldx % 8) == 0 && (a.ldw % 8) == 0 && ((uintptr_t)a.X % 16) == 0 && ((uintptr_t)a.W % 16) == 0) ? 1 : 0;
     if (a.M <= 0 || a.N <= 0) return hipSuccess;
     int variant = a.variant;
@@ -559,6 +561,7 @@ static hipError_t launch_t(const GemmArgs& a, hipStream_t st, int* kind_out) {
             return hipGetLastError();
         }
     }
+    if (a.slabs_out) return hipErrorInvalidValue;          // slab mode exists only on the packed skinny path
     if (a.W == nullptr) return hipErrorInvalidValue;       // only the packed copy exists but the shape needs the generic path
     int splits = 1;
     if (skinny) {
@@ -586,6 +589,8 @@ static hipError_t launch_t(const GemmArgs& a, hipStream_t st, int* kind_out) {
     }
     return hipGetLastError();
 }
+
+bool gemm_can_slab(int dtype, const GemmArgs& a) { return skinny_packed_ok(dtype, a) && a.splitk_ws != nullptr && a.epi != EPI_SWIGLU; }
 
 hipError_t launch_gemm(int dtype, const GemmArgs& a, hipStream_t st, int* kind_out) {
     return dtype == MMD_F32 ? launch_t<float>(a, st, kind_out) : launch_t<bf16_t>(a, st, kind_out);

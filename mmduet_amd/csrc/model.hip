@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <unordered_map>
@@ -20,7 +21,7 @@ static thread_local std::string g_create_error;
 struct RawTensor { void* p = nullptr; std::vector<int64_t> shape; int64_t numel = 0; };
 
 struct Prof {
-    bool on = false;
+    unsigned on = 0;                   // bitmask over MMD_K_* classes
     std::vector<hipEvent_t> pool;
     struct Pending { hipEvent_t a, b; int kind; };
     std::vector<Pending> pending;
@@ -65,6 +66,7 @@ struct mmd_ctx {
     // preprocess tables
     int pp_R = 0; int32_t* pp_coef = 0; int32_t* pp_bounds = 0; int pp_ksize = 0; uint8_t* pp_tmp = 0; size_t pp_tmp_bytes = 0;
     int last_vit_B = 0;
+    bool no_fuse = false;              // MMDUET_NO_FUSE=1: keep the unfused launch schedule (A/B and parity cross-check)
     Prof prof;
 };
 
@@ -99,7 +101,7 @@ static void dev_free(mmd_ctx* c, void* p) {
 struct ProfScope {
     mmd_ctx* c; int kind; hipEvent_t a = nullptr, b = nullptr;
     ProfScope(mmd_ctx* c_, int kind_, double bytes, double flops) : c(c_), kind(kind_) {
-        if (!c->prof.on) return;
+        if (!((c->prof.on >> kind_) & 1u)) return;
         auto get = [&]() { hipEvent_t e; if (!c->prof.pool.empty()) { e = c->prof.pool.back(); c->prof.pool.pop_back(); } else hipEventCreate(&e); return e; };
         a = get(); b = get();
         c->prof.bytes[kind] += bytes; c->prof.flops[kind] += flops; c->prof.n[kind] += 1;
@@ -156,6 +158,7 @@ extern "C" int mmd_create(const mmd_config* cfg, int device, mmd_ctx** out) {
     c->vit_kpad = (int)round_up(3 * cfg->vit_patch * cfg->vit_patch, 64);
     c->vit_ipad = (int)round_up(cfg->vit_intermediate, 64);
     c->qkv_w = (cfg->num_heads + 2 * cfg->num_kv_heads) * cfg->head_dim;
+    { const char* nf = getenv("MMDUET_NO_FUSE"); c->no_fuse = nf && nf[0] == '1'; }
     *out = c;
     return MMD_OK;
 }
@@ -594,14 +597,44 @@ extern "C" int mmd_llm_step(mmd_ctx* c, mmd_stream* s, const void* embeds, int S
     const int64_t n = s->len;
     HIPCHK(c, hipMemcpyAsync(c->l_h, embeds, (size_t)S * H * e, hipMemcpyDeviceToDevice, st));
     const size_t layer_elems = kv_layer_elems(c, s->cap);
+
+    // Fused schedule for the weight-streaming regime (S <= 64, packed bf16 weights): the skinny GEMMs leave fp32 split-K
+    // slabs and the NEXT operator consumes them (reduce + bias + RoPE + KV append; reduce + residual + RMSNorm):
+    // 9 launches per layer instead of 12, identical rounding points.
+    bool fused = false;
+    if (dt == MMD_BF16 && S <= 64 && H <= 4096 && (H & 3) == 0 && !c->no_fuse) {
+        GemmArgs probe; memset(&probe, 0, sizeof(probe));
+        probe.X = c->l_xn; probe.ldx = H; probe.Wp = c->L[0].wqkv_p; probe.M = S; probe.N = c->qkv_w; probe.K = H; probe.epi = EPI_NONE;
+        probe.splitk_ws = c->splitk_ws; probe.splitk_ws_bytes = c->splitk_bytes;
+        GemmArgs p2 = probe; p2.Wp = c->L[0].wdown_p; p2.N = H; p2.K = I; p2.ldx = I; p2.X = c->l_act;
+        GemmArgs p3 = probe; p3.Wp = c->L[0].wo_p; p3.N = H; p3.K = nh * d; p3.ldx = nh * d; p3.X = c->l_attn;
+        fused = gemm_can_slab(dt, probe) && gemm_can_slab(dt, p2) && gemm_can_slab(dt, p3);
+    }
+    auto slab_gemm = [&](const void* X, int64_t ldx, const void* Wp, int N, int K, int* splits) -> int {
+        GemmArgs a; memset(&a, 0, sizeof(a));
+        a.X = X; a.ldx = ldx; a.Wp = Wp; a.M = S; a.N = N; a.K = K; a.epi = EPI_NONE; a.variant = GEMM_SKINNY;
+        a.splitk_ws = c->splitk_ws; a.splitk_ws_bytes = c->splitk_bytes; a.slabs_out = splits;
+        ProfScope ps(c, MMD_K_GEMM_SKINNY, ((double)S * K + (double)N * K) * e + (double)S * N * e, 2.0 * S * N * K);
+        HIPCHK(c, launch_gemm(dt, a, st, nullptr));
+        return MMD_OK;
+    };
+    if (fused) { ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * S * H * e, 0); HIPCHK(c, launch_rmsnorm(dt, c->l_h, c->L[0].ln1, c->l_xn, S, H, g.rms_norm_eps, st)); }
+
     for (int i = 0; i < g.num_layers; ++i) {
         LlmLayer& L = c->L[i];
         void* Kl = (char*)s->K + (size_t)i * layer_elems * e;
         void* Vl = (char*)s->V + (size_t)i * layer_elems * e;
-        { ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * S * H * e, 0); HIPCHK(c, launch_rmsnorm(dt, c->l_h, L.ln1, c->l_xn, S, H, g.rms_norm_eps, st)); }
-        rc = gemm(c, c->l_xn, H, L.wqkv, H, L.bqkv, nullptr, 0, c->l_qkv, c->qkv_w, S, c->qkv_w, H, EPI_NONE, 0, GEMM_AUTO, L.wqkv_p); if (rc) return rc;
-        { ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * S * c->qkv_w * e, 0);
-          HIPCHK(c, launch_rope_append(dt, c->l_qkv, S, nh, nkv, d, c->inv_freq, n, c->l_q, Kl, Vl, s->cap, 1, st)); }
+        int splits = 1;
+        if (fused) {
+            rc = slab_gemm(c->l_xn, H, L.wqkv_p, c->qkv_w, H, &splits); if (rc) return rc;
+            ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * S * c->qkv_w * e, 0);
+            HIPCHK(c, launch_slab_rope_append(c->splitk_ws, splits, L.bqkv, S, nh, nkv, d, c->inv_freq, n, c->l_q, Kl, Vl, s->cap, st));
+        } else {
+            { ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * S * H * e, 0); HIPCHK(c, launch_rmsnorm(dt, c->l_h, L.ln1, c->l_xn, S, H, g.rms_norm_eps, st)); }
+            rc = gemm(c, c->l_xn, H, L.wqkv, H, L.bqkv, nullptr, 0, c->l_qkv, c->qkv_w, S, c->qkv_w, H, EPI_NONE, 0, GEMM_AUTO, L.wqkv_p); if (rc) return rc;
+            ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * S * c->qkv_w * e, 0);
+            HIPCHK(c, launch_rope_append(dt, c->l_qkv, S, nh, nkv, d, c->inv_freq, n, c->l_q, Kl, Vl, s->cap, 1, st));
+        }
         {
             AttnArgs a; memset(&a, 0, sizeof(a));
             a.q = c->l_q; a.ldq = (int64_t)nh * d; a.K = Kl; a.V = Vl; a.k_hs = s->cap * d; a.k_ts = d; a.v_hs = s->cap * d; a.v_ts = d;
@@ -611,12 +644,24 @@ extern "C" int mmd_llm_step(mmd_ctx* c, mmd_stream* s, const void* embeds, int S
             ProfScope ps(c, MMD_K_ATTN_LLM, kvb + 2.0 * S * nh * d * e, 4.0 * S * (double)(n + S) * nh * d);
             HIPCHK(c, launch_attention(dt, a, st));
         }
-        rc = gemm(c, c->l_attn, (int64_t)nh * d, L.wo, (int64_t)nh * d, nullptr, c->l_h, H, c->l_h, H, S, H, nh * d, EPI_RESID, 0, GEMM_AUTO, L.wo_p); if (rc) return rc;
-        { ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * S * H * e, 0); HIPCHK(c, launch_rmsnorm(dt, c->l_h, L.ln2, c->l_xn, S, H, g.rms_norm_eps, st)); }
-        rc = gemm(c, c->l_xn, H, L.wgu, H, nullptr, nullptr, 0, c->l_act, I, S, 2 * I, H, EPI_SWIGLU, 0, GEMM_AUTO, L.wgu_p); if (rc) return rc;
-        rc = gemm(c, c->l_act, I, L.wdown, I, nullptr, c->l_h, H, c->l_h, H, S, H, I, EPI_RESID, 0, GEMM_AUTO, L.wdown_p); if (rc) return rc;
+        const void* next_norm = (i + 1 < g.num_layers) ? c->L[i + 1].ln1 : c->fnorm;
+        void* next_xn = (i + 1 < g.num_layers) ? c->l_xn : c->l_hid;
+        if (fused) {
+            rc = slab_gemm(c->l_attn, (int64_t)nh * d, L.wo_p, H, nh * d, &splits); if (rc) return rc;
+            { ProfScope ps(c, MMD_K_NORM_ROPE, 4.0 * S * H * e, 0);
+              HIPCHK(c, launch_slab_resid_rmsnorm(c->splitk_ws, splits, S, H, c->l_h, c->l_h, L.ln2, g.rms_norm_eps, c->l_xn, st)); }
+            rc = gemm(c, c->l_xn, H, L.wgu, H, nullptr, nullptr, 0, c->l_act, I, S, 2 * I, H, EPI_SWIGLU, 0, GEMM_AUTO, L.wgu_p); if (rc) return rc;
+            rc = slab_gemm(c->l_act, I, L.wdown_p, H, I, &splits); if (rc) return rc;
+            ProfScope ps(c, MMD_K_NORM_ROPE, 4.0 * S * H * e, 0);
+            HIPCHK(c, launch_slab_resid_rmsnorm(c->splitk_ws, splits, S, H, c->l_h, c->l_h, next_norm, g.rms_norm_eps, next_xn, st));
+        } else {
+            rc = gemm(c, c->l_attn, (int64_t)nh * d, L.wo, (int64_t)nh * d, nullptr, c->l_h, H, c->l_h, H, S, H, nh * d, EPI_RESID, 0, GEMM_AUTO, L.wo_p); if (rc) return rc;
+            { ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * S * H * e, 0); HIPCHK(c, launch_rmsnorm(dt, c->l_h, L.ln2, c->l_xn, S, H, g.rms_norm_eps, st)); }
+            rc = gemm(c, c->l_xn, H, L.wgu, H, nullptr, nullptr, 0, c->l_act, I, S, 2 * I, H, EPI_SWIGLU, 0, GEMM_AUTO, L.wgu_p); if (rc) return rc;
+            rc = gemm(c, c->l_act, I, L.wdown, I, nullptr, c->l_h, H, c->l_h, H, S, H, I, EPI_RESID, 0, GEMM_AUTO, L.wdown_p); if (rc) return rc;
+        }
     }
-    { ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * S * H * e, 0); HIPCHK(c, launch_rmsnorm(dt, c->l_h, c->fnorm, c->l_hid, S, H, g.rms_norm_eps, st)); }
+    if (!fused) { ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * S * H * e, 0); HIPCHK(c, launch_rmsnorm(dt, c->l_h, c->fnorm, c->l_hid, S, H, g.rms_norm_eps, st)); }
     if (hidden_out) HIPCHK(c, hipMemcpyAsync(hidden_out, c->l_hid, (size_t)S * H * e, hipMemcpyDeviceToDevice, st));
     s->len = n + S;
     return MMD_OK;
@@ -689,7 +734,7 @@ extern "C" int mmd_greedy_generate(mmd_ctx* c, mmd_stream* s, const void* prompt
 }
 
 // ---- measurement -------------------------------------------------------------------------------------------------------
-extern "C" int mmd_prof_enable(mmd_ctx* c, int on) { if (!c) return MMD_EINVAL; if (!on) prof_drain(c); c->prof.on = on != 0; return MMD_OK; }
+extern "C" int mmd_prof_enable(mmd_ctx* c, int mask) { if (!c) return MMD_EINVAL; if (!mask) prof_drain(c); c->prof.on = (unsigned)mask; return MMD_OK; }
 extern "C" int mmd_prof_reset(mmd_ctx* c) {
     if (!c) return MMD_EINVAL;
     prof_drain(c);
@@ -732,7 +777,7 @@ extern "C" int mmd_op_gemm_bench(mmd_ctx* c, int M, int N, int K, int epi, int v
     HIPCHK(c, hipMemsetAsync(W, 0x3b, (size_t)N * K * e, c->stream));
     if (variant != GEMM_GENERIC && variant != GEMM_LARGE) { rc = make_packed(c, W, N, K, &Wp); if (rc) return rc; }
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    bool was = c->prof.on; c->prof.on = false;
+    unsigned was = c->prof.on; c->prof.on = 0;
     for (int i = 0; i < 3; ++i) { rc = gemm(c, X, K, W, K, nullptr, epi == EPI_RESID ? R : nullptr, NO, Y, NO, M, N, K, epi, 0, variant, Wp); if (rc) return rc; }
     hipEventRecord(a, c->stream);
     for (int i = 0; i < iters; ++i) gemm(c, X, K, W, K, nullptr, epi == EPI_RESID ? R : nullptr, NO, Y, NO, M, N, K, epi, 0, variant, Wp);

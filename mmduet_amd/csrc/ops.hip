@@ -76,6 +76,111 @@ hipError_t launch_layernorm(int dtype, const void* x, const void* w, const void*
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Fused consumers of the skinny GEMM's split-K slabs (bf16 model path).  They replace, with identical rounding points,
+//   splitk_reduce (+bias, +residual)  ->  RMSNorm          (after o_proj / down_proj)
+//   splitk_reduce (+bias)             ->  RoPE + KV append (after the fused q/k/v projection)
+// and save a launch + an activation round trip per GEMM.
+// ---------------------------------------------------------------------------------------------------------------
+template <int MAXS>
+__global__ __launch_bounds__(256) void slab_resid_rmsnorm_kernel(const float* __restrict__ slabs, int splits, int M, int H, const bf16_t* __restrict__ resid,
+                                                                 bf16_t* __restrict__ h_out, const bf16_t* __restrict__ w, float eps, bf16_t* __restrict__ xn) {
+    // one block per row; thread t owns columns {4t + 1024 j}.  All slab loads of a column group are issued before the
+    // first add (MAXS independent 16-byte loads in flight per thread) -- the kernel is pure load latency otherwise.
+    __shared__ float red[4];
+    const int m = blockIdx.x, tid = threadIdx.x;
+    const long long MN = (long long)M * H;
+    float hv[4][4];                                    // up to H = 4096
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = tid * 4 + j * 1024;
+        if (c < H) {
+            const float* sp = slabs + (long long)m * H + c;
+            f32x4_t part[MAXS];
+#pragma unroll
+            for (int s = 0; s < MAXS; ++s) part[s] = s < splits ? *reinterpret_cast<const f32x4_t*>(sp + s * MN) : f32x4_t{0, 0, 0, 0};
+            s16x4_t r = *reinterpret_cast<const s16x4_t*>(resid + (long long)m * H + c);
+            f32x4_t acc = part[0];
+#pragma unroll
+            for (int s = 1; s < MAXS; ++s) acc += part[s];          // same order as the serial reduce: slab 0, 1, 2, ...
+            s16x4_t o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = bf2f(f2bf(bf2f(f2bf(acc[e])) + bf2f((bf16_t)r[e])));      // rnd(rnd(gemm) + residual)
+                hv[j][e] = v; ss += v * v; o[e] = (short)f2bf(v);
+            }
+            *reinterpret_cast<s16x4_t*>(h_out + (long long)m * H + c) = o;
+        }
+    }
+    ss = wave_sum(ss);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    const float inv = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)H + eps);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = tid * 4 + j * 1024;
+        if (c < H) {
+            s16x4_t g = *reinterpret_cast<const s16x4_t*>(w + c);
+            s16x4_t o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (short)f2bf(bf2f((bf16_t)g[e]) * bf2f(f2bf(hv[j][e] * inv)));
+            *reinterpret_cast<s16x4_t*>(xn + (long long)m * H + c) = o;
+        }
+    }
+}
+hipError_t launch_slab_resid_rmsnorm(const float* slabs, int splits, int M, int H, const void* resid_in, void* h_out, const void* norm_w, float eps,
+                                     void* xn_out, hipStream_t st) {
+    if (M <= 0) return hipSuccess;
+    if (H > 4096 || (H & 3) || splits > 16) return hipErrorInvalidValue;
+    if (splits <= 4) hipLaunchKernelGGL(slab_resid_rmsnorm_kernel<4>, dim3(M), dim3(256), 0, st, slabs, splits, M, H, (const bf16_t*)resid_in, (bf16_t*)h_out, (const bf16_t*)norm_w, eps, (bf16_t*)xn_out);
+    else if (splits <= 8) hipLaunchKernelGGL(slab_resid_rmsnorm_kernel<8>, dim3(M), dim3(256), 0, st, slabs, splits, M, H, (const bf16_t*)resid_in, (bf16_t*)h_out, (const bf16_t*)norm_w, eps, (bf16_t*)xn_out);
+    else hipLaunchKernelGGL(slab_resid_rmsnorm_kernel<16>, dim3(M), dim3(256), 0, st, slabs, splits, M, H, (const bf16_t*)resid_in, (bf16_t*)h_out, (const bf16_t*)norm_w, eps, (bf16_t*)xn_out);
+    return hipGetLastError();
+}
+
+__global__ void slab_rope_append_kernel(const float* __restrict__ slabs, int splits, const bf16_t* __restrict__ bias, int S, int nh, int nkv, int d,
+                                        const float* __restrict__ inv_freq_tab, long long pos0, bf16_t* __restrict__ q_out, bf16_t* __restrict__ Kc,
+                                        bf16_t* __restrict__ Vc, long long cap) {
+    const int s = blockIdx.x, head = blockIdx.y, half = d >> 1;
+    const int row_w = (nh + 2 * nkv) * d;
+    const long long MN = (long long)S * row_w;
+    const long long base = (long long)s * row_w + (long long)head * d;
+    const long long pos = pos0 + s;
+    auto val = [&](int i) {                            // rnd(sum of slabs + bias): the bf16 output of the q/k/v projection
+        float part[16];
+#pragma unroll
+        for (int z = 0; z < 16; ++z) part[z] = z < splits ? slabs[z * MN + base + i] : 0.f;      // independent loads first
+        float a = part[0];
+#pragma unroll
+        for (int z = 1; z < 16; ++z) a += part[z];
+        return bf2f(f2bf(a + bf2f(bias[head * d + i])));
+    };
+    if (head >= nh + nkv) {
+        const int kvh = head - nh - nkv;
+        bf16_t* dst = Vc + (long long)kvh * cap * d + ((pos >> 6) * d << 6) + (pos & 63);      // transposed 64-token blocks
+        for (int i = threadIdx.x; i < d; i += blockDim.x) dst[(long long)i << 6] = f2bf(val(i));
+        return;
+    }
+    bf16_t* dst = head < nh ? q_out + (long long)s * nh * d + (long long)head * d : Kc + ((long long)(head - nh) * cap + pos) * d;
+    for (int i = threadIdx.x; i < half; i += blockDim.x) {
+        float ang = (float)pos * inv_freq_tab[i];
+        float c = bf2f(f2bf(cosf(ang))), sn = bf2f(f2bf(sinf(ang)));
+        float x1 = val(i), x2 = val(i + half);
+        float o1 = bf2f(f2bf(x1 * c)) + bf2f(f2bf(-x2 * sn));
+        float o2 = bf2f(f2bf(x2 * c)) + bf2f(f2bf(x1 * sn));
+        dst[i] = f2bf(o1);
+        dst[i + half] = f2bf(o2);
+    }
+}
+hipError_t launch_slab_rope_append(const float* slabs, int splits, const void* bias, int S, int nh, int nkv, int d, const float* inv_freq_dev,
+                                   int64_t pos0, void* q_out, void* Kc, void* Vc, int64_t cap, hipStream_t st) {
+    if (S <= 0) return hipSuccess;
+    hipLaunchKernelGGL(slab_rope_append_kernel, dim3(S, nh + 2 * nkv), dim3(64), 0, st, slabs, splits, (const bf16_t*)bias, S, nh, nkv, d, inv_freq_dev,
+                       (long long)pos0, (bf16_t*)q_out, (bf16_t*)Kc, (bf16_t*)Vc, (long long)cap);
+    return hipGetLastError();
+}
+
 // x[m, :] += add[m % period, :]   (learned position embedding, siglip/modeling_siglip.py:184)
 template <typename T>
 __global__ void add_rows_kernel(T* __restrict__ x, const T* __restrict__ add, long long total, int H, int period) {

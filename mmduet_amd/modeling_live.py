@@ -449,8 +449,15 @@ class VideoHeadLiveLlavaQwenForCausalLM:
         return ids, cache
 
     # ---- measurement --------------------------------------------------------------------------------------------------
-    def prof_enable(self, on=True):
-        check(lib().mmd_prof_enable(self._ctx, int(on)), self._ctx)
+    def prof_enable(self, classes=True):
+        """classes: True = all kernel classes, False = off, or an iterable of class names from _lib.K_NAMES."""
+        if classes is True:
+            mask = (1 << len(_lib.K_NAMES)) - 1
+        elif not classes:
+            mask = 0
+        else:
+            mask = sum(1 << _lib.K_NAMES.index(k) for k in classes)
+        check(lib().mmd_prof_enable(self._ctx, mask), self._ctx)
 
     def prof_reset(self):
         check(lib().mmd_prof_reset(self._ctx), self._ctx)
