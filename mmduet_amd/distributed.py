@@ -68,8 +68,8 @@ def gather_scores(local_scores, t_max=None):
         lens[i] = s.shape[0]
     if world == 1:
         return buf[None], lens[None]
-    out = torch.empty((world,) + tuple(buf.shape), dtype=torch.float32, device=dev)
-    out_l = torch.empty((world, n_max), dtype=torch.int32, device=dev)
-    dist.all_gather_into_tensor(out, buf)          # one RCCL all-gather of the padded score block
+    out = torch.empty((world * n_max, t_max, 2), dtype=torch.float32, device=dev)
+    out_l = torch.empty((world * n_max,), dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(out, buf)          # one RCCL all-gather of the padded score block (concatenated along dim 0)
     dist.all_gather_into_tensor(out_l, lens)
-    return out, out_l
+    return out.view(world, n_max, t_max, 2), out_l.view(world, n_max)

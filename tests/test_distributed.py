@@ -1,0 +1,55 @@
+"""world_size-2 gloo run of the data-parallel score gather (mmduet_amd/distributed.py) on CPU."""
+import os, socket, subprocess, sys, json
+from conftest import ROOT
+
+WORKER = r'''
+import os, sys, json, torch
+sys.path.insert(0, os.environ["MMD_ROOT"])
+from mmduet_amd.distributed import init_distributed, shard_indices, gather_scores
+rank, world, local = init_distributed(backend="gloo")
+lengths = [5, 9, 3, 7, 4]
+mine = shard_indices(len(lengths), rank, world)
+local_scores = [torch.full((lengths[i], 2), float(i)) + torch.arange(lengths[i])[:, None] * 0.01 for i in mine]
+scores, lens = gather_scores(local_scores)
+out = {"rank": rank, "mine": mine, "shape": list(scores.shape), "lens": lens.tolist(),
+       "first": [[float(scores[r, j, 0, 0]) for j in range(scores.shape[1])] for r in range(world)],
+       "balanced": [shard_indices(len(lengths), r, world, lengths) for r in range(world)]}
+print("RESULT " + json.dumps(out), flush=True)
+import torch.distributed as dist
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def test_gather_scores_world2_gloo(tmp_path):
+    script = tmp_path / 'worker.py'
+    script.write_text(WORKER)
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', LOCAL_RANK=str(r), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), MMD_ROOT=ROOT)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=120)
+        assert p.returncode == 0, e[-2000:]
+        outs.append(json.loads([l for l in o.splitlines() if l.startswith('RESULT ')][0][7:]))
+    a, b = sorted(outs, key=lambda x: x['rank'])
+    assert a['mine'] == [0, 2, 4] and b['mine'] == [1, 3]
+    assert a['shape'] == b['shape'] == [2, 3, 9, 2]                 # [world, n_max, t_max, 2]
+    assert a['lens'] == b['lens'] == [[5, 3, 4], [9, 7, 0]]
+    assert a['first'][0] == [0.0, 2.0, 4.0] and a['first'][1][:2] == [1.0, 3.0]
+    assert a['first'] == b['first'] or all(x == y or (x != x and y != y) for r in range(2) for x, y in zip(a['first'][r], b['first'][r]))
+    bal = a['balanced']
+    assert sorted(bal[0] + bal[1]) == [0, 1, 2, 3, 4] and abs(sum([5, 9, 3, 7, 4][i] for i in bal[0]) - 14) <= 2
+
+
+def test_single_process_gather_is_local():
+    import torch
+    from mmduet_amd.distributed import gather_scores, shard_indices
+    s, l = gather_scores([torch.ones(4, 2), torch.zeros(2, 2)])
+    assert s.shape == (1, 2, 4, 2) and l.tolist() == [[4, 2]]
+    assert shard_indices(5, 0, 1) == [0, 1, 2, 3, 4]

@@ -1,0 +1,113 @@
+"""True layer shapes (LLaVA-OV-Qwen2-7B widths, SigLIP-so400m widths; reduced layer count and vocab so the CPU oracle
+finishes in seconds): bf16 HIP path vs the oracle executed in bf16, plus size-independent properties of the schedule."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+from oracle import duet_oracle as O
+
+TOL = 6e-2        # bf16: accumulation-order differences on O(1) logits (the fp32 path is held to 3e-4 in test_gpu_model.py)
+
+
+@pytest.fixture(scope='module')
+def true_shape():
+    from mmduet_amd.configuration_live import VideoHeadLiveLlavaQwenConfig
+    from mmduet_amd.modeling_live import VideoHeadLiveLlavaQwenForCausalLM
+    ocfg = O.OracleConfig(vocab_size=2048, num_hidden_layers=2, vit_layers=1)          # every other dimension is the 7B / so400m default
+    w = O.random_weights(ocfg, seed=3, dtype=torch.bfloat16, scale='unit')
+    pcfg = VideoHeadLiveLlavaQwenConfig(vocab_size=2048, num_hidden_layers=2, vit_num_hidden_layers=2, vit_layers_removed=1,
+                                        frame_num_tokens=49, frame_resolution=384, v_placeholder='<image>')
+    m = VideoHeadLiveLlavaQwenForCausalLM(pcfg, torch_dtype=torch.bfloat16, max_vit_batch=4, max_step_tokens=512, kv_initial_tokens=1024)
+    m.load_state_dict(w)
+    return m, O.OracleModel(ocfg, w), ocfg
+
+
+def maxerr(a, b):
+    return (a.float().cpu() - b.float().cpu()).abs().max().item()
+
+
+def test_vit_projector_pool_true_shape(true_shape):
+    m, om, cfg = true_shape
+    g = torch.Generator().manual_seed(0)
+    px = torch.randn(2, 3, 384, 384, generator=g).to(torch.bfloat16)
+    ve = m.visual_embed(px.cuda())
+    ref = om.visual_embed(px)
+    assert ve.shape == (2 * 49, 3584)
+    scale = ref.float().abs().max().item()
+    assert maxerr(ve, ref) < TOL * max(1.0, scale), (maxerr(ve, ref), scale)
+
+
+def test_llm_steps_true_shape(true_shape):
+    m, om, cfg = true_shape
+    g = torch.Generator().manual_seed(1)
+    steps = [torch.randn(1, 59, 3584, generator=g), torch.randn(1, 49, 3584, generator=g), torch.randn(1, 1, 3584, generator=g),
+             torch.randn(1, 98, 3584, generator=g)]
+    cache = ocache = None
+    for x in steps:
+        x = (x * 0.5).to(torch.bfloat16)
+        out = m(inputs_embeds=x.cuda(), past_key_values=cache); cache = out.past_key_values
+        ref = om(inputs_embeds=x, past_key_values=ocache); ocache = ref.past_key_values
+        assert maxerr(out.informative_logits[0, -1], ref.informative_logits[0, -1]) < TOL
+        assert maxerr(out.relevance_logits[0, -1], ref.relevance_logits[0, -1]) < TOL
+        assert maxerr(out.logits[0, -1], ref.logits[0, -1]) < 2 * TOL
+    assert len(cache) == 59 + 49 + 1 + 98
+
+
+def test_chunked_forward_equals_per_frame_forward(true_shape):
+    """Causality: feeding k frames in one forward gives each frame's head logits as if fed one by one (up to bf16
+    accumulation order: the per-frame step runs the split-K skinny GEMM, the chunk the big-tile GEMM)."""
+    m, om, cfg = true_shape
+    g = torch.Generator().manual_seed(2)
+    frames = [(torch.randn(49, 3584, generator=g) * 0.5).to(torch.bfloat16).cuda() for _ in range(6)]
+    prompt = (torch.randn(1, 20, 3584, generator=g) * 0.5).to(torch.bfloat16).cuda()
+    base = m(inputs_embeds=prompt).past_key_values
+    per, cache = [], base
+    for f in frames:
+        sc, cache = m.frame_step(f[None], cache, [48]); per.append(sc[0])
+    n_end = len(cache)
+    sc_chunk, cache2 = m.frame_step(torch.cat(frames)[None], m.cache_prefix(base, len(base)), [49 * (j + 1) - 1 for j in range(6)])
+    assert len(cache2) == n_end
+    for j in range(6):
+        assert maxerr(sc_chunk[j], per[j]) < TOL
+    # truncate to the end of frame 3 and replay frames 4..5: same scores again (O(1) rollback of speculative chunks)
+    mid = m.cache_prefix(cache2, len(base) + 49 * 3)
+    sc_replay, cache3 = m.frame_step(torch.cat(frames[3:])[None], mid, [48, 97, 146])
+    assert len(cache3) == n_end
+    for j in range(3):
+        assert maxerr(sc_replay[j], sc_chunk[3 + j]) < TOL
+    # determinism: the same call twice is bit-identical
+    sc_a, _ = m.frame_step(frames[0][None], m.cache_prefix(base, len(base)), [48])
+    sc_b, _ = m.frame_step(frames[0][None], m.cache_prefix(base, len(base)), [48])
+    assert torch.equal(sc_a, sc_b)
+
+
+def test_fused_and_unfused_schedules_agree(true_shape, monkeypatch):
+    """The fused slab consumers (reduce+RoPE+append, reduce+residual+RMSNorm) keep the unfused rounding points."""
+    import subprocess, sys, os, json
+    code = r'''
+import os, sys, json, torch
+sys.path.insert(0, os.environ["MMD_ROOT"]); sys.path.insert(0, os.path.join(os.environ["MMD_ROOT"], "tests"))
+from oracle import duet_oracle as O
+from mmduet_amd.configuration_live import VideoHeadLiveLlavaQwenConfig
+from mmduet_amd.modeling_live import VideoHeadLiveLlavaQwenForCausalLM
+ocfg = O.OracleConfig(vocab_size=2048, num_hidden_layers=2, vit_layers=1)
+w = {k: v for k, v in O.random_weights(ocfg, seed=3, dtype=torch.bfloat16, scale="unit").items()}
+pcfg = VideoHeadLiveLlavaQwenConfig(vocab_size=2048, num_hidden_layers=2, vit_num_hidden_layers=2, vit_layers_removed=1, frame_num_tokens=49, frame_resolution=384)
+m = VideoHeadLiveLlavaQwenForCausalLM(pcfg, torch_dtype=torch.bfloat16, max_vit_batch=1, max_step_tokens=128, kv_initial_tokens=512)
+m.load_state_dict(w)
+g = torch.Generator().manual_seed(5)
+c = None; res = []
+for S in (49, 1, 30):
+    x = (torch.randn(1, S, 3584, generator=g) * 0.5).to(torch.bfloat16).cuda()
+    o = m(inputs_embeds=x, past_key_values=c); c = o.past_key_values
+    res.append(o.informative_logits[0, -1].tolist() + o.logits[0, -1, :8].tolist())
+print("RES " + json.dumps(res))
+'''
+    from conftest import ROOT
+    outs = []
+    for nf in ('0', '1'):
+        env = dict(os.environ, MMD_ROOT=ROOT, MMDUET_NO_FUSE=nf)
+        r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(json.loads([l for l in r.stdout.splitlines() if l.startswith('RES ')][0][4:]))
+    assert outs[0] == outs[1]           # bit-identical: same reduction order, same rounding points
