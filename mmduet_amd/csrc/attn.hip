@@ -252,7 +252,7 @@ __global__ void attn_combine_kernel(AttnP p, int nrows_total_all) {
 //   * long contexts: grid.z splits the keys (flash-decoding); attn_combine128_kernel merges the fp32 partials.
 // ------------------------------------------------------------------------------------------------------------------
 template <int RT>
-__global__ __launch_bounds__(256) void attn_gqa128_kernel(AttnP p) {
+__global__ __launch_bounds__(256, 2) void attn_gqa128_kernel(AttnP p) {
     constexpr int D = 128, KT = 64, KLD = D + 8, VLD = KT + 8;
     __shared__ __attribute__((aligned(16))) bf16_t Ks[KT * KLD];
     __shared__ __attribute__((aligned(16))) bf16_t Vt[D * VLD];

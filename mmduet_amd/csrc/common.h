@@ -48,6 +48,29 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
 }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// fast forms for the bf16 path (error <= 2e-7 abs, far below bf16 resolution): raw v_exp_f32 / v_rcp_f32
+__device__ __forceinline__ float gelu_tanh_fast(float x) {
+    const float k = 0.7978845608028654f;
+    float u = k * (x + 0.044715f * x * x * x);
+    // tanh(u) = 1 - 2 / (exp(2u) + 1);  exp(2u) = exp2(2u * log2 e); saturates correctly at +-inf
+    float e = __builtin_amdgcn_exp2f(u * 2.8853900817779268f);
+    float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+    return 0.5f * x * (1.0f + t);
+}
+__device__ __forceinline__ float gelu_erf_fast(float x) {
+    // erf via Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7)
+    float z = fabsf(x) * 0.7071067811865476f;
+    float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+    float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    float er = 1.0f - poly * __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);
+    er = x < 0.f ? -er : er;
+    return 0.5f * x * (1.0f + er);
+}
+template <typename T> __device__ __forceinline__ float gelu_tanh_t(float x) { if constexpr (sizeof(T) == 2) return gelu_tanh_fast(x); else return gelu_tanh_f(x); }
+template <typename T> __device__ __forceinline__ float gelu_erf_t(float x) { if constexpr (sizeof(T) == 2) return gelu_erf_fast(x); else return gelu_erf_f(x); }
+template <typename T> __device__ __forceinline__ float silu_t(float x) {
+    if constexpr (sizeof(T) == 2) return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-x * 1.4426950408889634f)); else return silu_f(x);
+}
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }

@@ -72,8 +72,8 @@ __device__ __forceinline__ void store4(const GemmP& p, int m, int n, const float
     for (int r = 0; r < 4; ++r) {
         float x = v[r];
         if (n + r < p.N && p.bias) x += to_f<T>(((const T*)p.bias)[n + r]);
-        if (p.epi == EPI_GELU_TANH) x = gelu_tanh_f(rnd<T>(x));
-        else if (p.epi == EPI_GELU_ERF) x = gelu_erf_f(rnd<T>(x));
+        if (p.epi == EPI_GELU_TANH) x = gelu_tanh_t<T>(rnd<T>(x));
+        else if (p.epi == EPI_GELU_ERF) x = gelu_erf_t<T>(rnd<T>(x));
         else if (p.epi == EPI_RESID) { if (n + r < p.N) x = rnd<T>(x) + to_f<T>(((const T*)p.R)[(long long)m * p.ldr + n + r]); }
         o[r] = x;
     }
@@ -107,7 +107,7 @@ __device__ __forceinline__ void store4_swiglu(const GemmP& p, int m, int n_gate,
     for (int r = 0; r < 4; ++r) {
         if (oc + r < NO) {
             float gg = rnd<T>(g[r]), uu = rnd<T>(u[r]);
-            float s = rnd<T>(silu_f(gg));
+            float s = rnd<T>(silu_t<T>(gg));
             y[r] = from_f<T>(s * uu);
         }
     }
@@ -417,7 +417,45 @@ static void launch_skinny_mt(const GemmP& p, const GemmArgs& a, hipStream_t st) 
 //     which makes the row-strided fragment reads bank-conflict-free.
 //   * rows beyond M are clamped on load and masked at the store; N % BN == 0 and K % 64 == 0 are dispatch conditions.
 // ------------------------------------------------------------------------------------------------------------------
-template <int BN>
+// guard-free epilogue of the big-tile kernel: N % BN == 0, ldy/ldr % 4 == 0 (dispatch conditions), one 8-byte access
+// per operand and tile; EPI is a compile-time constant so no per-element branches survive.
+template <int EPI>
+__device__ __forceinline__ void big_store(const GemmP& p, int m, int n, const f32x4_t& a) {
+    if (m >= p.M) return;
+    float v[4] = {a[0], a[1], a[2], a[3]};
+    if (p.bias) {
+        s16x4_t b = *reinterpret_cast<const s16x4_t*>((const bf16_t*)p.bias + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += bf2f((bf16_t)b[r]);
+    }
+    if constexpr (EPI == EPI_GELU_TANH) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_fast(bf2f(f2bf(v[r])));
+    } else if constexpr (EPI == EPI_GELU_ERF) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_erf_fast(bf2f(f2bf(v[r])));
+    } else if constexpr (EPI == EPI_RESID) {
+        s16x4_t rr = *reinterpret_cast<const s16x4_t*>((const bf16_t*)p.R + (long long)m * p.ldr + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = bf2f(f2bf(v[r])) + bf2f((bf16_t)rr[r]);
+    }
+    s16x4_t o = {(short)f2bf(v[0]), (short)f2bf(v[1]), (short)f2bf(v[2]), (short)f2bf(v[3])};
+    *reinterpret_cast<s16x4_t*>((bf16_t*)p.Y + (long long)m * p.ldy + n) = o;
+}
+__device__ __forceinline__ void big_store_swiglu(const GemmP& p, int m, int n_gate, const f32x4_t& g, const f32x4_t& u) {
+    if (m >= p.M) return;
+    const int oc = (n_gate >> 5) * 16 + (n_gate & 15);
+    s16x4_t o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float gg = bf2f(f2bf(g[r])), uu = bf2f(f2bf(u[r]));
+        float sl = bf2f(f2bf(gg * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-gg * 1.4426950408889634f))));
+        o[r] = (short)f2bf(sl * uu);
+    }
+    *reinterpret_cast<s16x4_t*>((bf16_t*)p.Y + (long long)m * p.ldy + oc) = o;
+}
+
+template <int BN, int EPI>
 __global__ __launch_bounds__(256) void gemm_big_kernel(GemmP p, int KT) {
     constexpr int BM = 128, BK = 64;
     constexpr int TM = 4, TN = BN / 32;                      // 16x16 tiles per wave (wave tile 64 x BN/2)
@@ -431,7 +469,10 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(GemmP p, int KT) {
     const int nbx = gridDim.x, nby = gridDim.y;
     int bid = blockIdx.y * nbx + blockIdx.x;
     const int nblk = nbx * nby;
-    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+    {   // bijective for any grid size: XCD x owns a contiguous run of q (+1 for the first r XCDs) tile ids
+        const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
     const int m0 = (bid / nbx) * BM, n0 = (bid % nbx) * BN;
     const bf16_t* X = (const bf16_t*)p.X;
     const bf16_t* Wp = (const bf16_t*)p.W;
@@ -495,28 +536,33 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(GemmP p, int KT) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + wm + i * 16 + lr;
-        if (p.epi == EPI_SWIGLU) {
+        if constexpr (EPI == EPI_SWIGLU) {
 #pragma unroll
-            for (int j = 0; j < TN; j += 2) {
-                const int n = n0 + wn + j * 16 + lq * 4;
-                float g[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                float u[4] = {acc[i][j + 1][0], acc[i][j + 1][1], acc[i][j + 1][2], acc[i][j + 1][3]};
-                store4_swiglu<bf16_t>(p, m, n, g, u);
-            }
+            for (int j = 0; j < TN; j += 2) big_store_swiglu(p, m, n0 + wn + j * 16 + lq * 4, acc[i][j], acc[i][j + 1]);
         } else {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = n0 + wn + j * 16 + lq * 4;
-                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                store4<bf16_t>(p, m, n, v);
-            }
+            for (int j = 0; j < TN; ++j) big_store<EPI>(p, m, n0 + wn + j * 16 + lq * 4, acc[i][j]);
         }
+    }
+}
+
+template <int BN>
+static void launch_big(const GemmP& p, const GemmArgs& a, hipStream_t st) {
+    dim3 grid(a.N / BN, cdiv(a.M, 128));
+    const int KT = a.K >> 5;
+    switch (a.epi) {
+        case EPI_GELU_TANH: hipLaunchKernelGGL((gemm_big_kernel<BN, EPI_GELU_TANH>), grid, dim3(256), 0, st, p, KT); break;
+        case EPI_GELU_ERF: hipLaunchKernelGGL((gemm_big_kernel<BN, EPI_GELU_ERF>), grid, dim3(256), 0, st, p, KT); break;
+        case EPI_RESID: hipLaunchKernelGGL((gemm_big_kernel<BN, EPI_RESID>), grid, dim3(256), 0, st, p, KT); break;
+        case EPI_SWIGLU: hipLaunchKernelGGL((gemm_big_kernel<BN, EPI_SWIGLU>), grid, dim3(256), 0, st, p, KT); break;
+        default: hipLaunchKernelGGL((gemm_big_kernel<BN, EPI_NONE>), grid, dim3(256), 0, st, p, KT); break;
     }
 }
 
 static bool big_packed_ok(int dtype, const GemmArgs& a, int BN) {
     return dtype == MMD_BF16 && a.Wp != nullptr && a.M > 64 && (a.N % BN) == 0 && (a.K % 64) == 0 && (a.ldx % 8) == 0 &&
-           ((uintptr_t)a.X % 16) == 0;
+           ((uintptr_t)a.X % 16) == 0 && !a.out_f32 && (a.ldy % 4) == 0 && ((uintptr_t)a.Y % 8) == 0 &&
+           (a.epi != EPI_RESID || ((a.ldr % 4) == 0 && ((uintptr_t)a.R % 8) == 0)) && (a.bias == nullptr || ((uintptr_t)a.bias % 8) == 0);
 }
 
 // packed-W skinny path usable?  bf16, M <= 64, N % 16 == 0, K % 32 == 0, 16-byte aligned rows of X
@@ -546,9 +592,7 @@ static hipError_t launch_t(const GemmArgs& a, hipStream_t st, int* kind_out) {
             if (bn) {
                 p.W = a.Wp;
                 if (kind_out) *kind_out = MMD_K_GEMM_TILE;
-                dim3 grid(a.N / bn, cdiv(a.M, 128));
-                if (bn == 128) hipLaunchKernelGGL((gemm_big_kernel<128>), grid, dim3(256), 0, st, p, a.K >> 5);
-                else hipLaunchKernelGGL((gemm_big_kernel<64>), grid, dim3(256), 0, st, p, a.K >> 5);
+                if (bn == 128) launch_big<128>(p, a, st); else launch_big<64>(p, a, st);
                 return hipGetLastError();
             }
             if (variant == GEMM_BIG) return hipErrorInvalidValue;
