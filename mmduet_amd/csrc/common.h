@@ -91,6 +91,7 @@ struct GemmArgs {
     int epi; int out_f32;
     int variant;
     float* splitk_ws; size_t splitk_ws_bytes;   // fp32 partial slabs
+    int no_gemv = 0;                            // A/B switch: use the LDS-staged skinny kernel also for M <= 16
     int* slabs_out = nullptr;                   // if set (packed skinny path only): leave [splits][M][N] fp32 slabs in splitk_ws, no
                                                 // epilogue, and return the split count here; a fused consumer kernel reduces them
 };

@@ -381,6 +381,102 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmP p, int KT, int k
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// M <= 16 (decode, M = 1): pure weight streaming.  A block owns NT n-tiles; its 4 waves split K four ways and each
+// wave streams its part of the packed W with U independent 1 KiB non-temporal loads in flight (no LDS, no barrier in
+// the loop -- "GEMV: load straight to VGPRs, deep unroll, late wait").  X rows (<= 16, L2-resident) are read as MFMA
+// operands directly.  The four partial accumulators meet in LDS once; wave 0 applies the epilogue (or leaves ONE fp32
+// slab for the fused consumer): no split-K slabs, no reduce launch.
+// ------------------------------------------------------------------------------------------------------------------
+template <int NT, int U>
+__global__ __launch_bounds__(256) void gemm_gemv16_kernel(GemmP p, int KT) {
+    __shared__ __attribute__((aligned(16))) float red[3][NT][64][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int nt0 = blockIdx.x * NT;
+    // K range of this block (grid.y splits K into slabs when N alone gives too few blocks), then of this wave
+    const int ktb = (KT + gridDim.y - 1) / gridDim.y;
+    const int blk_beg = blockIdx.y * ktb, blk_end = min(KT, blk_beg + ktb);
+    const int ktw = (blk_end - blk_beg + 3) >> 2;
+    const int kt_beg = blk_beg + wave * ktw, kt_end = min(blk_end, kt_beg + ktw);
+    const bf16_t* Wp = (const bf16_t*)p.W;
+    const bf16_t* xrow = (const bf16_t*)p.X + (long long)lr * p.ldx + lq * 8;
+    const bool row_ok = lr < p.M;
+
+    f32x4_t acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j] = f32x4_t{0, 0, 0, 0};
+
+    for (int kt0 = kt_beg; kt0 < kt_end; kt0 += U) {
+        bf16x8_t w[NT][U], x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int kt = kt0 + u;
+            s16x8_t xv = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (kt < kt_end) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    w[j][u] = __builtin_bit_cast(bf16x8_t, __builtin_nontemporal_load(reinterpret_cast<const s16x8_t*>(Wp + (((long long)(nt0 + j) * KT + kt) * 64 + lane) * 8)));
+                if (row_ok) xv = *reinterpret_cast<const s16x8_t*>(xrow + kt * 32);
+            } else {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) w[j][u] = __builtin_bit_cast(bf16x8_t, xv);
+            }
+            x[u] = __builtin_bit_cast(bf16x8_t, xv);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j][u], x[u], acc[j], 0, 0, 0);
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) *reinterpret_cast<f32x4_t*>(&red[wave - 1][j][lane][0]) = acc[j];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int w2 = 0; w2 < 3; ++w2) acc[j] += *reinterpret_cast<const f32x4_t*>(&red[w2][j][lane][0]);
+    const int m = lr;
+    if (m >= p.M) return;
+    if (p.slabs) {
+        float* ws = p.ws + (long long)blockIdx.y * p.M * p.N;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) *reinterpret_cast<f32x4_t*>(ws + (long long)m * p.N + (nt0 + j) * 16 + lq * 4) = acc[j];
+        return;
+    }
+    if (p.epi == EPI_SWIGLU) {
+        if constexpr (NT >= 2) {
+#pragma unroll
+            for (int j = 0; j < NT; j += 2) {
+                float g[4] = {acc[j][0], acc[j][1], acc[j][2], acc[j][3]};
+                float u[4] = {acc[j + 1][0], acc[j + 1][1], acc[j + 1][2], acc[j + 1][3]};
+                store4_swiglu<bf16_t>(p, m, (nt0 + j) * 16 + lq * 4, g, u);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            float v[4] = {acc[j][0], acc[j][1], acc[j][2], acc[j][3]};
+            store4<bf16_t>(p, m, (nt0 + j) * 16 + lq * 4, v);
+        }
+    }
+}
+
+static void launch_gemv16(const GemmP& p, const GemmArgs& a, hipStream_t st) {
+    const int KT = a.K >> 5, ntiles = a.N >> 4;
+    int ksplit = 1;
+    if (a.slabs_out && ntiles < 512 && KT >= 256 && a.splitk_ws) {          // long K, few n-tiles (down_proj): 2-4 K slabs
+        ksplit = cdiv(768, ntiles); if (ksplit > 4) ksplit = 4;
+        while (ksplit > 1 && (size_t)ksplit * a.M * a.N * sizeof(float) > a.splitk_ws_bytes) --ksplit;
+    }
+    if (a.slabs_out) *a.slabs_out = ksplit;
+    if (a.epi == EPI_SWIGLU || (ntiles % 2 == 0 && ntiles >= 2048)) hipLaunchKernelGGL((gemm_gemv16_kernel<2, 8>), dim3(ntiles / 2, ksplit), dim3(256), 0, st, p, KT);
+    else hipLaunchKernelGGL((gemm_gemv16_kernel<1, 8>), dim3(ntiles, ksplit), dim3(256), 0, st, p, KT);
+}
+
 template <int MT>
 static void launch_skinny_mt(const GemmP& p, const GemmArgs& a, hipStream_t st) {
     const int KT = a.K >> 5, ntiles = a.N >> 4;
@@ -599,7 +695,8 @@ static hipError_t launch_t(const GemmArgs& a, hipStream_t st, int* kind_out) {
         }
         if (skinny && skinny_packed_ok(MMD_BF16, a)) {
             p.W = a.Wp;
-            if (a.M <= 16) launch_skinny_mt<1>(p, a, st);
+            if (a.M <= 16 && !a.no_gemv) launch_gemv16(p, a, st);
+            else if (a.M <= 16) launch_skinny_mt<1>(p, a, st);
             else if (a.M <= 32) launch_skinny_mt<2>(p, a, st);
             else launch_skinny_mt<4>(p, a, st);
             return hipGetLastError();

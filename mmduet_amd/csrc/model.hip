@@ -776,11 +776,22 @@ extern "C" int mmd_op_gemm_bench(mmd_ctx* c, int M, int N, int K, int epi, int v
     HIPCHK(c, hipMemsetAsync(X, 0x3c, (size_t)M * K * e, c->stream));
     HIPCHK(c, hipMemsetAsync(W, 0x3b, (size_t)N * K * e, c->stream));
     if (variant != GEMM_GENERIC && variant != GEMM_LARGE) { rc = make_packed(c, W, N, K, &Wp); if (rc) return rc; }
+    if (variant == 5 && !Wp) FAIL(c, MMD_EINVAL, "slab mode needs a packable shape");
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     unsigned was = c->prof.on; c->prof.on = 0;
-    for (int i = 0; i < 3; ++i) { rc = gemm(c, X, K, W, K, nullptr, epi == EPI_RESID ? R : nullptr, NO, Y, NO, M, N, K, epi, 0, variant, Wp); if (rc) return rc; }
+    int slabs = 0;
+    auto run = [&]() -> int {
+        if (variant == 5) {        // skinny path in slab mode (what the fused LLM schedule launches); the consumer kernel is not part of this timing
+            GemmArgs g; memset(&g, 0, sizeof(g));
+            g.X = X; g.ldx = K; g.Wp = Wp; g.M = M; g.N = N; g.K = K; g.epi = EPI_NONE; g.variant = GEMM_SKINNY;
+            g.splitk_ws = c->splitk_ws; g.splitk_ws_bytes = c->splitk_bytes; g.slabs_out = &slabs;
+            return launch_gemm(c->cfg.dtype, g, c->stream, nullptr) == hipSuccess ? MMD_OK : MMD_EHIP;
+        }
+        return gemm(c, X, K, W, K, nullptr, epi == EPI_RESID ? R : nullptr, NO, Y, NO, M, N, K, epi, 0, variant, Wp);
+    };
+    for (int i = 0; i < 3; ++i) { rc = run(); if (rc) return rc; }
     hipEventRecord(a, c->stream);
-    for (int i = 0; i < iters; ++i) gemm(c, X, K, W, K, nullptr, epi == EPI_RESID ? R : nullptr, NO, Y, NO, M, N, K, epi, 0, variant, Wp);
+    for (int i = 0; i < iters; ++i) run();
     hipEventRecord(b, c->stream);
     hipEventSynchronize(b);
     float ms = 0; hipEventElapsedTime(&ms, a, b);

@@ -21,7 +21,8 @@ if __name__ == '__main__':
         for M in (1, 16, 49, 64):
             for name, N, K, epi in LLM:
                 if name == 'lm_head' and M > 1: continue
-                for variant, vn in ((1, 'generic64'), (2, 'skinny')):
+                for variant, vn in ((2, 'skinny'), (5, 'skinny-slab')):
+                    if variant == 5 and (epi == 'swiglu' or name == 'lm_head'): continue
                     ms = run(ops, M, N, K, epi, variant)
                     gb = (N * K + M * K + M * (N // 2 if epi == 'swiglu' else N)) * 2 / 1e9
                     print(f'M={M:4d} {name:8s} N={N:6d} K={K:6d} {vn:10s} {ms*1e3:8.1f} us  {gb/ms*1e3:7.0f} GB/s  {2*M*N*K/ms/1e9:7.1f} TF', flush=True)
