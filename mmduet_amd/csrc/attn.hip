@@ -478,6 +478,191 @@ static hipError_t launch_gqa128(AttnP& p, const AttnArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// attn_rowmajor_kernel: MHSA over token-major K/V rows (the fused SigLIP qkv buffer; head_dim 72 -> 96 for QK^T, 80 for
+// P.V).  Same register-resident softmax pipeline as attn_gqa128_kernel; the V^T operand comes from a ROW-MAJOR V tile via
+// the gfx950 LDS transpose read (ds_read_b64_tr_b16): V is staged as [d/16][key/4][4 keys][16 dims] blocks, a 16-lane
+// group reads one 4x16 block and every lane receives 4 consecutive keys of ONE dim -- exactly the k-slot order the P
+// operand already has -- so no transposed copy of V is ever made.  128 query rows per block (4 waves x 2 row tiles),
+// 64-key tiles, next tile prefetched into registers during the MFMAs.
+// ------------------------------------------------------------------------------------------------------------------
+template <int NC, int DVT>      // NC = ceil(d/32) QK k-steps, DVT = max 16-wide output tiles
+__global__ __launch_bounds__(256, 2) void attn_rowmajor_kernel(AttnP p) {
+    constexpr int RT = 2, KT = 64, DQ = NC * 32, KLD = DQ + 8;
+    constexpr int NCH = DQ / 8;                                 // 16-byte chunks per key row (incl. zero padding)
+    constexpr int PRE = (KT * NCH + 255) / 256;
+    __shared__ __attribute__((aligned(16))) bf16_t Ks[KT * KLD];
+    __shared__ __attribute__((aligned(16))) bf16_t Vs[DVT * 16 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int d = p.d, dvt = (d + 15) >> 4, nch = d >> 3;
+    const int G = p.nh / p.nkv;
+    const int head = blockIdx.y, kvh = head / G, b = blockIdx.z;
+    const int n_tot = (int)(p.n_ctx + p.S);
+    const bf16_t* Kg = (const bf16_t*)p.K + b * p.kv_bs + kvh * p.k_hs;
+    const bf16_t* Vg = (const bf16_t*)p.V + b * p.kv_bs + kvh * p.v_hs;
+    const int row_base = blockIdx.x * (64 * RT) + wave * (16 * RT);
+
+    int my_tok[RT]; bool row_ok[RT]; int my_limit[RT];
+    bf16x8_t qf[RT][NC];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        my_tok[rt] = row_base + rt * 16 + lr;
+        row_ok[rt] = my_tok[rt] < p.S;
+        my_limit[rt] = !row_ok[rt] ? 0 : (p.causal ? (int)p.n_ctx + my_tok[rt] + 1 : n_tot);
+        const bf16_t* qrow = (const bf16_t*)p.q + b * p.q_bs + (long long)(row_ok[rt] ? my_tok[rt] : 0) * p.ldq + (long long)head * d;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int e = c * 32 + lq * 8;
+            s16x8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (row_ok[rt] && e + 8 <= d) v = *reinterpret_cast<const s16x8_t*>(qrow + e);
+            qf[rt][c] = __builtin_bit_cast(bf16x8_t, v);
+        }
+    }
+    const bool wave_active = row_base < p.S;
+    const int blk_last = min(blockIdx.x * (64 * RT) + 64 * RT - 1, p.S - 1);
+    const int kend = p.causal ? min(n_tot, (int)p.n_ctx + blk_last + 1) : n_tot;
+    const int blk_min_limit = p.causal ? (int)p.n_ctx + blockIdx.x * (64 * RT) + 1 : n_tot;
+
+    // zero both images once: padding chunks / dims are never written again
+    for (int i = tid; i < KT * KLD / 8; i += 256) *reinterpret_cast<s16x8_t*>(Ks + i * 8) = s16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = tid; i < DVT * 16 * 64 / 8; i += 256) *reinterpret_cast<s16x8_t*>(Vs + i * 8) = s16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+
+    f32x4_t oacc[RT][DVT];
+    float m_run[RT], l_run[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        m_run[rt] = -INFINITY; l_run[rt] = 0.f;
+#pragma unroll
+        for (int t = 0; t < DVT; ++t) oacc[rt][t] = f32x4_t{0, 0, 0, 0};
+    }
+
+    s16x8_t pk_[PRE], pv_[PRE];
+    auto prefetch = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < PRE; ++j) {
+            const int i = tid + 256 * j;
+            const int key = i / NCH, c = i % NCH;
+            s16x8_t kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (i < KT * NCH && c < nch && k0 + key < kend) {
+                kv = *reinterpret_cast<const s16x8_t*>(Kg + (long long)(k0 + key) * p.k_ts + c * 8);
+                vv = *reinterpret_cast<const s16x8_t*>(Vg + (long long)(k0 + key) * p.v_ts + c * 8);
+            }
+            pk_[j] = kv; pv_[j] = vv;
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int j = 0; j < PRE; ++j) {
+            const int i = tid + 256 * j;
+            const int key = i / NCH, c = i % NCH;
+            if (i < KT * NCH && c < nch) {
+                *reinterpret_cast<s16x8_t*>(Ks + key * KLD + c * 8) = pk_[j];
+                // V image: block (dtile = c>>1, quad = key>>2), row key&3, cols (c&1)*8..
+                *reinterpret_cast<s16x8_t*>(Vs + (((c >> 1) * 16 + (key >> 2)) * 4 + (key & 3)) * 16 + (c & 1) * 8) = pv_[j];
+            }
+        }
+    };
+
+    if (0 < kend) prefetch(0);
+    for (int k0 = 0; k0 < kend; k0 += KT) {
+        __syncthreads();
+        commit();
+        __syncthreads();
+        if (k0 + KT < kend) prefetch(k0 + KT);
+        if (!wave_active) continue;
+        const bool need_mask = (k0 + KT > blk_min_limit) || (k0 + KT > kend);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f32x4_t st[RT][2];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) { st[rt][0] = f32x4_t{0, 0, 0, 0}; st[rt][1] = f32x4_t{0, 0, 0, 0}; }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + (h * 32 + t * 16 + lr) * KLD + c * 32 + lq * 8);
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) st[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[rt][c], st[rt][t], 0, 0, 0);
+                }
+            bf16x8_t pf[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                float sv[8];
+                float mx = -INFINITY;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = st[rt][t][r] * p.scale_log2;
+                        if (need_mask) {
+                            const int key = k0 + h * 32 + t * 16 + lq * 4 + r;
+                            if (!(key < my_limit[rt] && key < kend)) v = -INFINITY;
+                        }
+                        sv[t * 4 + r] = v;
+                        mx = fmaxf(mx, v);
+                    }
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                float m_new = fmaxf(m_run[rt], mx);
+                float m_use = m_new == -INFINITY ? 0.f : m_new;
+                float alpha = __builtin_amdgcn_exp2f(m_run[rt] - m_use);
+                float psum = 0.f;
+                s16x8_t pk;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { float pv = __builtin_amdgcn_exp2f(sv[i] - m_use); psum += pv; pk[i] = (short)f2bf(pv); }
+                l_run[rt] = l_run[rt] * alpha + psum;
+                m_run[rt] = m_new;
+                pf[rt] = __builtin_bit_cast(bf16x8_t, pk);
+                if (alpha != 1.0f) {
+#pragma unroll
+                    for (int t = 0; t < DVT; ++t) oacc[rt][t] *= alpha;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < DVT; ++t) {
+                if (t < dvt) {
+                    // transpose reads: 4x16 blocks (quad = h*8 + lq) and (quad = h*8 + 4 + lq) of d-tile t
+                    const bf16_t* blk = Vs + ((t * 16 + h * 8 + lq) * 64) + lr * 4;
+                    s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(blk));
+                    s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(blk + 4 * 64));
+                    s16x8_t vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    bf16x8_t vfb = __builtin_bit_cast(bf16x8_t, vf);
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) oacc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfb, pf[rt], oacc[rt][t], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        float l = l_run[rt];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        if (!row_ok[rt]) continue;
+        bf16_t* orow = (bf16_t*)p.out + b * p.o_bs + (long long)my_tok[rt] * p.ldo + (long long)head * d;
+        const float inv = l > 0.f ? 1.0f / l : 0.f;
+#pragma unroll
+        for (int t = 0; t < DVT; ++t) {
+            const int e = t * 16 + lq * 4;
+            if (t < dvt && e + 4 <= d) {
+                s16x4_t o = {(short)f2bf(oacc[rt][t][0] * inv), (short)f2bf(oacc[rt][t][1] * inv), (short)f2bf(oacc[rt][t][2] * inv), (short)f2bf(oacc[rt][t][3] * inv)};
+                *reinterpret_cast<s16x4_t*>(orow + e) = o;
+            } else if (t < dvt) {
+                for (int r = 0; r < 4; ++r) if (e + r < d) orow[e + r] = f2bf(oacc[rt][t][r] * inv);
+            }
+        }
+    }
+}
+
+template <int NC, int DVT>
+static hipError_t launch_rowmajor(AttnP& p, const AttnArgs& a, hipStream_t st) {
+    p.splits = 1; p.kv_per_split = 0;
+    hipLaunchKernelGGL((attn_rowmajor_kernel<NC, DVT>), dim3(cdiv(a.S, 128), a.nh, a.batch), dim3(256), 0, st, p);
+    return hipGetLastError();
+}
+
 template <int DP>
 static hipError_t launch_mfma(AttnP& p, const AttnArgs& a, hipStream_t st) {
     int G = a.nh / a.nkv;
@@ -520,7 +705,16 @@ hipError_t launch_attention(int dtype, const AttnArgs& a, hipStream_t st) {
                     (a.k_hs % 8) == 0 && (a.v_hs % 8) == 0 && (a.kv_bstride % 8) == 0 && (a.q_bstride % 8) == 0;
     int variant = a.variant;
     const bool can_gqa128 = can_mfma && a.d == 128 && a.v_transposed && a.batch == 1 && a.k_ts == 128;
-    if (variant == 0) variant = can_gqa128 ? 3 : (can_mfma ? 2 : 1);
+    // token-major K/V rows (ViT fused qkv): the transpose-read kernel; it keeps a whole sequence per (head, batch) block
+    const bool can_rowmajor = can_mfma && !a.v_transposed && a.n_ctx + a.S < (1 << 30) && (a.o_bstride % 4) == 0 && (a.ldo % 4) == 0;
+    if (variant == 0) variant = can_gqa128 ? 3 : (can_rowmajor && a.S >= 64 ? 4 : (can_mfma ? 2 : 1));
+    if (variant == 4) {
+        if (!can_rowmajor) return hipErrorInvalidValue;
+        if (a.d <= 32) return launch_rowmajor<1, 2>(p, a, st);
+        if (a.d <= 64) return launch_rowmajor<2, 4>(p, a, st);
+        if (a.d <= 96) return launch_rowmajor<3, 6>(p, a, st);
+        return launch_rowmajor<4, 8>(p, a, st);
+    }
     if (variant == 2 && !can_mfma) return hipErrorInvalidValue;
     if (variant == 3) {
         if (!can_gqa128) return hipErrorInvalidValue;

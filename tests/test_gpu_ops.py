@@ -135,13 +135,13 @@ def ref_attention(q, K, V, nh, nkv, d, n_ctx, causal, dtype):
 ATTN_CASES = [  # S, nh, nkv, d, n_ctx, causal
     (1, 4, 2, 16, 0, True), (7, 4, 2, 16, 5, True), (49, 4, 1, 32, 300, True), (130, 4, 2, 16, 41, True),
     (49, 28, 4, 128, 0, True), (49, 28, 4, 128, 3000, True), (1, 28, 4, 128, 2500, True), (3, 28, 4, 128, 70, True), (98, 28, 4, 128, 777, True),
-    (49, 28, 4, 128, 15000, True), (20, 8, 8, 128, 100, False), (200, 8, 8, 72, 0, False),
+    (49, 28, 4, 128, 15000, True), (20, 8, 8, 128, 100, False), (729, 16, 16, 72, 0, False), (300, 4, 4, 72, 0, False), (130, 2, 1, 24, 0, False), (200, 8, 8, 72, 0, False),
     (16, 2, 2, 24, 0, False), (33, 4, 4, 64, 100, False),
 ]
 
 
 @pytest.mark.parametrize('S,nh,nkv,d,n_ctx,causal', ATTN_CASES)
-@pytest.mark.parametrize('variant', [1, 2, 3])
+@pytest.mark.parametrize('variant', [1, 2, 3, 4])
 def test_attention(ops, S, nh, nkv, d, n_ctx, causal, variant):
     if variant >= 2 and ops.dtype != torch.bfloat16:
         pytest.skip('the MFMA attention kernels are bf16 only')
