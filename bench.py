@@ -15,7 +15,7 @@ scores are all-gathered over RCCL inside the timed region.
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP events on the launch stream) and `cpu_baseline`
 (the oracle on the host cores, bounded sample).
 """
-import argparse, json, math, os, sys, time
+import argparse, json, math, os, random, sys, time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -32,10 +32,11 @@ def parse():
     p.add_argument('--warmup', type=int, default=1)
     p.add_argument('--frames', type=int, default=300)
     p.add_argument('--resolution', type=int, default=336)
-    p.add_argument('--frames-per-forward', type=int, default=16, help='frames per causal LLM forward (1 = the reference schedule; results agree up to fp reduction order)')
-    p.add_argument('--responses', type=int, default=4, help='responses per stream, forced at evenly spaced frames (random-init heads carry no signal)')
+    p.add_argument('--frames-per-forward', type=int, default=20, help='frames per causal LLM forward (1 = the reference schedule; results agree up to fp reduction order)')
+    p.add_argument('--responses', type=int, default=4, help='responses per stream, forced at frames drawn once from random.Random(0) (random-init heads carry no signal)')
     p.add_argument('--max-new-tokens', type=int, default=32)
     p.add_argument('--tiny', action='store_true', help='tiny model (plumbing check, not a valid measurement)')
+    p.add_argument('--no-overlap', action='store_true', help='run the vision tower and the LLM steps on one stream')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-prof', action='store_true', help='do not bracket the dominant kernel with HIP events in the timed region')
     p.add_argument('--layers', type=int, default=None, help='debug: override LLM layer count (INVALID as a measurement)')
@@ -82,7 +83,7 @@ def make_driver(args, model, tok, threshold, forced=()):
             return fired or (self.frame_idx in self.forced_frames)
     a = LiveTestArguments(llm_pretrained='synthetic:bench', frame_fps=1.0, bf16=True, stream_end_prob_threshold=threshold,
                           score_heads='informative_score', max_new_tokens=args.max_new_tokens,
-                          frames_per_forward=args.frames_per_forward,
+                          frames_per_forward=args.frames_per_forward, overlap_vision=not args.no_overlap,
                           system_prompt='A multimodal AI assistant is helping users with some activities.')
     d = BenchDriver(a, model=model, tokenizer=tok)
     d.eos_token_id = -1            # random weights: let every response run to the cap so the work per response is fixed
@@ -141,7 +142,7 @@ def main():
 
     # untimed pass with every kernel class bracketed: finds the dominant kernel class of this schedule
     T = args.frames
-    forced = [int(round((i + 1) * T / args.responses)) for i in range(args.responses)] if args.responses > 0 else []
+    forced = sorted(random.Random(0).sample(range(1, T + 1), args.responses)) if args.responses > 0 else []   # fixed pseudo-random frames
     threshold = 1.0          # informative probability never exceeds 1: the rule is evaluated every frame but responses follow `forced`
     driver = make_driver(args, model, tok, threshold, forced)
     model.prof_reset(); model.prof_enable(True)

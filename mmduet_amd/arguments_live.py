@@ -69,6 +69,7 @@ class LiveTestArguments(LiveTrainingArguments):
     frames_per_forward: int = 1          # speculative multi-frame causal chunks (DESIGN.md "chunked stepping")
     kv_capacity_tokens: int = 0          # 0 = size the KV arena from max_num_frames
     max_new_tokens: int = 200            # test/inference.py:42 uses a 200-wide output buffer
+    overlap_vision: bool = True          # encode frames on a side HIP stream, overlapping the LLM steps
 
 
 def get_args_class(args_version: str):

@@ -71,6 +71,8 @@ class LiveInferForBenchmark:
         self.remove_assistant_turns = args.remove_assistant_turns
         self.repetition_penalty = args.repetition_penalty
         self.frames_per_forward = max(1, int(getattr(args, 'frames_per_forward', 1)))
+        self.overlap_vision = bool(getattr(args, 'overlap_vision', True))
+        self._vit_stream = None
 
         self.eos_token_id = self.model.config.eos_token_id
         dev = self.device
@@ -105,6 +107,8 @@ class LiveInferForBenchmark:
         self.stream_end_prob_list = list()
         self.stream_end_score_sum = 0
         self.consecutive_n_frames = 0
+        self._frame_ready = {}
+        self._vit_keepalive = None
         self.forward_calls = 0              # LLM forwards issued (diagnostics of the chunked schedule)
         self.replayed_frames = 0
 
@@ -112,11 +116,32 @@ class LiveInferForBenchmark:
     @torch.no_grad()
     def input_video_stream(self, video_frames):
         """All frames of the video at once (uint8 [T,3,R,R]); queues (time, [frame_num_tokens, hidden]) per frame."""
-        pixel_values = self.image_processor.preprocess(video_frames, return_tensors='pt')['pixel_values']
-        pixel_values = pixel_values.to(self.device).to(self.torch_dtype)
-        for b0 in range(0, len(pixel_values), VIT_BATCH):
-            embeds = self.model.visual_embed(pixel_values[b0:b0 + VIT_BATCH]).split(self.frame_num_tokens)
-            self.frame_embeds_queue.extend(((r + b0) / self.frame_fps, f) for r, f in enumerate(embeds))
+        overlap = self.overlap_vision and self.device.type == 'cuda'
+        if not overlap:
+            pixel_values = self.image_processor.preprocess(video_frames, return_tensors='pt')['pixel_values']
+            pixel_values = pixel_values.to(self.device).to(self.torch_dtype)
+            for b0 in range(0, len(pixel_values), VIT_BATCH):
+                embeds = self.model.visual_embed(pixel_values[b0:b0 + VIT_BATCH]).split(self.frame_num_tokens)
+                self.frame_embeds_queue.extend(((r + b0) / self.frame_fps, f) for r, f in enumerate(embeds))
+            return
+        # The tower is MFMA-bound, the LLM steps (weight streaming, token-by-token decoding) are not: encode the frames on a
+        # side HIP stream so that batch i+1 of the tower overlaps the LLM work on batch i.  Every queued frame carries the
+        # event of its batch; the LLM stream waits on it right before the frame is consumed.  Results are unchanged.
+        if self._vit_stream is None:
+            self._vit_stream = torch.cuda.Stream(device=self.device)
+        main = torch.cuda.current_stream(self.device)
+        side = self._vit_stream
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            pixel_values = self.image_processor.preprocess(video_frames, return_tensors='pt')['pixel_values'].to(self.torch_dtype)
+            for b0 in range(0, len(pixel_values), VIT_BATCH):
+                embeds = self.model.visual_embed(pixel_values[b0:b0 + VIT_BATCH])
+                ev = torch.cuda.Event()
+                ev.record(side)
+                for r, f in enumerate(embeds.split(self.frame_num_tokens)):
+                    self._frame_ready[f.data_ptr()] = ev
+                    self.frame_embeds_queue.append(((r + b0) / self.frame_fps, f))
+            self._vit_keepalive = pixel_values          # freed (on the side stream's allocator pool) at the next reset
 
     def input_query_stream(self, conversation):
         for turn in conversation:
@@ -141,6 +166,13 @@ class LiveInferForBenchmark:
     def _forward_frames(self, frames):
         """One causal forward over `frames` (list of [frame_num_tokens, hidden]); returns per-frame
         (informative_score, relevance_score) and the KV length at the end of each frame."""
+        if self._frame_ready:
+            waited = set()
+            for f in frames:
+                ev = self._frame_ready.pop(f.data_ptr(), None)
+                if ev is not None and id(ev) not in waited:
+                    torch.cuda.current_stream(self.device).wait_event(ev)
+                    waited.add(id(ev))
         self.last_ids = self._prefix_ids_for_next_frame()
         prefix = self._embed(self.last_ids)
         P = prefix.shape[1]

@@ -27,7 +27,7 @@ if __name__ == '__main__':
                     gb = (N * K + M * K + M * (N // 2 if epi == 'swiglu' else N)) * 2 / 1e9
                     print(f'M={M:4d} {name:8s} N={N:6d} K={K:6d} {vn:10s} {ms*1e3:8.1f} us  {gb/ms*1e3:7.0f} GB/s  {2*M*N*K/ms/1e9:7.1f} TF', flush=True)
     if which in ('big', 'all'):
-        for M in (98, 196, 392, 784, 23328):
+        for M in (392, 784, 980, 1274, 23328):
             shapes = (LLM[:4] if M < 2000 else VIT)
             for name, N, K, epi in shapes:
                 for variant, vn in ((1, 'generic64'), (4, 'big')):

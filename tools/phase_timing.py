@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Wall-clock phase breakdown of one bench stream (sync after each phase) -- diagnostic only."""
-import sys, os, time
+import sys, os, time, random
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
 import torch, bench
 sys.argv = [sys.argv[0]] + sys.argv[1:]
@@ -9,7 +9,7 @@ dev = torch.device('cuda', 0)
 model, tok, cfg = bench.build(args, dev)
 frames = torch.randint(0, 256, (args.frames, 3, args.resolution, args.resolution), dtype=torch.uint8).to(dev)
 T = args.frames
-forced = [int(round((i + 1) * T / args.responses)) for i in range(args.responses)]
+forced = sorted(random.Random(0).sample(range(1, T + 1), args.responses))
 d = bench.make_driver(args, model, tok, 1.0, forced)
 gen_t = [0.0]
 orig = d._generate_response
