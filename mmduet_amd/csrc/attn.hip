@@ -21,6 +21,8 @@ struct AttnP {
     long long ldq, ldo, k_hs, k_ts, v_hs, v_ts, q_bs, kv_bs, o_bs;
     long long n_ctx;
     int S, nh, nkv, d, causal, splits, kv_per_split;
+    const StepState* dyn;   // graph-replayed decode: n_ctx / arena base / capacity are read from device memory
+    int layer;
     int v_tr;          // V stored transposed in 64-token blocks: (tok, e) at ((tok>>6)*d + e)*64 + (tok&63) inside the head region
     float scale_log2;
 };
@@ -261,9 +263,20 @@ __global__ __launch_bounds__(256, 2) void attn_gqa128_kernel(AttnP p) {
     const int G = p.nh / p.nkv, kvh = blockIdx.y;
     const int rows_total = p.S * G;
     const int row_base = blockIdx.x * (64 * RT) + wave * (16 * RT);
-    const long long n_tot = p.n_ctx + p.S;
-    const bf16_t* Kg = (const bf16_t*)p.K + kvh * p.k_hs;
-    const bf16_t* Vg = (const bf16_t*)p.V + kvh * p.v_hs;
+    long long n_ctx = p.n_ctx, k_hs = p.k_hs, v_hs = p.v_hs;
+    const bf16_t* Kb = (const bf16_t*)p.K; const bf16_t* Vb = (const bf16_t*)p.V;
+    int kv_per_split = p.kv_per_split;
+    if (p.dyn) {                                   // captured decode step: everything that changes between replays lives in *dyn
+        n_ctx = p.dyn->n_ctx;
+        const long long cap = p.dyn->cap, le = (long long)p.nkv * cap * D;
+        Kb = (const bf16_t*)p.dyn->K + p.layer * le; Vb = (const bf16_t*)p.dyn->V + p.layer * le;
+        k_hs = v_hs = cap * D;
+        const long long tiles = (n_ctx + p.S + 63) >> 6;
+        kv_per_split = (int)((tiles + gridDim.z - 1) / gridDim.z) * 64;
+    }
+    const long long n_tot = n_ctx + p.S;
+    const bf16_t* Kg = Kb + kvh * k_hs;
+    const bf16_t* Vg = Vb + kvh * v_hs;
 
     int my_row[RT], my_tok[RT], my_head[RT]; bool row_ok[RT]; long long my_limit[RT];
     bf16x8_t qf[RT][4];
@@ -273,7 +286,7 @@ __global__ __launch_bounds__(256, 2) void attn_gqa128_kernel(AttnP p) {
         row_ok[rt] = my_row[rt] < rows_total;
         my_tok[rt] = row_ok[rt] ? my_row[rt] / G : 0;
         my_head[rt] = kvh * G + (row_ok[rt] ? my_row[rt] % G : 0);
-        my_limit[rt] = !row_ok[rt] ? 0 : (p.causal ? p.n_ctx + my_tok[rt] + 1 : n_tot);
+        my_limit[rt] = !row_ok[rt] ? 0 : (p.causal ? n_ctx + my_tok[rt] + 1 : n_tot);
         const bf16_t* qrow = (const bf16_t*)p.q + (long long)my_tok[rt] * p.ldq + (long long)my_head[rt] * D;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -286,10 +299,10 @@ __global__ __launch_bounds__(256, 2) void attn_gqa128_kernel(AttnP p) {
     // key range of this block / split (multiples of 64 except at the very end)
     const int blk_first_row = blockIdx.x * (64 * RT);
     const int blk_last_row = min(blk_first_row + 64 * RT - 1, rows_total - 1);
-    const long long blk_limit = p.causal ? min(n_tot, p.n_ctx + (long long)(blk_last_row / G) + 1) : n_tot;
-    const long long blk_min_limit = p.causal ? p.n_ctx + (long long)(blk_first_row / G) + 1 : n_tot;   // keys below this are visible to every row
-    const long long kbeg = (long long)blockIdx.z * p.kv_per_split;
-    const long long kend = min(blk_limit, kbeg + p.kv_per_split);
+    const long long blk_limit = p.causal ? min(n_tot, n_ctx + (long long)(blk_last_row / G) + 1) : n_tot;
+    const long long blk_min_limit = p.causal ? n_ctx + (long long)(blk_first_row / G) + 1 : n_tot;   // keys below this are visible to every row
+    const long long kbeg = (long long)blockIdx.z * kv_per_split;
+    const long long kend = min(blk_limit, kbeg + kv_per_split);
 
     f32x4_t oacc[RT][8];
     float m_run[RT], l_run[RT];
@@ -461,14 +474,16 @@ static hipError_t launch_gqa128(AttnP& p, const AttnArgs& a, hipStream_t st) {
     const int blocks = qblocks * a.nkv;
     const int tiles = cdiv(n_tot, 64);
     int splits = 1;
-    if (blocks < 256 && a.ws) {
+    if (a.dyn) {
+        splits = a.dyn_splits;                                     // fixed grid under graph replay; empty splits write (m = -inf, l = 0)
+    } else if (blocks < 256 && a.ws) {
         splits = cdiv(320, blocks);
         int maxs = tiles / 2; if (maxs < 1) maxs = 1;              // >= 2 key tiles per split
         if (splits > maxs) splits = maxs;
         while (splits > 1 && (size_t)splits * a.nkv * rows_total * (128 + 2) * sizeof(float) > a.ws_bytes) --splits;
     }
     int per = cdiv(tiles, splits) * 64;
-    splits = cdiv(n_tot, per);
+    if (!a.dyn) splits = cdiv(n_tot, per);
     p.splits = splits; p.kv_per_split = per;
     const int nrows_all = a.nkv * rows_total;
     p.ws_o = a.ws;
@@ -699,7 +714,7 @@ hipError_t launch_attention(int dtype, const AttnArgs& a, hipStream_t st) {
     p.k_hs = a.k_hs; p.k_ts = a.k_ts; p.v_hs = a.v_hs; p.v_ts = a.v_ts;
     p.q_bs = a.q_bstride; p.kv_bs = a.kv_bstride; p.o_bs = a.o_bstride;
     p.n_ctx = a.n_ctx; p.S = a.S; p.nh = a.nh; p.nkv = a.nkv; p.d = a.d; p.causal = a.causal;
-    p.splits = 1; p.kv_per_split = 0; p.v_tr = a.v_transposed;
+    p.splits = 1; p.kv_per_split = 0; p.v_tr = a.v_transposed; p.dyn = a.dyn; p.layer = a.layer;
     p.scale_log2 = (1.0f / sqrtf((float)a.d)) * 1.4426950408889634f;
     bool can_mfma = dtype == MMD_BF16 && (a.d % 8) == 0 && a.d <= 128 && (a.ldq % 8) == 0 && (a.k_ts % 8) == 0 && (a.v_ts % 8) == 0 &&
                     (a.k_hs % 8) == 0 && (a.v_hs % 8) == 0 && (a.kv_bstride % 8) == 0 && (a.q_bstride % 8) == 0;

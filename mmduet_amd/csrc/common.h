@@ -76,6 +76,9 @@ static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 static inline size_t dtype_size(int dt) { return dt == MMD_F32 ? 4 : 2; }
 
+// device-resident state of a graph-captured decode step (updated by the last kernel of the graph)
+struct StepState { long long n_ctx; long long cap; void* K; void* V; int n_prev; int pad; };
+
 // ---- epilogues of the GEMM family ------------------------------------------------------------------------------
 enum { EPI_NONE = 0, EPI_GELU_TANH = 1, EPI_GELU_ERF = 2, EPI_RESID = 3, EPI_SWIGLU = 4 };
 enum { GEMM_AUTO = 0, GEMM_GENERIC = 1, GEMM_SKINNY = 2, GEMM_LARGE = 3, GEMM_BIG = 4 };
@@ -106,7 +109,8 @@ hipError_t launch_layernorm(int dtype, const void* x, const void* w, const void*
 hipError_t launch_slab_resid_rmsnorm(const float* slabs, int splits, int M, int H, const void* resid_in, void* h_out, const void* norm_w, float eps,
                                      void* xn_out, hipStream_t st);
 hipError_t launch_slab_rope_append(const float* slabs, int splits, const void* bias, int S, int nh, int nkv, int d, const float* inv_freq_dev,
-                                   int64_t pos0, void* q_out, void* Kc, void* Vc, int64_t cap, hipStream_t st);
+                                   int64_t pos0, void* q_out, void* Kc, void* Vc, int64_t cap, hipStream_t st, const StepState* dyn = nullptr, int layer = 0);
+hipError_t launch_advance_state(StepState* st_dev, const int64_t* tok_dev, int64_t* prev_dev, int prev_cap, int64_t eos, int use_penalty, hipStream_t st);
 hipError_t launch_add_rows(int dtype, void* x, const void* add, int M, int H, int period, hipStream_t st);   // x[m,:] += add[m % period,:]
 hipError_t launch_rope_append(int dtype, const void* qkv, int S, int nh, int nkv, int d, const float* inv_freq_dev, int64_t pos0, void* q_out,
                               void* Kc, void* Vc, int64_t cap, int v_transposed, hipStream_t st);
@@ -117,7 +121,7 @@ hipError_t launch_pool(int dtype, const void* x, void* y, int B, int grid, int H
 hipError_t launch_heads(int dtype, const void* hidden, int64_t ldh, const int32_t* rows_dev, int M, const void* W4, int H, float* out,
                         hipStream_t st);
 hipError_t launch_argmax_penalty(const float* logits, int V, const int64_t* prev_ids_dev, int n_prev, float penalty, int64_t* out_id,
-                                 hipStream_t st);
+                                 hipStream_t st, const StepState* dyn = nullptr);
 hipError_t launch_convert(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, hipStream_t st);
 hipError_t launch_copy_rows(int dtype, const void* src, int64_t lds_, void* dst, int64_t ldd, int rows, int cols, hipStream_t st);
 hipError_t launch_interleave16(int dtype, const void* a, const void* b, void* out, int rows, int cols, hipStream_t st);
@@ -138,5 +142,6 @@ struct AttnArgs {
     int batch; int64_t q_bstride, kv_bstride, o_bstride;   // ViT: batch of independent sequences (elements)
     float* ws; size_t ws_bytes;      // split-KV partials
     int variant;
+    const StepState* dyn; int layer; int dyn_splits;   // graph mode (attn_gqa128 only)
 };
 hipError_t launch_attention(int dtype, const AttnArgs& a, hipStream_t st);

@@ -66,6 +66,10 @@ struct mmd_ctx {
     // preprocess tables
     int pp_R = 0; int32_t* pp_coef = 0; int32_t* pp_bounds = 0; int pp_ksize = 0; uint8_t* pp_tmp = 0; size_t pp_tmp_bytes = 0;
     int last_vit_B = 0;
+    // graph-captured decode step (one per context; per-call state lives in *step_dev)
+    StepState* step_dev = nullptr; StepState* step_host = nullptr;
+    hipGraphExec_t dec_graph = nullptr; hipGraph_t dec_graph_src = nullptr;
+    float dec_pen = 0.f; int64_t dec_eos = 0; bool no_graph = false;
     bool no_fuse = false;              // MMDUET_NO_FUSE=1: keep the unfused launch schedule (A/B and parity cross-check)
     Prof prof;
 };
@@ -159,6 +163,10 @@ extern "C" int mmd_create(const mmd_config* cfg, int device, mmd_ctx** out) {
     c->vit_ipad = (int)round_up(cfg->vit_intermediate, 64);
     c->qkv_w = (cfg->num_heads + 2 * cfg->num_kv_heads) * cfg->head_dim;
     { const char* nf = getenv("MMDUET_NO_FUSE"); c->no_fuse = nf && nf[0] == '1'; }
+    // graph replay of the decode step is opt-in (MMDUET_GRAPH=1): measured on MI355X it is not faster than eager launches
+    // from this C++ loop (458 vs 480-500 ms for 128 tokens) -- the step is bound by the ~1.5 us GPU-side kernel boundaries,
+    // which a graph does not remove, not by host launch latency.
+    { const char* ng = getenv("MMDUET_GRAPH"); c->no_graph = !(ng && ng[0] == '1'); }
     *out = c;
     return MMD_OK;
 }
@@ -173,6 +181,9 @@ extern "C" void mmd_destroy(mmd_ctx* c) {
     if (c->heads_host) hipHostFree(c->heads_host);
     if (c->rows_host) hipHostFree(c->rows_host);
     if (c->tok_host) hipHostFree(c->tok_host);
+    if (c->step_host) hipHostFree(c->step_host);
+    if (c->dec_graph) hipGraphExecDestroy(c->dec_graph);
+    if (c->dec_graph_src) hipGraphDestroy(c->dec_graph_src);
     hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -420,6 +431,8 @@ static int alloc_workspaces(mmd_ctx* c) {
     HIPCHK(c, hipHostMalloc((void**)&c->heads_host, (size_t)S * 4 * sizeof(float)));
     HIPCHK(c, hipHostMalloc((void**)&c->rows_host, (size_t)S * sizeof(int32_t)));
     HIPCHK(c, hipHostMalloc((void**)&c->tok_host, 64));
+    HIPCHK(c, hipHostMalloc((void**)&c->step_host, sizeof(StepState)));
+    rc = dev_alloc(c, (void**)&c->step_dev, sizeof(StepState)); if (rc) return rc;
     return MMD_OK;
 }
 
@@ -586,13 +599,16 @@ static int kv_reserve(mmd_ctx* c, mmd_stream* s, int64_t need) {
     return MMD_OK;
 }
 
-extern "C" int mmd_llm_step(mmd_ctx* c, mmd_stream* s, const void* embeds, int S, void* hidden_out) {
+// dyn != nullptr: the step is being captured into the decode graph -- position and arena come from device state, no
+// host-side allocation / bookkeeping / event recording may happen here.
+static int llm_step_impl(mmd_ctx* c, mmd_stream* s, const void* embeds, int S, void* hidden_out, const StepState* dyn) {
     NEED_FINAL(c);
     if (!s || s->ctx != c) FAIL(c, MMD_EINVAL, "stream does not belong to this context");
     if (S <= 0) return MMD_OK;
     const mmd_config& g = c->cfg; const int dt = g.dtype; const size_t e = es(c); hipStream_t st = c->stream;
     if (S > g.max_step_tokens) FAIL(c, MMD_ERANGE, "step of %d tokens exceeds max_step_tokens %d", S, g.max_step_tokens);
-    int rc = kv_reserve(c, s, s->len + S); if (rc) return rc;
+    int rc = MMD_OK;
+    if (!dyn) { rc = kv_reserve(c, s, s->len + S); if (rc) return rc; }
     const int H = g.hidden_size, I = g.intermediate_size, nh = g.num_heads, nkv = g.num_kv_heads, d = g.head_dim;
     const int64_t n = s->len;
     HIPCHK(c, hipMemcpyAsync(c->l_h, embeds, (size_t)S * H * e, hipMemcpyDeviceToDevice, st));
@@ -618,6 +634,7 @@ extern "C" int mmd_llm_step(mmd_ctx* c, mmd_stream* s, const void* embeds, int S
         HIPCHK(c, launch_gemm(dt, a, st, nullptr));
         return MMD_OK;
     };
+    if (dyn && !fused) FAIL(c, MMD_EINVAL, "graph decode needs the fused bf16 schedule");
     if (fused) { ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * S * H * e, 0); HIPCHK(c, launch_rmsnorm(dt, c->l_h, c->L[0].ln1, c->l_xn, S, H, g.rms_norm_eps, st)); }
 
     for (int i = 0; i < g.num_layers; ++i) {
@@ -628,7 +645,7 @@ extern "C" int mmd_llm_step(mmd_ctx* c, mmd_stream* s, const void* embeds, int S
         if (fused) {
             rc = slab_gemm(c->l_xn, H, L.wqkv_p, c->qkv_w, H, &splits); if (rc) return rc;
             ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * S * c->qkv_w * e, 0);
-            HIPCHK(c, launch_slab_rope_append(c->splitk_ws, splits, L.bqkv, S, nh, nkv, d, c->inv_freq, n, c->l_q, Kl, Vl, s->cap, st));
+            HIPCHK(c, launch_slab_rope_append(c->splitk_ws, splits, L.bqkv, S, nh, nkv, d, c->inv_freq, n, c->l_q, Kl, Vl, s->cap, st, dyn, i));
         } else {
             { ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * S * H * e, 0); HIPCHK(c, launch_rmsnorm(dt, c->l_h, L.ln1, c->l_xn, S, H, g.rms_norm_eps, st)); }
             rc = gemm(c, c->l_xn, H, L.wqkv, H, L.bqkv, nullptr, 0, c->l_qkv, c->qkv_w, S, c->qkv_w, H, EPI_NONE, 0, GEMM_AUTO, L.wqkv_p); if (rc) return rc;
@@ -640,6 +657,7 @@ extern "C" int mmd_llm_step(mmd_ctx* c, mmd_stream* s, const void* embeds, int S
             a.q = c->l_q; a.ldq = (int64_t)nh * d; a.K = Kl; a.V = Vl; a.k_hs = s->cap * d; a.k_ts = d; a.v_hs = s->cap * d; a.v_ts = d;
             a.out = c->l_attn; a.ldo = (int64_t)nh * d; a.S = S; a.nh = nh; a.nkv = nkv; a.d = d; a.n_ctx = n; a.causal = 1; a.v_transposed = 1;
             a.batch = 1; a.ws = c->attn_ws; a.ws_bytes = c->attn_bytes; a.variant = 0;
+            a.dyn = dyn; a.layer = i; a.dyn_splits = 64;
             double kvb = 2.0 * (double)(n + S) * nkv * d * e;
             ProfScope ps(c, MMD_K_ATTN_LLM, kvb + 2.0 * S * nh * d * e, 4.0 * S * (double)(n + S) * nh * d);
             HIPCHK(c, launch_attention(dt, a, st));
@@ -663,8 +681,12 @@ extern "C" int mmd_llm_step(mmd_ctx* c, mmd_stream* s, const void* embeds, int S
     }
     if (!fused) { ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * S * H * e, 0); HIPCHK(c, launch_rmsnorm(dt, c->l_h, c->fnorm, c->l_hid, S, H, g.rms_norm_eps, st)); }
     if (hidden_out) HIPCHK(c, hipMemcpyAsync(hidden_out, c->l_hid, (size_t)S * H * e, hipMemcpyDeviceToDevice, st));
-    s->len = n + S;
+    if (!dyn) s->len = n + S;
     return MMD_OK;
+}
+
+extern "C" int mmd_llm_step(mmd_ctx* c, mmd_stream* s, const void* embeds, int S, void* hidden_out) {
+    return llm_step_impl(c, s, embeds, S, hidden_out, nullptr);
 }
 
 extern "C" int mmd_video_heads(mmd_ctx* c, const void* hidden, int M, float* out) {
@@ -696,6 +718,18 @@ extern "C" int mmd_frame_step(mmd_ctx* c, mmd_stream* s, const void* embeds, int
     return MMD_OK;
 }
 
+// one decode step (feed the previously sampled token, sample the next) enqueued on the stream; `dyn` selects the
+// graph-capturable form that reads position / arena / penalty-list length from device state
+static int decode_step_enqueue(mmd_ctx* c, mmd_stream* s, bool pen, float rep_penalty, int np, int64_t eos_id, const StepState* dyn) {
+    const mmd_config& g = c->cfg; hipStream_t st = c->stream; const int H = g.hidden_size;
+    HIPCHK(c, launch_embed(g.dtype, c->embed, c->tok_dev, 1, H, g.vocab_size, c->gen_embed, st));
+    int rc = llm_step_impl(c, s, c->gen_embed, 1, nullptr, dyn); if (rc) return rc;
+    rc = gemm(c, c->l_hid, H, c->lm_head, H, nullptr, nullptr, 0, c->logits_ws, g.vocab_size, 1, g.vocab_size, H, EPI_NONE, 1, GEMM_AUTO, c->lm_head_p); if (rc) return rc;
+    HIPCHK(c, launch_argmax_penalty(c->logits_ws, g.vocab_size, c->prev_dev, pen ? np : 0, pen ? rep_penalty : 1.f, c->tok_dev, st, dyn));
+    if (dyn) HIPCHK(c, launch_advance_state(c->step_dev, c->tok_dev, c->prev_dev, c->prev_cap, eos_id, pen ? 1 : 0, st));
+    return MMD_OK;
+}
+
 extern "C" int mmd_greedy_generate(mmd_ctx* c, mmd_stream* s, const void* prompt_embeds, int S, int64_t eos_id, float rep_penalty,
                                    int64_t* prev_ids_host, int* n_prev, int prev_cap, int64_t* out_ids_host, int max_new, int* n_out) {
     NEED_FINAL(c);
@@ -705,27 +739,72 @@ extern "C" int mmd_greedy_generate(mmd_ctx* c, mmd_stream* s, const void* prompt
     int np = (pen && n_prev) ? *n_prev : 0;
     if (np > c->prev_cap) FAIL(c, MMD_ERANGE, "repetition-penalty list too long");
     if (np > 0) HIPCHK(c, hipMemcpyAsync(c->prev_dev, prev_ids_host, sizeof(int64_t) * np, hipMemcpyHostToDevice, st));
-    const void* x = prompt_embeds; int xs = S;
     int produced = 0;
-    for (int i = 0; i < max_new; ++i) {
-        int rc = mmd_llm_step(c, s, x, xs, nullptr); if (rc) return rc;
-        const void* last = (const char*)c->l_hid + (size_t)(xs - 1) * H * e;
-        rc = gemm(c, last, H, c->lm_head, H, nullptr, nullptr, 0, c->logits_ws, g.vocab_size, 1, g.vocab_size, H, EPI_NONE, 1, GEMM_AUTO, c->lm_head_p); if (rc) return rc;
-        { ProfScope ps(c, MMD_K_OTHER, 0, 0);
-          HIPCHK(c, launch_argmax_penalty(c->logits_ws, g.vocab_size, c->prev_dev, pen ? np : 0, pen ? rep_penalty : 1.f, c->tok_dev, st)); }
+    auto read_token = [&](int64_t* tok) -> int {
         HIPCHK(c, hipMemcpyAsync(c->tok_host, c->tok_dev, sizeof(int64_t), hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipStreamSynchronize(st));
-        int64_t tok = c->tok_host[0];
+        *tok = c->tok_host[0];
+        return MMD_OK;
+    };
+    // step 0: the prompt (eager)
+    int rc = llm_step_impl(c, s, prompt_embeds, S, nullptr, nullptr); if (rc) return rc;
+    {
+        const void* last = (const char*)c->l_hid + (size_t)(S - 1) * H * e;
+        rc = gemm(c, last, H, c->lm_head, H, nullptr, nullptr, 0, c->logits_ws, g.vocab_size, 1, g.vocab_size, H, EPI_NONE, 1, GEMM_AUTO, c->lm_head_p); if (rc) return rc;
+        ProfScope ps(c, MMD_K_OTHER, 0, 0);
+        HIPCHK(c, launch_argmax_penalty(c->logits_ws, g.vocab_size, c->prev_dev, pen ? np : 0, pen ? rep_penalty : 1.f, c->tok_dev, st, nullptr));
+    }
+    int64_t tok = 0;
+    rc = read_token(&tok); if (rc) return rc;
+    out_ids_host[produced++] = tok;
+    bool stop = tok == eos_id;
+    if (!stop && pen) {
+        if (np < c->prev_cap) HIPCHK(c, hipMemcpyAsync(c->prev_dev + np, c->tok_dev, sizeof(int64_t), hipMemcpyDeviceToDevice, st));
+        if (prev_ids_host && np < prev_cap) prev_ids_host[np] = tok;
+        ++np;
+    }
+    // steps 1..: one token in, one token out.  bf16 + fused schedule: replay a captured hipGraph of the whole step
+    // (~255 kernels) instead of launching them one by one -- the decode step is made of 5-50 us kernels and is otherwise
+    // paced by host launch latency.
+    const bool can_graph = !stop && max_new > 1 && !c->no_graph && !c->no_fuse && c->prof.on == 0 && g.dtype == MMD_BF16 && c->L[0].wqkv_p != nullptr &&
+                           g.hidden_size <= 4096 && g.head_dim == 128;     // head_dim 128: the attention kernel that reads *dyn
+    if (can_graph) {
+        rc = kv_reserve(c, s, s->len + max_new + 1); if (rc) return rc;
+        StepState* hs = c->step_host;
+        hs->n_ctx = s->len; hs->cap = s->cap; hs->K = s->K; hs->V = s->V; hs->n_prev = np; hs->pad = 0;
+        HIPCHK(c, hipMemcpyAsync(c->step_dev, hs, sizeof(StepState), hipMemcpyHostToDevice, st));
+        if (!c->dec_graph || c->dec_pen != (pen ? rep_penalty : 0.f) || c->dec_eos != eos_id) {
+            if (c->dec_graph) { hipGraphExecDestroy(c->dec_graph); c->dec_graph = nullptr; }
+            if (c->dec_graph_src) { hipGraphDestroy(c->dec_graph_src); c->dec_graph_src = nullptr; }
+            HIPCHK(c, hipStreamSynchronize(st));
+            // capture on the context's own stream (the legacy null stream -- torch's default -- cannot be captured);
+            // the instantiated graph is then launched on whatever stream the caller bound
+            c->stream = c->own_stream;
+            hipError_t be = hipStreamBeginCapture(c->own_stream, hipStreamCaptureModeThreadLocal);
+            if (be != hipSuccess) { c->stream = st; HIPCHK(c, be); }
+            rc = decode_step_enqueue(c, s, pen, rep_penalty, np, eos_id, c->step_dev);
+            hipError_t ce = hipStreamEndCapture(c->own_stream, &c->dec_graph_src);
+            c->stream = st;
+            if (rc) { if (c->dec_graph_src) { hipGraphDestroy(c->dec_graph_src); c->dec_graph_src = nullptr; } return rc; }
+            HIPCHK(c, ce);
+            HIPCHK(c, hipGraphInstantiate(&c->dec_graph, c->dec_graph_src, nullptr, nullptr, 0));
+            c->dec_pen = pen ? rep_penalty : 0.f; c->dec_eos = eos_id;
+        }
+    }
+    for (int i = 1; i < max_new && !stop; ++i) {
+        if (can_graph) {
+            HIPCHK(c, hipGraphLaunch(c->dec_graph, st));
+            s->len += 1;
+        } else {
+            rc = decode_step_enqueue(c, s, pen, rep_penalty, np, eos_id, nullptr); if (rc) return rc;
+        }
+        rc = read_token(&tok); if (rc) return rc;
         out_ids_host[produced++] = tok;
         if (tok == eos_id) break;
         if (pen) {
-            if (np < c->prev_cap) HIPCHK(c, hipMemcpyAsync(c->prev_dev + np, c->tok_dev, sizeof(int64_t), hipMemcpyDeviceToDevice, st));
+            if (!can_graph && np < c->prev_cap) HIPCHK(c, hipMemcpyAsync(c->prev_dev + np, c->tok_dev, sizeof(int64_t), hipMemcpyDeviceToDevice, st));
             if (prev_ids_host && np < prev_cap) prev_ids_host[np] = tok;
             ++np;
-        }
-        if (i + 1 < max_new) {
-            HIPCHK(c, launch_embed(g.dtype, c->embed, c->tok_dev, 1, H, g.vocab_size, c->gen_embed, st));
-            x = c->gen_embed; xs = 1;
         }
     }
     *n_out = produced;

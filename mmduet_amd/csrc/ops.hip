@@ -141,7 +141,12 @@ hipError_t launch_slab_resid_rmsnorm(const float* slabs, int splits, int M, int 
 
 __global__ void slab_rope_append_kernel(const float* __restrict__ slabs, int splits, const bf16_t* __restrict__ bias, int S, int nh, int nkv, int d,
                                         const float* __restrict__ inv_freq_tab, long long pos0, bf16_t* __restrict__ q_out, bf16_t* __restrict__ Kc,
-                                        bf16_t* __restrict__ Vc, long long cap) {
+                                        bf16_t* __restrict__ Vc, long long cap, const StepState* __restrict__ dyn, int layer) {
+    if (dyn) {                                     // graph replay: position / arena come from device state
+        pos0 = dyn->n_ctx; cap = dyn->cap;
+        const long long le = (long long)nkv * cap * d;
+        Kc = (bf16_t*)dyn->K + layer * le; Vc = (bf16_t*)dyn->V + layer * le;
+    }
     const int s = blockIdx.x, head = blockIdx.y, half = d >> 1;
     const int row_w = (nh + 2 * nkv) * d;
     const long long MN = (long long)S * row_w;
@@ -174,10 +179,10 @@ __global__ void slab_rope_append_kernel(const float* __restrict__ slabs, int spl
     }
 }
 hipError_t launch_slab_rope_append(const float* slabs, int splits, const void* bias, int S, int nh, int nkv, int d, const float* inv_freq_dev,
-                                   int64_t pos0, void* q_out, void* Kc, void* Vc, int64_t cap, hipStream_t st) {
+                                   int64_t pos0, void* q_out, void* Kc, void* Vc, int64_t cap, hipStream_t st, const StepState* dyn, int layer) {
     if (S <= 0) return hipSuccess;
     hipLaunchKernelGGL(slab_rope_append_kernel, dim3(S, nh + 2 * nkv), dim3(64), 0, st, slabs, splits, (const bf16_t*)bias, S, nh, nkv, d, inv_freq_dev,
-                       (long long)pos0, (bf16_t*)q_out, (bf16_t*)Kc, (bf16_t*)Vc, (long long)cap);
+                       (long long)pos0, (bf16_t*)q_out, (bf16_t*)Kc, (bf16_t*)Vc, (long long)cap, dyn, layer);
     return hipGetLastError();
 }
 
@@ -384,8 +389,9 @@ hipError_t launch_heads(int dtype, const void* hidden, int64_t ldh, const int32_
 // Single block; V up to a few 100k.
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void argmax_penalty_kernel(const float* __restrict__ logits, int V, const int64_t* __restrict__ prev, int n_prev, float penalty,
-                                      int64_t* __restrict__ out_id) {
+                                      int64_t* __restrict__ out_id, const StepState* __restrict__ dyn) {
     __shared__ float sv[16]; __shared__ int si[16];
+    if (dyn && penalty != 1.f) n_prev = dyn->n_prev;
     float best = -INFINITY; int bi = 0x7fffffff;
     for (int i = threadIdx.x; i < V; i += blockDim.x) {
         float v = logits[i];
@@ -409,8 +415,21 @@ __global__ void argmax_penalty_kernel(const float* __restrict__ logits, int V, c
         *out_id = bi;
     }
 }
-hipError_t launch_argmax_penalty(const float* logits, int V, const int64_t* prev_ids_dev, int n_prev, float penalty, int64_t* out_id, hipStream_t st) {
-    hipLaunchKernelGGL(argmax_penalty_kernel, dim3(1), dim3(1024), 0, st, logits, V, prev_ids_dev, n_prev, penalty, out_id);
+hipError_t launch_argmax_penalty(const float* logits, int V, const int64_t* prev_ids_dev, int n_prev, float penalty, int64_t* out_id, hipStream_t st,
+                                 const StepState* dyn) {
+    hipLaunchKernelGGL(argmax_penalty_kernel, dim3(1), dim3(1024), 0, st, logits, V, prev_ids_dev, n_prev, penalty, out_id, dyn);
+    return hipGetLastError();
+}
+
+// last node of the captured decode step: append the sampled token to the penalty list (unless EOS) and advance the position
+__global__ void advance_state_kernel(StepState* st, const int64_t* __restrict__ tok, int64_t* __restrict__ prev, int prev_cap, long long eos, int use_penalty) {
+    if (threadIdx.x != 0) return;
+    const long long t = *tok;
+    if (use_penalty && t != eos && st->n_prev < prev_cap) { prev[st->n_prev] = t; st->n_prev += 1; }
+    st->n_ctx += 1;
+}
+hipError_t launch_advance_state(StepState* st_dev, const int64_t* tok_dev, int64_t* prev_dev, int prev_cap, int64_t eos, int use_penalty, hipStream_t st) {
+    hipLaunchKernelGGL(advance_state_kernel, dim3(1), dim3(64), 0, st, st_dev, tok_dev, prev_dev, prev_cap, (long long)eos, use_penalty);
     return hipGetLastError();
 }
 

@@ -81,6 +81,34 @@ def test_chunked_forward_equals_per_frame_forward(true_shape):
     assert torch.equal(sc_a, sc_b)
 
 
+@pytest.mark.parametrize('penalty', [None, 1.3])
+def test_graph_replayed_decode_equals_call_loop(true_shape, penalty):
+    """mmd_greedy_generate replays a captured hipGraph per token (position / arena / penalty list in device state);
+    it must produce the tokens of the plain call-by-call loop, leave the same KV length, and be reusable across
+    streams (different arenas) and contexts lengths."""
+    from mmduet_amd.modeling_live import fast_greedy_generate
+    m, om, cfg = true_shape
+    g = torch.Generator().manual_seed(7)
+    for ctx_len in (30, 700):
+        ctx = (torch.randn(1, ctx_len, 3584, generator=g) * 0.5).to(torch.bfloat16).cuda()
+        prompt = (torch.randn(1, 13, 3584, generator=g) * 0.5).to(torch.bfloat16).cuda()
+        res = []
+        for loop in (False, True):
+            base = m(inputs_embeds=ctx).past_key_values                   # a fresh arena each time
+            out = torch.zeros(1, 12, dtype=torch.long, device='cuda'); seen = [5, 9]
+            m.python_generate_loop = loop
+            try:
+                ids, cache, seen = fast_greedy_generate(model=m, inputs_embeds=prompt, past_key_values=base, eos_token_id=-1,
+                                                        inplace_output_ids=out, repetition_penalty=penalty, generated_token_ids=seen)
+            finally:
+                m.python_generate_loop = False
+            nxt = m(inputs_embeds=prompt[:, :3], past_key_values=cache)   # the context left behind is usable and identical
+            res.append((ids[0].tolist(), list(seen), len(cache), nxt.informative_logits[0, -1].tolist()))
+        assert res[0][0] == res[1][0], (res[0][0], res[1][0])
+        assert res[0][1] == res[1][1] and res[0][2] == res[1][2] == ctx_len + 13 + 11
+        assert res[0][3] == pytest.approx(res[1][3], abs=2e-2)
+
+
 def test_fused_and_unfused_schedules_agree(true_shape, monkeypatch):
     """The fused slab consumers (reduce+RoPE+append, reduce+residual+RMSNorm) keep the unfused rounding points."""
     import subprocess, sys, os, json
