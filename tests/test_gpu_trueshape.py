@@ -82,12 +82,19 @@ def test_chunked_forward_equals_per_frame_forward(true_shape):
 
 
 @pytest.mark.parametrize('penalty', [None, 1.3])
-def test_graph_replayed_decode_equals_call_loop(true_shape, penalty):
+def test_graph_replayed_decode_equals_call_loop(penalty, monkeypatch):
     """mmd_greedy_generate replays a captured hipGraph per token (position / arena / penalty list in device state);
     it must produce the tokens of the plain call-by-call loop, leave the same KV length, and be reusable across
     streams (different arenas) and contexts lengths."""
-    from mmduet_amd.modeling_live import fast_greedy_generate
-    m, om, cfg = true_shape
+    from mmduet_amd.modeling_live import fast_greedy_generate, VideoHeadLiveLlavaQwenForCausalLM
+    from mmduet_amd.configuration_live import VideoHeadLiveLlavaQwenConfig
+    monkeypatch.setenv('MMDUET_GRAPH', '1')            # read when the native context is created
+    ocfg = O.OracleConfig(vocab_size=2048, num_hidden_layers=2, vit_layers=1)
+    w = O.random_weights(ocfg, seed=3, dtype=torch.bfloat16, scale='unit')
+    pcfg = VideoHeadLiveLlavaQwenConfig(vocab_size=2048, num_hidden_layers=2, vit_num_hidden_layers=2, vit_layers_removed=1,
+                                        frame_num_tokens=49, frame_resolution=384, v_placeholder='<image>')
+    m = VideoHeadLiveLlavaQwenForCausalLM(pcfg, torch_dtype=torch.bfloat16, max_vit_batch=1, max_step_tokens=1024, kv_initial_tokens=1024)
+    m.load_state_dict(w)
     g = torch.Generator().manual_seed(7)
     for ctx_len in (30, 700):
         ctx = (torch.randn(1, ctx_len, 3584, generator=g) * 0.5).to(torch.bfloat16).cuda()
