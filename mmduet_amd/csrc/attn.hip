@@ -476,6 +476,9 @@ static hipError_t launch_gqa128(AttnP& p, const AttnArgs& a, hipStream_t st) {
     int splits = 1;
     if (a.dyn) {
         splits = a.dyn_splits;                                     // fixed grid under graph replay; empty splits write (m = -inf, l = 0)
+    } else if (rows_total <= 16 && a.ws) {
+        splits = 64;                                               // decode: same key ranges as the graph-replayed form -> identical bits
+        if (splits > tiles) splits = tiles;
     } else if (blocks < 256 && a.ws) {
         splits = cdiv(320, blocks);
         int maxs = tiles / 2; if (maxs < 1) maxs = 1;              // >= 2 key tiles per split
