@@ -569,7 +569,13 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(GemmP p, int KT) {
         const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    const int m0 = (bid / nbx) * BM, n0 = (bid % nbx) * BN;
+    // tile order inside an XCD's run: sweep the dimension whose operand is SMALLER fastest, so the larger operand's panel
+    // is fetched from HBM once and the smaller one is re-read from L2 / Infinity Cache.  ViT (M >> N): n fastest, the X
+    // panel stays put; LLM chunks (N >> M, W = 270 MB > 256 MB Infinity Cache): m fastest, every W panel is streamed once
+    // (measured FETCH_SIZE for gate_up at M = 980: 2.1 GB with n-fastest order = 8 x the weights).
+    int mt, nt;
+    if (p.N > p.M) { nt = bid / nby; mt = bid % nby; } else { mt = bid / nbx; nt = bid % nbx; }
+    const int m0 = mt * BM, n0 = nt * BN;
     const bf16_t* X = (const bf16_t*)p.X;
     const bf16_t* Wp = (const bf16_t*)p.W;
     const int nsteps = p.K / BK;
@@ -603,11 +609,14 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(GemmP p, int KT) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0, 0, 0, 0};
 
-    stage(0, 0);
+    // optional split-K over grid.z (medium M with few tiles: fills the CUs; fp32 slabs reduced by splitk_reduce_kernel)
+    const int zsteps = (nsteps + gridDim.z - 1) / gridDim.z;
+    const int t0 = blockIdx.z * zsteps, t1 = min(nsteps, t0 + zsteps);
+    if (t0 < t1) stage(0, t0);
     int cur = 0;
-    for (int t = 0; t < nsteps; ++t) {
+    for (int t = t0; t < t1; ++t) {
         __syncthreads();                                     // (compiler drains the DMA queue here: vmcnt(0))
-        if (t + 1 < nsteps) stage(cur ^ 1, t + 1);
+        if (t + 1 < t1) stage(cur ^ 1, t + 1);
         const bf16_t* xs = lds + cur * (XE + WE);
         const bf16_t* ws = xs + XE;
 #pragma unroll
@@ -629,6 +638,18 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(GemmP p, int KT) {
         cur ^= 1;
     }
 
+    if (gridDim.z > 1) {
+        float* ws = p.ws + (long long)blockIdx.z * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm + i * 16 + lr;
+            if (m < p.M) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) *reinterpret_cast<f32x4_t*>(ws + (long long)m * p.N + n0 + wn + j * 16 + lq * 4) = acc[i][j];
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + wm + i * 16 + lr;
@@ -644,7 +665,13 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(GemmP p, int KT) {
 
 template <int BN>
 static void launch_big(const GemmP& p, const GemmArgs& a, hipStream_t st) {
-    dim3 grid(a.N / BN, cdiv(a.M, 128));
+    const int tiles = (a.N / BN) * cdiv(a.M, 128);
+    int splits = 1;
+    if (tiles < 320 && a.K >= 8192 && a.epi != EPI_SWIGLU && a.splitk_ws) {      // long K, under one block per CU (down_proj): split K
+        splits = 3;                                                                // (measured: splitting K = 3584 GEMMs costs more than it fills)
+        while (splits > 1 && (size_t)splits * a.M * a.N * sizeof(float) > a.splitk_ws_bytes) --splits;
+    }
+    dim3 grid(a.N / BN, cdiv(a.M, 128), splits);
     const int KT = a.K >> 5;
     switch (a.epi) {
         case EPI_GELU_TANH: hipLaunchKernelGGL((gemm_big_kernel<BN, EPI_GELU_TANH>), grid, dim3(256), 0, st, p, KT); break;
@@ -652,6 +679,10 @@ static void launch_big(const GemmP& p, const GemmArgs& a, hipStream_t st) {
         case EPI_RESID: hipLaunchKernelGGL((gemm_big_kernel<BN, EPI_RESID>), grid, dim3(256), 0, st, p, KT); break;
         case EPI_SWIGLU: hipLaunchKernelGGL((gemm_big_kernel<BN, EPI_SWIGLU>), grid, dim3(256), 0, st, p, KT); break;
         default: hipLaunchKernelGGL((gemm_big_kernel<BN, EPI_NONE>), grid, dim3(256), 0, st, p, KT); break;
+    }
+    if (splits > 1) {
+        long long work = (long long)a.M * ((a.N + 3) / 4);
+        hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), dim3(cdiv(work, 256)), dim3(256), 0, st, p, splits);
     }
 }
 
