@@ -196,6 +196,15 @@ def main():
             else:
                 ach = p['bytes'] / p['launches'] / (avg_ms * 1e-3) / 1e9
                 roof = dict(bound='hbm', kernel=dom, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(ach / HBM_PEAK_GBS, 4), traffic=None)
+            # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
+            # runs of this same workload; gfx950 FETCH_SIZE correction applied) -- not re-measured here
+            try:
+                tr = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json'))).get(dom)
+                if tr:
+                    roof['traffic'] = round(tr['hbm_bytes_per_launch'])
+                    roof['traffic_source'] = 'profiles/r01_pmc_traffic.json'
+            except Exception:
+                pass
             roof['avg_launch_us'] = round(avg_ms * 1e3, 2)
             roof['launches'] = int(p['launches'])
             roof['per_class_ms_untimed_pass'] = {k: round(v['ms'], 1) for k, v in prof_all.items()}
