@@ -286,6 +286,16 @@ static int make_packed(mmd_ctx* c, const void* W, int N, int K, void** out) {
     HIPCHK(c, launch_pack_w(W, K, N, K, *out, c->stream));
     return MMD_OK;
 }
+// pack and, when every GEMM regime can run from the packed copy alone (N % 64 == 0 and K % 64 == 0: gemv16 / skinny / big
+// kernels), drop the row-major original: one copy of the weights in HBM (15.8 GB instead of 31 GB for the 7B model)
+static int pack_and_release(mmd_ctx* c, void** W, int N, int K, void** out) {
+    int rc = make_packed(c, *W, N, K, out); if (rc) return rc;
+    if (*out && (N % 64) == 0 && (K % 64) == 0) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        dev_free(c, *W); *W = nullptr;
+    }
+    return MMD_OK;
+}
 
 extern "C" int mmd_finalize_weights(mmd_ctx* c) {
     if (!c) return MMD_EINVAL;
@@ -329,10 +339,10 @@ extern "C" int mmd_finalize_weights(mmd_ctx* c) {
         HIPCHK(c, launch_interleave16(dt, wg.p, wu.p, L.wgu, I, H, st));
         if (Ipad != I) FAIL(c, MMD_EINVAL, "intermediate_size must be a multiple of 16 (got %d)", I);
         { TAKE(t, p + "mlp.down_proj.weight", {H, I}); L.wdown = t.p; }
-        rc = make_packed(c, L.wqkv, c->qkv_w, H, &L.wqkv_p); if (rc) return rc;
-        rc = make_packed(c, L.wo, H, nh * d, &L.wo_p); if (rc) return rc;
-        rc = make_packed(c, L.wgu, 2 * I, H, &L.wgu_p); if (rc) return rc;
-        rc = make_packed(c, L.wdown, H, I, &L.wdown_p); if (rc) return rc;
+        rc = pack_and_release(c, &L.wqkv, c->qkv_w, H, &L.wqkv_p); if (rc) return rc;
+        rc = pack_and_release(c, &L.wo, H, nh * d, &L.wo_p); if (rc) return rc;
+        rc = pack_and_release(c, &L.wgu, 2 * I, H, &L.wgu_p); if (rc) return rc;
+        rc = pack_and_release(c, &L.wdown, H, I, &L.wdown_p); if (rc) return rc;
         HIPCHK(c, hipStreamSynchronize(st));
         dev_free(c, wq.p); dev_free(c, wk.p); dev_free(c, wv.p); dev_free(c, bq.p); dev_free(c, bk.p); dev_free(c, bv.p); dev_free(c, wg.p); dev_free(c, wu.p);
     }
@@ -372,10 +382,10 @@ extern "C" int mmd_finalize_weights(mmd_ctx* c) {
         HIPCHK(c, hipMemcpyAsync(L.w1, w1.p, (size_t)CI * C * e, hipMemcpyDeviceToDevice, st));
         HIPCHK(c, hipMemcpyAsync(L.b1, b1.p, (size_t)CI * e, hipMemcpyDeviceToDevice, st));
         HIPCHK(c, launch_pad_cols(dt, w2.p, C, CI, L.w2, c->vit_ipad, st));
-        rc = make_packed(c, L.wqkv, 3 * C, C, &L.wqkv_p); if (rc) return rc;
-        rc = make_packed(c, L.wo, C, C, &L.wo_p); if (rc) return rc;
-        rc = make_packed(c, L.w1, c->vit_ipad, C, &L.w1_p); if (rc) return rc;
-        rc = make_packed(c, L.w2, C, c->vit_ipad, &L.w2_p); if (rc) return rc;
+        rc = pack_and_release(c, &L.wqkv, 3 * C, C, &L.wqkv_p); if (rc) return rc;
+        rc = pack_and_release(c, &L.wo, C, C, &L.wo_p); if (rc) return rc;
+        rc = pack_and_release(c, &L.w1, c->vit_ipad, C, &L.w1_p); if (rc) return rc;
+        rc = pack_and_release(c, &L.w2, C, c->vit_ipad, &L.w2_p); if (rc) return rc;
         HIPCHK(c, hipStreamSynchronize(st));
         dev_free(c, wq.p); dev_free(c, wk.p); dev_free(c, wv.p); dev_free(c, bq.p); dev_free(c, bk.p); dev_free(c, bv.p);
         dev_free(c, w1.p); dev_free(c, b1.p); dev_free(c, w2.p);
