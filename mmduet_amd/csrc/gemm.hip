@@ -686,6 +686,175 @@ static void launch_big(const GemmP& p, const GemmArgs& a, hipStream_t st) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// gemm_big256_kernel: 256 x 256 block tile, 8 waves (2 x 4, wave tile 128 x 64), BK = 64, two 64 KB LDS stages (128 KB).
+// Per MFMA the 256^2 tile needs half the DMA instructions and 25 % fewer LDS fragment bytes of the 128^2 kernel; the
+// remaining latency is hidden by running the two wave groups of a SIMD (waves w and w+4 share a SIMD) half a phase
+// apart: each K-tile is four phases (C quadrants of 64 x 32, 16 MFMAs each); a phase is a LOAD segment (ds_read the
+// fragments of the quadrant, issue this wave's share of the NEXT tile's DMA) and an MFMA segment, each closed by a raw
+// s_barrier.  Group 1 enters the loop one barrier late, so while one group issues MFMAs its SIMD partner reads LDS /
+// issues DMA.  DMA completion is waited per wave with s_waitcnt vmcnt(0) two barriers before any wave reads the stage
+// (group 0 at the end of its MFMA phase 3, group 1 at the end of its MFMA phase 2); a stage is refilled at the earliest
+// two barriers after its last fragment read.  One __shared__ array, no __syncthreads() (it would drain the DMA queue).
+// ------------------------------------------------------------------------------------------------------------------
+#define MMD_BAR() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_big256_kernel(GemmP p, int KT) {
+    constexpr int BM = 256, BN = 256, BK = 64;
+    constexpr int XE = BM * BK, WE = BN * BK;                 // elements per stage image
+    extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int wr = wave >> 2, wc = wave & 3;                  // wr = wave group (M half), wc = N quarter
+    const int nbx = gridDim.x, nby = gridDim.y;
+    int bid = blockIdx.y * nbx + blockIdx.x;
+    const int nblk = nbx * nby;
+    {
+        const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    int mt, nt;
+    if (p.N > p.M) { nt = bid / nby; mt = bid % nby; } else { mt = bid / nbx; nt = bid % nbx; }
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int ntiles = p.N >> 4;
+    const bf16_t* X = (const bf16_t*)p.X;
+    const bf16_t* Wp = (const bf16_t*)p.W;
+    const int nsteps = p.K / BK;
+
+    // this wave's share of a stage: 4 X pieces (8 rows x 128 B each) + 4 W pieces (fragment tiles); `part` 0/1 issues 2 + 2
+    auto stage_part = [&](int buf, int step, int part) {
+        bf16_t* xs = lds + buf * (XE + WE);
+        bf16_t* ws = xs + XE;
+        const int k0 = step * BK;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int pi = wave + 8 * (part * 2 + j);          // 32 X pieces
+            int row = m0 + pi * 8 + (lane >> 3);
+            row = row < p.M ? row : p.M - 1;
+            const int chunk = (lane & 7) ^ (lane >> 3);
+            const bf16_t* src = X + (long long)row * p.ldx + k0 + chunk * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(xs + pi * 512), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int wi = wave + 8 * (part * 2 + j);          // 32 W pieces: (n-tile wi>>1, k-tile wi&1)
+            int ntile = n0 / 16 + (wi >> 1);
+            ntile = ntile < ntiles ? ntile : ntiles - 1;       // N tail: clamp (results masked at the store)
+            const bf16_t* src = Wp + (((long long)ntile * KT + (k0 >> 5) + (wi & 1)) * 64 + lane) * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(ws + wi * 512), 16, 0, 0);
+        }
+    };
+
+    f32x4_t acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0, 0, 0, 0};
+    bf16x8_t a[4][2], b0[2][2], b1[2][2];
+
+    auto load_a = [&](const bf16_t* xs, int mh) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                const int mtile = wr * 8 + mh * 4 + i, c = kt * 4 + lq;
+                a[i][kt] = *reinterpret_cast<const bf16x8_t*>(xs + (mtile * 2 + (lr >> 3)) * 512 + (lr & 7) * 64 + ((c ^ (lr & 7)) * 8));
+            }
+    };
+    auto load_b = [&](const bf16_t* ws, int nh, bf16x8_t (&b)[2][2]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) b[j][kt] = *reinterpret_cast<const bf16x8_t*>(ws + ((wc * 4 + nh * 2 + j) * 2 + kt) * 512 + lane * 8);
+    };
+    auto mma = [&](int mh, int nh, const bf16x8_t (&b)[2][2]) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[mh * 4 + i][nh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][kt], a[i][kt], acc[mh * 4 + i][nh * 2 + j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // prologue: everyone stages tile 0, waits for its own DMA, one common barrier
+    stage_part(0, 0, 0); stage_part(0, 0, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MMD_BAR();
+    if (wr == 1) MMD_BAR();                                    // group 1 runs one barrier behind group 0
+
+    for (int t = 0; t < nsteps; ++t) {
+        const int cur = t & 1;
+        const bf16_t* xs = lds + cur * (XE + WE);
+        const bf16_t* ws = xs + XE;
+        const bool more = t + 1 < nsteps;
+        // phase 0: quadrant (m half 0, n half 0)
+        load_a(xs, 0); load_b(ws, 0, b0);
+        if (more) stage_part(cur ^ 1, t + 1, 0);
+        MMD_BAR();
+        mma(0, 0, b0);
+        MMD_BAR();
+        // phase 1: (m0, n1)
+        load_b(ws, 1, b1);
+        if (more) stage_part(cur ^ 1, t + 1, 1);
+        MMD_BAR();
+        mma(0, 1, b1);
+        MMD_BAR();
+        // phase 2: (m1, n1)
+        load_a(xs, 1);
+        MMD_BAR();
+        mma(1, 1, b1);
+        if (wr == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        MMD_BAR();
+        // phase 3: (m1, n0) -- fragments already resident
+        MMD_BAR();
+        mma(1, 0, b0);
+        if (wr == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        MMD_BAR();
+    }
+    if (wr == 0) MMD_BAR();                                    // match group 1's extra barrier
+
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int m = m0 + wr * 128 + i * 16 + lr;
+        if constexpr (EPI == EPI_SWIGLU) {
+#pragma unroll
+            for (int j = 0; j < 4; j += 2) { const int nb = n0 + wc * 64 + j * 16; if (nb + 32 <= p.N) big_store_swiglu(p, m, nb + lq * 4, acc[i][j], acc[i][j + 1]); }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const int nb = n0 + wc * 64 + j * 16; if (nb + 16 <= p.N) big_store<EPI>(p, m, nb + lq * 4, acc[i][j]); }
+        }
+    }
+}
+
+static hipError_t launch_big256(const GemmP& p, const GemmArgs& a, hipStream_t st) {
+    dim3 grid(cdiv(a.N, 256), cdiv(a.M, 256));
+    const int KT = a.K >> 5;
+    const size_t smem = 2 * (256 * 64 + 256 * 64) * sizeof(bf16_t);          // 128 KB
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)gemm_big256_kernel<EPI_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipFuncSetAttribute((const void*)gemm_big256_kernel<EPI_GELU_TANH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipFuncSetAttribute((const void*)gemm_big256_kernel<EPI_GELU_ERF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipFuncSetAttribute((const void*)gemm_big256_kernel<EPI_RESID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipFuncSetAttribute((const void*)gemm_big256_kernel<EPI_SWIGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_set = true;
+    }
+    switch (a.epi) {
+        case EPI_GELU_TANH: hipLaunchKernelGGL((gemm_big256_kernel<EPI_GELU_TANH>), grid, dim3(512), smem, st, p, KT); break;
+        case EPI_GELU_ERF: hipLaunchKernelGGL((gemm_big256_kernel<EPI_GELU_ERF>), grid, dim3(512), smem, st, p, KT); break;
+        case EPI_RESID: hipLaunchKernelGGL((gemm_big256_kernel<EPI_RESID>), grid, dim3(512), smem, st, p, KT); break;
+        case EPI_SWIGLU: hipLaunchKernelGGL((gemm_big256_kernel<EPI_SWIGLU>), grid, dim3(512), smem, st, p, KT); break;
+        default: hipLaunchKernelGGL((gemm_big256_kernel<EPI_NONE>), grid, dim3(512), smem, st, p, KT); break;
+    }
+    return hipGetLastError();
+}
+
 static bool big_packed_ok(int dtype, const GemmArgs& a, int BN) {
     return dtype == MMD_BF16 && a.Wp != nullptr && a.M > 64 && (a.N % BN) == 0 && (a.K % 64) == 0 && (a.ldx % 8) == 0 &&
            ((uintptr_t)a.X % 16) == 0 && !a.out_f32 && (a.ldy % 4) == 0 && ((uintptr_t)a.Y % 8) == 0 &&
@@ -711,6 +880,13 @@ static hipError_t launch_t(const GemmArgs& a, hipStream_t st, int* kind_out) {
     bool large = (variant == GEMM_LARGE) || (variant == GEMM_AUTO && a.M >= 256 && a.N >= 128);
     if (kind_out) *kind_out = skinny ? MMD_K_GEMM_SKINNY : MMD_K_GEMM_TILE;
     if constexpr (sizeof(T) == 2) {
+        if (variant == GEMM_BIG256 || (variant == GEMM_AUTO && a.M >= 2048 && (a.N % 32) == 0 && big_packed_ok(MMD_BF16, a, 16) &&
+                                       (long long)cdiv(a.M, 256) * cdiv(a.N, 256) >= 256 && !getenv("MMDUET_NO_BIG256"))) {
+            if (!big_packed_ok(MMD_BF16, a, 16) || (a.N % 32) != 0) return hipErrorInvalidValue;
+            p.W = a.Wp;
+            if (kind_out) *kind_out = MMD_K_GEMM_TILE;
+            return launch_big256(p, a, st);
+        }
         const bool want_big = variant == GEMM_BIG || (variant == GEMM_AUTO && a.M > 64);
         if (want_big) {
             int bn = 0;
