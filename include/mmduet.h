@@ -31,7 +31,8 @@ extern "C" {
 #define MMD_EHIP (-5)
 
 typedef enum { MMD_F32 = 0, MMD_BF16 = 1 } mmd_dtype;
-typedef enum { MMD_POOL_BILINEAR = 0, MMD_POOL_AVERAGE = 1, MMD_POOL_MAX = 2 } mmd_pool_mode;
+/* ADAPTIVE_AVG = adaptive_avg_pool2d to pool_stride x pool_stride tokens (the secondary encoder path, models/vision_live.py:17-24) */
+typedef enum { MMD_POOL_BILINEAR = 0, MMD_POOL_AVERAGE = 1, MMD_POOL_MAX = 2, MMD_POOL_ADAPTIVE_AVG = 3 } mmd_pool_mode;
 
 /* Shape of the model.  Mirrors the fields of VideoHeadLiveLlavaQwenConfig (models/live_llava/video_head_live_llava_qwen.py:41-45,
  * models/configuration_live.py:22-36) plus the SigLIP tower shape LLaVA-NeXT hard-codes. */

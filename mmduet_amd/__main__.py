@@ -1,0 +1,52 @@
+"""`python -m mmduet_amd ...` -- benchmark inference over pre-decoded videos (mirror of `python -m test.inference`,
+test/inference.py:332-363).
+
+The reference decodes videos with OpenCV inside its dataset class (test/datasets.py:32-85); OpenCV is not part of this
+package, so `--test_fname` is a JSON list whose entries carry the already sampled, letter-boxed frames:
+    {"question_id": ..., "frames": "clip0.npy" (uint8 [T,3,R,R], relative to --input_dir), "fps": 1.0,
+     "video_duration": 30.0, "conversation": [{"role": "user", "content": "...", "time": 0.0}, ...]}
+Everything else (flags, JSONL output format, `--start_idx/--end_idx` sharding, skip-on-unreadable) follows the reference.
+With torchrun, entries are sharded over the ranks (`i % world == rank`) and every rank writes `<output_fname>.rank<r>`.
+"""
+import json, os, sys
+import numpy as np
+import torch
+
+
+def main(argv=None):
+    from .arguments_live import parse_args
+    from .inference import LiveInferForBenchmark
+    from .results import result_record
+    from .distributed import init_distributed, shard_indices
+    args = parse_args('test', argv)
+    rank, world, local = init_distributed()
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    data = json.load(open(args.test_fname))[args.start_idx:args.end_idx]
+    mine = shard_indices(len(data), rank, world)
+    infer = LiveInferForBenchmark(args)
+    out_name = args.output_fname if world == 1 else f'{args.output_fname}.rank{rank}'
+    with open(out_name, 'w') as f_out:
+        for n, i in enumerate(mine):
+            ex = data[i]
+            try:
+                frames = torch.from_numpy(np.load(os.path.join(args.input_dir, ex['frames'])))
+            except Exception as e:      # test/datasets.py:102-104: unreadable videos are skipped
+                print(f"error loading {ex.get('question_id')} due to exception {e}, this example will be skipped", file=sys.stderr)
+                continue
+            if args.max_num_frames:
+                frames = frames[:args.max_num_frames]
+            conversation = [{'role': 'system', 'content': args.system_prompt}] + list(ex['conversation'])
+            infer.reset()
+            infer.set_fps(fps=ex.get('fps', args.frame_fps))
+            infer.input_video_stream(frames)
+            infer.input_query_stream(conversation)
+            responses = infer.inference()
+            rec = result_record(ex['question_id'], responses, ex.get('video_duration', len(frames) / infer.frame_fps), infer.debug_data_list)
+            f_out.write(json.dumps(rec) + '\n')
+            if n % 5 == 0:
+                f_out.flush()
+
+
+if __name__ == '__main__':
+    main()

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libmmduet_hip.so')
 
 MMD_F32, MMD_BF16 = 0, 1
-POOL_MODES = {'bilinear': 0, 'average': 1, 'max': 2}
+POOL_MODES = {'bilinear': 0, 'average': 1, 'max': 2, 'adaptive_avg': 3}
 K_NAMES = ('gemm_skinny', 'gemm_tile', 'attn_llm', 'attn_vit', 'norm_rope', 'other')
 EPI = {'none': 0, 'gelu_tanh': 1, 'gelu_erf': 2, 'resid': 3, 'swiglu': 4}
 

@@ -340,6 +340,13 @@ __global__ void pool_kernel(const T* __restrict__ x, T* __restrict__ y, int g, i
         float cq = to_f<T>(xb[((long long)y1 * g + x0) * H + c]), dq = to_f<T>(xb[((long long)y1 * g + x1) * H + c]);
         float top = a * (1.f - lx) + bq * lx, bot = cq * (1.f - lx) + dq * lx;
         r = top * (1.f - ly) + bot * ly;
+    } else if (mode == MMD_POOL_ADAPTIVE_AVG) {
+        // adaptive_avg_pool2d of the token grid (models/vision_live.py:17-24): bin i = [floor(i g / out), ceil((i+1) g / out))
+        const int ys = (oy * g) / out, ye = ((oy + 1) * g + out - 1) / out, xs = (ox * g) / out, xe = ((ox + 1) * g + out - 1) / out;
+        float acc = 0.f;
+        for (int yy = ys; yy < ye; ++yy)
+            for (int xx = xs; xx < xe; ++xx) acc += to_f<T>(xb[((long long)yy * g + xx) * H + c]);
+        r = acc / (float)((ye - ys) * (xe - xs));
     } else {
         float acc = mode == MMD_POOL_MAX ? -INFINITY : 0.f;
         for (int dy = 0; dy < stride; ++dy)
@@ -352,7 +359,7 @@ __global__ void pool_kernel(const T* __restrict__ x, T* __restrict__ y, int g, i
     y[(((long long)b * out + oy) * out + ox) * H + c] = from_f<T>(r);
 }
 hipError_t launch_pool(int dtype, const void* x, void* y, int B, int grid, int H, int mode, int stride, hipStream_t st) {
-    int out = mode == MMD_POOL_BILINEAR ? (grid + stride - 1) / stride : grid / stride;
+    int out = mode == MMD_POOL_BILINEAR ? (grid + stride - 1) / stride : mode == MMD_POOL_ADAPTIVE_AVG ? stride : grid / stride;   // adaptive: `stride` carries the output side
     if (B <= 0 || out <= 0) return hipSuccess;
     dim3 g(cdiv(H, 256), out * out, B), block(256);
     if (dtype == MMD_F32) hipLaunchKernelGGL(pool_kernel<float>, g, block, 0, st, (const float*)x, (float*)y, grid, H, mode, stride, out);

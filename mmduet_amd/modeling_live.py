@@ -214,7 +214,10 @@ class VideoHeadLiveLlavaQwenForCausalLM:
             raise ValueError(f'Unexpected mm_spatial_pool_mode: {config.mm_spatial_pool_mode}')
         c.pool_mode, c.pool_stride = POOL_MODES[config.mm_spatial_pool_mode], config.video_pooling_stride
         g = config.vit_grid
-        out_side = -(-g // config.video_pooling_stride) if config.mm_spatial_pool_mode == 'bilinear' else g // config.video_pooling_stride
+        if config.mm_spatial_pool_mode == 'adaptive_avg':       # secondary path (models/vision_live.py): pool to frame_token_pooled[0] per side
+            out_side = config.video_pooling_stride
+        else:
+            out_side = -(-g // config.video_pooling_stride) if config.mm_spatial_pool_mode == 'bilinear' else g // config.video_pooling_stride
         self.tokens_per_frame = out_side * out_side
         c.frame_num_tokens = self.tokens_per_frame
         c.max_vit_batch, c.max_step_tokens = max_vit_batch, max_step_tokens

@@ -59,7 +59,7 @@ class RawOps:
 
     def pool(self, x, grid, mode, stride):
         B, _, H = x.shape
-        out = -(-grid // stride) if mode == 0 else grid // stride
+        out = -(-grid // stride) if mode == 0 else stride if mode == 3 else grid // stride
         y = torch.empty(B, out * out, H, device=self.dev, dtype=self.dtype); self.m._bind_stream()
         xd = self.t(x)
         check(lib().mmd_op_pool(self.ctx, _ptr(xd), _ptr(y), B, grid, H, mode, stride), self.ctx)

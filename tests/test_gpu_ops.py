@@ -170,6 +170,15 @@ def test_pooling_modes(ops):
             assert_close(ops.pool(x, grid, mode, stride), ref, ops.dtype, what=f'pool {name} {grid}/{stride}')
 
 
+def test_adaptive_avg_pool_secondary_path(ops):
+    """adaptive_avg_pool2d of the token grid to frame_token_pooled (models/vision_live.py:17-24)."""
+    g = torch.Generator().manual_seed(4)
+    for grid, out in ((24, 7), (27, 7), (5, 3), (4, 4)):
+        x = torch.randn(2, grid * grid, 24, generator=g)
+        ref = O.adaptive_avg_pool_tokens(rt(x, ops.dtype).to(ops.dtype), (out, out))
+        assert_close(ops.pool(x, grid, 3, out), ref, ops.dtype, what=f'adaptive pool {grid}->{out}')
+
+
 def test_preprocess_bit_exact_with_pillow(ops):
     """mmd_preprocess_frames against image_processor outputs recorded from the reference stack (PIL bicubic)."""
     z = load_npz('preprocess.npz')
