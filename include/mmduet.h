@@ -102,7 +102,8 @@ int mmd_stream_create(mmd_ctx* ctx, int64_t initial_tokens, mmd_stream** out);
 void mmd_stream_destroy(mmd_stream* s);
 int64_t mmd_kv_len(const mmd_stream* s);
 int64_t mmd_kv_capacity(const mmd_stream* s);
-int mmd_kv_truncate(mmd_stream* s, int64_t new_len);     /* rollback: remove_assistant_turns (test/inference.py:265-269), speculative chunks */
+int mmd_kv_truncate(mmd_stream* s, int64_t new_len);
+int mmd_kv_debug_set_len(mmd_stream* s, int64_t n);       /* measurement aid: mark n slots live without computing them */     /* rollback: remove_assistant_turns (test/inference.py:265-269), speculative chunks */
 
 /* replaces VideoHeadLiveLlavaQwenForCausalLM.forward body (models/live_llava/video_head_live_llava_qwen.py:141) ==
  * Qwen2Model.forward for batch 1: embeds [S, hidden] are appended at positions kv_len..kv_len+S-1; hidden_out

@@ -54,6 +54,7 @@ _SIGS = {
     'mmd_kv_len': (_I64, [_VP]),
     'mmd_kv_capacity': (_I64, [_VP]),
     'mmd_kv_truncate': (_I, [_VP, _I64]),
+    'mmd_kv_debug_set_len': (_I, [_VP, _I64]),
     'mmd_llm_step': (_I, [_VP, _VP, _VP, _I, _VP]),
     'mmd_video_heads': (_I, [_VP, _VP, _I, _VP]),
     'mmd_lm_head': (_I, [_VP, _VP, _I, _VP]),

@@ -589,13 +589,35 @@ extern "C" int mmd_kv_truncate(mmd_stream* s, int64_t n) {
     return MMD_OK;
 }
 
+static int kv_reserve(mmd_ctx* c, mmd_stream* s, int64_t need);
+// measurement aid (tools/kv_growth_sweep.py): declare the first n slots of the arena live without computing them, to time a
+// step at a given context length (the slots hold zeros / stale data -- numerically meaningless, same memory traffic)
+extern "C" int mmd_kv_debug_set_len(mmd_stream* s, int64_t n) {
+    if (!s || n < 0) return MMD_EINVAL;
+    hipSetDevice(s->ctx->device);
+    int rc = kv_reserve(s->ctx, s, n); if (rc) return rc;
+    s->len = n;
+    return MMD_OK;
+}
+
 static int kv_reserve(mmd_ctx* c, mmd_stream* s, int64_t need) {
     if (need <= s->cap) return MMD_OK;
     int64_t ncap = s->cap * 2; while (ncap < need) ncap *= 2;
     size_t e = es(c);
     size_t bytes = kv_layer_elems(c, ncap) * c->cfg.num_layers * e;
     void *nK = nullptr, *nV = nullptr;
-    if (hipMalloc(&nK, bytes) != hipSuccess || hipMalloc(&nV, bytes) != hipSuccess) { if (nK) hipFree(nK); FAIL(c, MMD_ENOMEM, "cannot grow KV arena to %lld tokens", (long long)ncap); }
+    if (hipMalloc(&nK, bytes) != hipSuccess || hipMalloc(&nV, bytes) != hipSuccess) {
+        // doubling does not fit next to the old arena: fall back to the exact need (+1/8 headroom)
+        if (nK) { hipFree(nK); nK = nullptr; }
+        (void)hipGetLastError();
+        ncap = round_up(need + need / 8, 64);
+        bytes = kv_layer_elems(c, ncap) * c->cfg.num_layers * e;
+        if (hipMalloc(&nK, bytes) != hipSuccess || hipMalloc(&nV, bytes) != hipSuccess) {
+            if (nK) hipFree(nK);
+            (void)hipGetLastError();
+            FAIL(c, MMD_ENOMEM, "cannot grow KV arena to %lld tokens (%zu bytes x2 next to the live arena)", (long long)ncap, bytes);
+        }
+    }
     hipMemsetAsync(nK, 0, bytes, c->stream); hipMemsetAsync(nV, 0, bytes, c->stream);
     size_t rows = (size_t)c->cfg.num_layers * c->cfg.num_kv_heads;
     size_t w = (size_t)round_up(s->len, 64) * c->cfg.head_dim * e;        // V is stored in whole 64-token blocks
