@@ -21,7 +21,8 @@ out = []
 for n_ctx in (0, 29400, 100_000, 300_000, 1_000_000, 2_000_000, 3_000_000, 4_000_000, 4_500_000):
     try:
         if n_ctx >= 3_000_000:      # growth by reallocation needs old + new arena at once: start the big ones fresh
-            del cache; torch.cuda.synchronize()
+            import gc
+            h = h2 = sc = None; del cache; gc.collect(); torch.cuda.synchronize()
             cache = model.new_cache(initial_tokens=n_ctx + 2048)
         check(lib().mmd_kv_debug_set_len(cache.arena.h, n_ctx), model._ctx, 'set_len')
     except Exception as e:
