@@ -38,6 +38,7 @@ def parse():
     p.add_argument('--tiny', action='store_true', help='tiny model (plumbing check, not a valid measurement)')
     p.add_argument('--no-overlap', action='store_true', help='run the vision tower and the LLM steps on one stream')
     p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--prof-stride', type=int, default=7, help='bracket every n-th launch of the dominant kernel class with HIP events')
     p.add_argument('--no-prof', action='store_true', help='do not bracket the dominant kernel with HIP events in the timed region')
     p.add_argument('--layers', type=int, default=None, help='debug: override LLM layer count (INVALID as a measurement)')
     return p.parse_args()
@@ -163,6 +164,7 @@ def main():
         gather_scores([sc])
     prof_on = not args.no_prof
     model.prof_reset()
+    model.prof_set_stride(args.prof_stride)                 # every 7th launch of the class carries the two HIP events (sampling)
     model.prof_enable([dom] if prof_on else False)        # only the dominant class is bracketed inside the timed region
     sync()
     t0 = time.perf_counter()
@@ -206,7 +208,8 @@ def main():
             except Exception:
                 pass
             roof['avg_launch_us'] = round(avg_ms * 1e3, 2)
-            roof['launches'] = int(p['launches'])
+            roof['launches_timed'] = int(p['launches'])
+            roof['sampling_stride'] = args.prof_stride
             roof['per_class_ms_untimed_pass'] = {k: round(v['ms'], 1) for k, v in prof_all.items()}
         cpu = None if (args.no_cpu_baseline or args.tiny or world > 1) else cpu_baseline()
         line = {

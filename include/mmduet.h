@@ -132,6 +132,7 @@ int mmd_greedy_generate(mmd_ctx* ctx, mmd_stream* s, const void* prompt_embeds, 
 enum { MMD_K_GEMM_SKINNY = 0, MMD_K_GEMM_TILE = 1, MMD_K_ATTN_LLM = 2, MMD_K_ATTN_VIT = 3, MMD_K_NORM_ROPE = 4,
        MMD_K_OTHER = 5, MMD_K_COUNT = 6 };
 int mmd_prof_enable(mmd_ctx* ctx, int class_mask);       /* bit k set = bracket launches of class MMD_K_k; 0 = off */
+int mmd_prof_set_stride(mmd_ctx* ctx, int stride);       /* bracket only every stride-th launch of an enabled class (sampling) */
 int mmd_prof_read(mmd_ctx* ctx, double* ms_out /*[MMD_K_COUNT]*/, int64_t* launches_out /*[MMD_K_COUNT]*/,
                   double* bytes_out /*[MMD_K_COUNT] algorithmic bytes*/, double* flops_out /*[MMD_K_COUNT]*/);
 int mmd_prof_reset(mmd_ctx* ctx);

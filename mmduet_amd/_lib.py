@@ -61,6 +61,7 @@ _SIGS = {
     'mmd_frame_step': (_I, [_VP, _VP, _VP, _I, _VP, _I, _VP]),
     'mmd_greedy_generate': (_I, [_VP, _VP, _VP, _I, _I64, _F, _VP, C.POINTER(_I), _I, _VP, _I, C.POINTER(_I)]),
     'mmd_prof_enable': (_I, [_VP, _I]),
+    'mmd_prof_set_stride': (_I, [_VP, _I]),
     'mmd_prof_read': (_I, [_VP, _VP, _VP, _VP, _VP]),
     'mmd_prof_reset': (_I, [_VP]),
     'mmd_op_gemm': (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _I]),

@@ -22,6 +22,8 @@ struct RawTensor { void* p = nullptr; std::vector<int64_t> shape; int64_t numel 
 
 struct Prof {
     unsigned on = 0;                   // bitmask over MMD_K_* classes
+    int stride = 1;                    // bracket every stride-th launch of an enabled class (event records are not free)
+    int64_t seen[MMD_K_COUNT] = {0};
     std::vector<hipEvent_t> pool;
     struct Pending { hipEvent_t a, b; int kind; };
     std::vector<Pending> pending;
@@ -106,6 +108,7 @@ struct ProfScope {
     mmd_ctx* c; int kind; hipEvent_t a = nullptr, b = nullptr;
     ProfScope(mmd_ctx* c_, int kind_, double bytes, double flops) : c(c_), kind(kind_) {
         if (!((c->prof.on >> kind_) & 1u)) return;
+        if ((c->prof.seen[kind_]++ % c->prof.stride) != 0) return;
         auto get = [&]() { hipEvent_t e; if (!c->prof.pool.empty()) { e = c->prof.pool.back(); c->prof.pool.pop_back(); } else hipEventCreate(&e); return e; };
         a = get(); b = get();
         c->prof.bytes[kind] += bytes; c->prof.flops[kind] += flops; c->prof.n[kind] += 1;
@@ -846,10 +849,11 @@ extern "C" int mmd_greedy_generate(mmd_ctx* c, mmd_stream* s, const void* prompt
 
 // ---- measurement -------------------------------------------------------------------------------------------------------
 extern "C" int mmd_prof_enable(mmd_ctx* c, int mask) { if (!c) return MMD_EINVAL; if (!mask) prof_drain(c); c->prof.on = (unsigned)mask; return MMD_OK; }
+extern "C" int mmd_prof_set_stride(mmd_ctx* c, int stride) { if (!c || stride < 1) return MMD_EINVAL; c->prof.stride = stride; return MMD_OK; }
 extern "C" int mmd_prof_reset(mmd_ctx* c) {
     if (!c) return MMD_EINVAL;
     prof_drain(c);
-    for (int i = 0; i < MMD_K_COUNT; ++i) { c->prof.ms[i] = 0; c->prof.n[i] = 0; c->prof.bytes[i] = 0; c->prof.flops[i] = 0; }
+    for (int i = 0; i < MMD_K_COUNT; ++i) { c->prof.ms[i] = 0; c->prof.n[i] = 0; c->prof.bytes[i] = 0; c->prof.flops[i] = 0; c->prof.seen[i] = 0; }
     return MMD_OK;
 }
 extern "C" int mmd_prof_read(mmd_ctx* c, double* ms, int64_t* n, double* bytes, double* flops) {

@@ -17,6 +17,7 @@ how the work is scheduled on the GPU:
 from __future__ import annotations
 import collections
 import math
+import os
 from dataclasses import asdict
 import torch
 
@@ -128,7 +129,9 @@ class LiveInferForBenchmark:
         # side HIP stream so that batch i+1 of the tower overlaps the LLM work on batch i.  Every queued frame carries the
         # event of its batch; the LLM stream waits on it right before the frame is consumed.  Results are unchanged.
         if self._vit_stream is None:
-            self._vit_stream = torch.cuda.Stream(device=self.device)
+            lo, hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, 'priority_range') else (0, -1)
+            # lowest priority for the tower: the LLM's short latency-bound kernels go first, tower tiles fill the gaps
+            self._vit_stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get('MMDUET_VIT_PRIO', lo)))
         main = torch.cuda.current_stream(self.device)
         side = self._vit_stream
         side.wait_stream(main)

@@ -462,6 +462,9 @@ class VideoHeadLiveLlavaQwenForCausalLM:
             mask = sum(1 << _lib.K_NAMES.index(k) for k in classes)
         check(lib().mmd_prof_enable(self._ctx, mask), self._ctx)
 
+    def prof_set_stride(self, stride):
+        check(lib().mmd_prof_set_stride(self._ctx, int(stride)), self._ctx)
+
     def prof_reset(self):
         check(lib().mmd_prof_reset(self._ctx), self._ctx)
 
