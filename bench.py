@@ -32,7 +32,7 @@ def parse():
     p.add_argument('--warmup', type=int, default=1)
     p.add_argument('--frames', type=int, default=300)
     p.add_argument('--resolution', type=int, default=336)
-    p.add_argument('--frames-per-forward', type=int, default=20, help='frames per causal LLM forward (1 = the reference schedule; results agree up to fp reduction order)')
+    p.add_argument('--frames-per-forward', type=int, default=26, help='frames per causal LLM forward (1 = the reference schedule; results agree up to fp reduction order)')
     p.add_argument('--responses', type=int, default=4, help='responses per stream, forced at frames drawn once from random.Random(0) (random-init heads carry no signal)')
     p.add_argument('--max-new-tokens', type=int, default=32)
     p.add_argument('--tiny', action='store_true', help='tiny model (plumbing check, not a valid measurement)')

@@ -880,8 +880,9 @@ static hipError_t launch_t(const GemmArgs& a, hipStream_t st, int* kind_out) {
     bool large = (variant == GEMM_LARGE) || (variant == GEMM_AUTO && a.M >= 256 && a.N >= 128);
     if (kind_out) *kind_out = skinny ? MMD_K_GEMM_SKINNY : MMD_K_GEMM_TILE;
     if constexpr (sizeof(T) == 2) {
-        if (variant == GEMM_BIG256 || (variant == GEMM_AUTO && a.M >= 2048 && (a.N % 32) == 0 && big_packed_ok(MMD_BF16, a, 16) &&
-                                       (long long)cdiv(a.M, 256) * cdiv(a.N, 256) >= 256 && !getenv("MMDUET_NO_BIG256"))) {
+        // 256^2 tiles pay once there are >= 2 full block waves of them (ViT qkv / fc1 / projector, gate_up of a >= 1000-row chunk)
+        if (variant == GEMM_BIG256 || (variant == GEMM_AUTO && a.M >= 512 && (a.N % 32) == 0 && big_packed_ok(MMD_BF16, a, 16) &&
+                                       (long long)cdiv(a.M, 256) * cdiv(a.N, 256) >= 512 && !getenv("MMDUET_NO_BIG256"))) {
             if (!big_packed_ok(MMD_BF16, a, 16) || (a.N % 32) != 0) return hipErrorInvalidValue;
             p.W = a.Wp;
             if (kind_out) *kind_out = MMD_K_GEMM_TILE;
