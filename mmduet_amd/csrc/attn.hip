@@ -16,6 +16,9 @@
 // softmax statistics are fp32; P is rounded to the storage type before P.V (flash / sdpa semantics).
 #include "common.h"
 
+// defer-max threshold (log2 units) of the flash kernels: the running maximum moves only when it grows by more than this
+#define ATTN_DEFER 4.0f
+
 struct AttnP {
     const void* q; const void* K; const void* V; void* out; float* ws_o; float* ws_ml;
     long long ldq, ldo, k_hs, k_ts, v_hs, v_ts, q_bs, kv_bs, o_bs;
@@ -373,13 +376,16 @@ __global__ __launch_bounds__(256, 2) void attn_gqa128_kernel(AttnP p) {
             bf16x8_t pf[RT];
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
+                // softmax on raw scores: the 1/sqrt(d)*log2(e) scale is folded into one FMA per element, and the running
+                // maximum is only moved (O and l rescaled) when it grows by more than 2^DEFER -- P then ranges up to 2^DEFER
+                // instead of 1, which bf16 P / fp32 O and l absorb; saves ~30 VALU per 16 MFMAs in a VALU-bound loop
                 float sv[8];
                 float mx = -INFINITY;
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float v = st[rt][t][r] * p.scale_log2;
+                        float v = st[rt][t][r];
                         if (need_mask) {
                             long long key = k0 + h * 32 + t * 16 + lq * 4 + r;
                             if (!(key < my_limit[rt] && key < kend)) v = -INFINITY;
@@ -389,20 +395,21 @@ __global__ __launch_bounds__(256, 2) void attn_gqa128_kernel(AttnP p) {
                     }
                 mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
                 mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-                float m_new = fmaxf(m_run[rt], mx);
-                float m_use = m_new == -INFINITY ? 0.f : m_new;
-                float alpha = __builtin_amdgcn_exp2f(m_run[rt] - m_use);
+                mx *= p.scale_log2;                                   // scale > 0: max commutes with it
+                if (mx > m_run[rt] + ATTN_DEFER) {                    // (first tile: m_run = -inf -> always)
+                    const float alpha = __builtin_amdgcn_exp2f(m_run[rt] - mx);      // m_run = -inf -> 0
+                    l_run[rt] *= alpha;
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) oacc[rt][t] *= alpha;
+                    m_run[rt] = mx;
+                }
+                const float neg_m = m_run[rt] == -INFINITY ? 0.f : -m_run[rt];
                 float psum = 0.f;
                 s16x8_t pk;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) { float pv = __builtin_amdgcn_exp2f(sv[i] - m_use); psum += pv; pk[i] = (short)f2bf(pv); }
-                l_run[rt] = l_run[rt] * alpha + psum;
-                m_run[rt] = m_new;
+                for (int i = 0; i < 8; ++i) { float pv = __builtin_amdgcn_exp2f(fmaf(sv[i], p.scale_log2, neg_m)); psum += pv; pk[i] = (short)f2bf(pv); }
+                l_run[rt] += psum;
                 pf[rt] = __builtin_bit_cast(bf16x8_t, pk);
-                if (alpha != 1.0f) {
-#pragma unroll
-                    for (int t = 0; t < 8; ++t) oacc[rt][t] *= alpha;
-                }
             }
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
@@ -493,9 +500,9 @@ static hipError_t launch_gqa128(AttnP& p, const AttnArgs& a, hipStream_t st) {
     } else if (rows_total <= 16 && a.ws) {
         splits = 64;                                               // decode: same key ranges as the graph-replayed form -> identical bits
         if (splits > tiles) splits = tiles;
-    } else if (blocks < 256 && a.ws) {
-        splits = cdiv(320, blocks);
-        int maxs = tiles / 2; if (maxs < 1) maxs = 1;              // >= 2 key tiles per split
+    } else if (blocks < 512 && a.ws) {                             // two 4-wave blocks per CU hide each other's barriers
+        splits = cdiv(576, blocks);
+        int maxs = tiles / 4; if (maxs < 1) maxs = 1;              // >= 4 key tiles per split
         if (splits > maxs) splits = maxs;
         while (splits > 1 && (size_t)splits * a.nkv * rows_total * (128 + 2) * sizeof(float) > a.ws_bytes) --splits;
     }
@@ -621,13 +628,16 @@ __global__ __launch_bounds__(256, 2) void attn_rowmajor_kernel(AttnP p) {
             bf16x8_t pf[RT];
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
+                // softmax on raw scores: the 1/sqrt(d)*log2(e) scale is folded into one FMA per element, and the running
+                // maximum is only moved (O and l rescaled) when it grows by more than 2^DEFER -- P then ranges up to 2^DEFER
+                // instead of 1, which bf16 P / fp32 O and l absorb; saves ~30 VALU per 16 MFMAs in a VALU-bound loop
                 float sv[8];
                 float mx = -INFINITY;
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float v = st[rt][t][r] * p.scale_log2;
+                        float v = st[rt][t][r];
                         if (need_mask) {
                             const int key = k0 + h * 32 + t * 16 + lq * 4 + r;
                             if (!(key < my_limit[rt] && key < kend)) v = -INFINITY;
@@ -637,20 +647,21 @@ __global__ __launch_bounds__(256, 2) void attn_rowmajor_kernel(AttnP p) {
                     }
                 mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
                 mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-                float m_new = fmaxf(m_run[rt], mx);
-                float m_use = m_new == -INFINITY ? 0.f : m_new;
-                float alpha = __builtin_amdgcn_exp2f(m_run[rt] - m_use);
+                mx *= p.scale_log2;                                   // scale > 0: max commutes with it
+                if (mx > m_run[rt] + ATTN_DEFER) {                    // (first tile: m_run = -inf -> always)
+                    const float alpha = __builtin_amdgcn_exp2f(m_run[rt] - mx);      // m_run = -inf -> 0
+                    l_run[rt] *= alpha;
+#pragma unroll
+                    for (int t = 0; t < DVT; ++t) oacc[rt][t] *= alpha;
+                    m_run[rt] = mx;
+                }
+                const float neg_m = m_run[rt] == -INFINITY ? 0.f : -m_run[rt];
                 float psum = 0.f;
                 s16x8_t pk;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) { float pv = __builtin_amdgcn_exp2f(sv[i] - m_use); psum += pv; pk[i] = (short)f2bf(pv); }
-                l_run[rt] = l_run[rt] * alpha + psum;
-                m_run[rt] = m_new;
+                for (int i = 0; i < 8; ++i) { float pv = __builtin_amdgcn_exp2f(fmaf(sv[i], p.scale_log2, neg_m)); psum += pv; pk[i] = (short)f2bf(pv); }
+                l_run[rt] += psum;
                 pf[rt] = __builtin_bit_cast(bf16x8_t, pk);
-                if (alpha != 1.0f) {
-#pragma unroll
-                    for (int t = 0; t < DVT; ++t) oacc[rt][t] *= alpha;
-                }
             }
 #pragma unroll
             for (int t = 0; t < DVT; ++t) {
