@@ -257,6 +257,9 @@ class LiveInferForBenchmark:
         """Frames that may share the next forward: up to frames_per_forward, never across a pending user query
         (a query due at frame j must be encoded before frame j, test/inference.py:281-282)."""
         k = min(self.frames_per_forward, len(self.frame_embeds_queue))
+        cap = getattr(self.model, 'max_step_tokens', None)
+        if cap:                                  # leave room for the text prefix of the step (system prompt / stream header)
+            k = max(1, min(k, (cap - 128) // self.frame_num_tokens))
         if self.query_queue:
             q_time = self.query_queue[0][0]
             for j in range(1, k):

@@ -528,6 +528,14 @@ def build_live(*, is_training: bool, config_class=VideoHeadLiveLlavaQwenConfig, 
     if torch_dtype == 'auto' or torch_dtype is None:
         torch_dtype = torch.bfloat16
     runtime = {k: kwargs.pop(k) for k in ('max_vit_batch', 'max_step_tokens', 'kv_initial_tokens') if k in kwargs}
+    # workspace sizing from the driver flags: rows of one LLM forward (frames_per_forward chunks) and the KV arena
+    fpf = int(kwargs.get('frames_per_forward', 1) or 1)
+    nt = int(kwargs.get('frame_num_tokens', 49) or 49)
+    runtime.setdefault('max_step_tokens', max(1024, fpf * nt + 256))
+    if kwargs.get('kv_capacity_tokens'):
+        runtime.setdefault('kv_initial_tokens', int(kwargs['kv_capacity_tokens']))
+    elif kwargs.get('max_num_frames'):
+        runtime.setdefault('kv_initial_tokens', max(32768, int(kwargs['max_num_frames']) * nt + 4096))
     if llm_pretrained.startswith('synthetic'):
         config = config_class(**kwargs)
     else:

@@ -67,3 +67,15 @@ def test_demo_driver_single_frame_steps():
     assert [o['informative_score'] for o in outs] == pytest.approx([x['informative_score'] for x in case['debug_data']], abs=2e-5)
     assert sum(o['response'] is not None for o in outs) == case['n_responses']
     assert len(d.past_key_values) == case['final_kv_len']
+
+
+def test_chunk_size_respects_model_step_capacity():
+    model, _, _ = oracle_model('A')
+    model.max_step_tokens = 128 + 3 * 4            # room for 3 frames of 4 tokens
+    tok = tokenizer_for(model.config)
+    d = LiveInferForBenchmark(make_args(stream_end_prob_threshold=2.0, frames_per_forward=50), model=model, tokenizer=tok)
+    from helpers import stream_frames
+    d.input_video_stream(stream_frames('grounding_q0'))
+    assert d._chunk_size() == 3
+    d.inference()
+    assert len(d.debug_data_list) == 10 and d.forward_calls == 4
