@@ -891,7 +891,10 @@ static hipError_t launch_t(const GemmArgs& a, hipStream_t st, int* kind_out) {
         const bool want_big = variant == GEMM_BIG || (variant == GEMM_AUTO && a.M > 64);
         if (want_big) {
             int bn = 0;
-            if (big_packed_ok(MMD_BF16, a, 128) && (long long)cdiv(a.M, 128) * (a.N / 128) >= 224) bn = 128;
+            // 128-wide tiles need ~1.5 block waves to keep two blocks per CU busy; below that 64-wide tiles (3 blocks/CU) win
+            // by 8-10 % (measured at M = 980 / 1274, K = 3584); long-K shapes keep 128 and split K instead
+            const long long t128 = (long long)cdiv(a.M, 128) * (a.N / 128);
+            if (big_packed_ok(MMD_BF16, a, 128) && (t128 >= 400 || (a.K >= 8192 && t128 >= 224))) bn = 128;
             else if (big_packed_ok(MMD_BF16, a, 64)) bn = 64;
             if (bn) {
                 p.W = a.Wp;
