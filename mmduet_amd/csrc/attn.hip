@@ -473,12 +473,19 @@ __global__ __launch_bounds__(256) void attn_combine128_kernel(AttnP p, int nrows
         M = Mn;
         const int cnt = min(64, p.splits - s0);
         const float* obase = p.ws_o + ((long long)s0 * nrows_all + grow) * 128 + lane * 2;
-#pragma unroll 4
-        for (int j = 0; j < cnt; ++j) {
-            float wj = __shfl(w, j, 64);
-            const float* o = obase + (long long)j * nrows_all * 128;
-            float2 v = *reinterpret_cast<const float2*>(o);
-            a0 += wj * v.x; a1 += wj * v.y;
+        // 16 independent 512-byte row loads in flight per wave (the merge is pure load latency), fixed summation order
+        for (int j0 = 0; j0 < cnt; j0 += 16) {
+            float2 v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                v[u] = float2{0.f, 0.f};
+                if (j0 + u < cnt) v[u] = *reinterpret_cast<const float2*>(obase + (long long)(j0 + u) * nrows_all * 128);
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                float wj = __shfl(w, (j0 + u) & 63, 64);
+                a0 += wj * v[u].x; a1 += wj * v[u].y;
+            }
         }
     }
     float inv = L > 0.f ? 1.0f / L : 0.f;

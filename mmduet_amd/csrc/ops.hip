@@ -59,6 +59,44 @@ __global__ void layernorm_kernel(const T* __restrict__ x, const T* __restrict__ 
     if (row >= M) return;
     const T* xr = x + (long long)row * H;
     T* yr = y + (long long)row * H;
+    if constexpr (sizeof(T) == 2) {
+        if ((H & 7) == 0 && H <= 2048) {
+            // one wave per row, 16-byte accesses, the row stays in registers between the statistics and the output pass
+            float v[4][8];
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = lane * 8 + j * 512;
+                if (c < H) {
+                    s16x8_t raw = *reinterpret_cast<const s16x8_t*>(xr + c);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { v[j][e] = bf2f((bf16_t)raw[e]); s += v[j][e]; }
+                }
+            }
+            const float mu = wave_sum(s) / (float)H;
+            float q = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = lane * 8 + j * 512;
+                if (c < H) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { const float dlt = v[j][e] - mu; q += dlt * dlt; }
+                }
+            }
+            const float inv = rsqrtf(wave_sum(q) / (float)H + eps);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = lane * 8 + j * 512;
+                if (c < H) {
+                    s16x8_t g = *reinterpret_cast<const s16x8_t*>(w + c), bb = *reinterpret_cast<const s16x8_t*>(b + c), o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (short)f2bf((v[j][e] - mu) * inv * bf2f((bf16_t)g[e]) + bf2f((bf16_t)bb[e]));
+                    *reinterpret_cast<s16x8_t*>(yr + c) = o;
+                }
+            }
+            return;
+        }
+    }
     float s = 0.f;
     for (int c = lane; c < H; c += 64) s += to_f<T>(xr[c]);
     float mu = wave_sum(s) / (float)H;
