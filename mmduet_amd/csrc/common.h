@@ -121,7 +121,7 @@ hipError_t launch_pool(int dtype, const void* x, void* y, int B, int grid, int H
 hipError_t launch_heads(int dtype, const void* hidden, int64_t ldh, const int32_t* rows_dev, int M, const void* W4, int H, float* out,
                         hipStream_t st);
 hipError_t launch_argmax_penalty(const float* logits, int V, const int64_t* prev_ids_dev, int n_prev, float penalty, int64_t* out_id,
-                                 hipStream_t st, const StepState* dyn = nullptr);
+                                 hipStream_t st, const StepState* dyn, void* scratch512);
 hipError_t launch_convert(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, hipStream_t st);
 hipError_t launch_copy_rows(int dtype, const void* src, int64_t lds_, void* dst, int64_t ldd, int rows, int cols, hipStream_t st);
 hipError_t launch_interleave16(int dtype, const void* a, const void* b, void* out, int rows, int cols, hipStream_t st);

@@ -61,6 +61,7 @@ struct mmd_ctx {
     float* heads_dev = 0;              // [max_step_tokens,4]
     int32_t* rows_dev = 0;
     int64_t* tok_dev = 0;              // sampled token id
+    void* argmax_scratch = 0;          // candidates of the two-stage argmax
     int64_t* prev_dev = 0; int prev_cap = 0;
     void* gen_embed = 0;               // [1,H]
     // pinned staging
@@ -438,7 +439,7 @@ static int alloc_workspaces(mmd_ctx* c) {
     c->attn_bytes = (size_t)128 << 20; WS(c->attn_ws, c->attn_bytes);
     WS(c->logits_ws, (size_t)g.vocab_size * sizeof(float));
     WS(c->heads_dev, (size_t)S * 4 * sizeof(float)); WS(c->rows_dev, (size_t)S * sizeof(int32_t));
-    WS(c->tok_dev, 64); c->prev_cap = 16384; WS(c->prev_dev, (size_t)c->prev_cap * sizeof(int64_t));
+    WS(c->tok_dev, 64); WS(c->argmax_scratch, 1024); c->prev_cap = 16384; WS(c->prev_dev, (size_t)c->prev_cap * sizeof(int64_t));
     WS(c->gen_embed, (size_t)H * e);
 #undef WS
     HIPCHK(c, hipHostMalloc((void**)&c->heads_host, (size_t)S * 4 * sizeof(float)));
@@ -760,7 +761,7 @@ static int decode_step_enqueue(mmd_ctx* c, mmd_stream* s, bool pen, float rep_pe
     HIPCHK(c, launch_embed(g.dtype, c->embed, c->tok_dev, 1, H, g.vocab_size, c->gen_embed, st));
     int rc = llm_step_impl(c, s, c->gen_embed, 1, nullptr, dyn); if (rc) return rc;
     rc = gemm(c, c->l_hid, H, c->lm_head, H, nullptr, nullptr, 0, c->logits_ws, g.vocab_size, 1, g.vocab_size, H, EPI_NONE, 1, GEMM_AUTO, c->lm_head_p); if (rc) return rc;
-    HIPCHK(c, launch_argmax_penalty(c->logits_ws, g.vocab_size, c->prev_dev, pen ? np : 0, pen ? rep_penalty : 1.f, c->tok_dev, st, dyn));
+    HIPCHK(c, launch_argmax_penalty(c->logits_ws, g.vocab_size, c->prev_dev, pen ? np : 0, pen ? rep_penalty : 1.f, c->tok_dev, st, dyn, c->argmax_scratch));
     if (dyn) HIPCHK(c, launch_advance_state(c->step_dev, c->tok_dev, c->prev_dev, c->prev_cap, eos_id, pen ? 1 : 0, st));
     return MMD_OK;
 }
@@ -787,7 +788,7 @@ extern "C" int mmd_greedy_generate(mmd_ctx* c, mmd_stream* s, const void* prompt
         const void* last = (const char*)c->l_hid + (size_t)(S - 1) * H * e;
         rc = gemm(c, last, H, c->lm_head, H, nullptr, nullptr, 0, c->logits_ws, g.vocab_size, 1, g.vocab_size, H, EPI_NONE, 1, GEMM_AUTO, c->lm_head_p); if (rc) return rc;
         ProfScope ps(c, MMD_K_OTHER, 0, 0);
-        HIPCHK(c, launch_argmax_penalty(c->logits_ws, g.vocab_size, c->prev_dev, pen ? np : 0, pen ? rep_penalty : 1.f, c->tok_dev, st, nullptr));
+        HIPCHK(c, launch_argmax_penalty(c->logits_ws, g.vocab_size, c->prev_dev, pen ? np : 0, pen ? rep_penalty : 1.f, c->tok_dev, st, nullptr, c->argmax_scratch));
     }
     int64_t tok = 0;
     rc = read_token(&tok); if (rc) return rc;

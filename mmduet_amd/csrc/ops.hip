@@ -433,36 +433,56 @@ hipError_t launch_heads(int dtype, const void* hidden, int64_t ldh, const int32_
 // generation/logits_process.py) + argmax (first maximal index, like torch.argmax) -- models/modeling_live.py:60-72.
 // Single block; V up to a few 100k.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void argmax_penalty_kernel(const float* __restrict__ logits, int V, const int64_t* __restrict__ prev, int n_prev, float penalty,
-                                      int64_t* __restrict__ out_id, const StepState* __restrict__ dyn) {
-    __shared__ float sv[16]; __shared__ int si[16];
+// two stages (V = 152064: one block would crawl through 600 KB alone): ARGMAX_BLOCKS blocks reduce their slice to a
+// (value, index) candidate, one block picks the winner; ties -> smallest index, like torch.argmax
+#define ARGMAX_BLOCKS 64
+__device__ __forceinline__ bool better(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
+
+__global__ __launch_bounds__(256) void argmax_penalty_kernel(const float* __restrict__ logits, int V, const int64_t* __restrict__ prev, int n_prev, float penalty,
+                                                             float* __restrict__ cand_v, int* __restrict__ cand_i, const StepState* __restrict__ dyn) {
+    __shared__ float sv[4]; __shared__ int si[4];
     if (dyn && penalty != 1.f) n_prev = dyn->n_prev;
+    const int per = (V + gridDim.x - 1) / gridDim.x;
+    const int beg = blockIdx.x * per, end = min(V, beg + per);
     float best = -INFINITY; int bi = 0x7fffffff;
-    for (int i = threadIdx.x; i < V; i += blockDim.x) {
+    for (int i = beg + threadIdx.x; i < end; i += blockDim.x) {
         float v = logits[i];
         if (n_prev > 0) {
             bool seen = false;
             for (int j = 0; j < n_prev; ++j) if (prev[j] == i) { seen = true; break; }
             if (seen) v = v < 0.f ? v * penalty : v / penalty;
         }
-        if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+        if (better(v, i, best, bi)) { best = v; bi = i; }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         float ov = __shfl_xor(best, o, 64); int oi = __shfl_xor(bi, o, 64);
-        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        if (better(ov, oi, best, bi)) { best = ov; bi = oi; }
     }
-    int w = threadIdx.x >> 6;
+    const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { sv[w] = best; si[w] = bi; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int k = 1; k < (int)(blockDim.x >> 6); ++k) if (sv[k] > best || (sv[k] == best && si[k] < bi)) { best = sv[k]; bi = si[k]; }
-        *out_id = bi;
+        for (int k = 1; k < 4; ++k) if (better(sv[k], si[k], best, bi)) { best = sv[k]; bi = si[k]; }
+        cand_v[blockIdx.x] = best; cand_i[blockIdx.x] = bi;
     }
 }
+__global__ void argmax_final_kernel(const float* __restrict__ cand_v, const int* __restrict__ cand_i, int n, int64_t* __restrict__ out_id) {
+    float best = -INFINITY; int bi = 0x7fffffff;
+    const int lane = threadIdx.x;
+    if (lane < n) { best = cand_v[lane]; bi = cand_i[lane]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float ov = __shfl_xor(best, o, 64); int oi = __shfl_xor(bi, o, 64);
+        if (better(ov, oi, best, bi)) { best = ov; bi = oi; }
+    }
+    if (lane == 0) *out_id = bi;
+}
 hipError_t launch_argmax_penalty(const float* logits, int V, const int64_t* prev_ids_dev, int n_prev, float penalty, int64_t* out_id, hipStream_t st,
-                                 const StepState* dyn) {
-    hipLaunchKernelGGL(argmax_penalty_kernel, dim3(1), dim3(1024), 0, st, logits, V, prev_ids_dev, n_prev, penalty, out_id, dyn);
+                                 const StepState* dyn, void* scratch) {
+    float* cand_v = (float*)scratch; int* cand_i = (int*)((char*)scratch + ARGMAX_BLOCKS * sizeof(float));      // >= 512 bytes of context scratch
+    hipLaunchKernelGGL(argmax_penalty_kernel, dim3(ARGMAX_BLOCKS), dim3(256), 0, st, logits, V, prev_ids_dev, n_prev, penalty, cand_v, cand_i, dyn);
+    hipLaunchKernelGGL(argmax_final_kernel, dim3(1), dim3(64), 0, st, cand_v, cand_i, ARGMAX_BLOCKS, out_id);
     return hipGetLastError();
 }
 
