@@ -12,6 +12,8 @@
 // activation / residual add / gate*up product (no-ops in fp32).
 #include "common.h"
 
+#define MMD_BAR() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+
 struct GemmP {
     const void* X; const void* W; const void* bias; const void* R; void* Y; float* ws;
     long long ldx, ldw, ldr, ldy;
@@ -697,7 +699,6 @@ static void launch_big(const GemmP& p, const GemmArgs& a, hipStream_t st) {
 // (group 0 at the end of its MFMA phase 3, group 1 at the end of its MFMA phase 2); a stage is refilled at the earliest
 // two barriers after its last fragment read.  One __shared__ array, no __syncthreads() (it would drain the DMA queue).
 // ------------------------------------------------------------------------------------------------------------------
-#define MMD_BAR() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_big256_kernel(GemmP p, int KT) {
