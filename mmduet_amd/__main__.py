@@ -5,6 +5,7 @@ The reference decodes videos with OpenCV inside its dataset class (test/datasets
 package, so `--test_fname` is a JSON list whose entries carry the already sampled, letter-boxed frames:
     {"question_id": ..., "frames": "clip0.npy" (uint8 [T,3,R,R], relative to --input_dir), "fps": 1.0,
      "video_duration": 30.0, "conversation": [{"role": "user", "content": "...", "time": 0.0}, ...]}
+`--evaluator_format true` writes debug_data in the deprecated shape `test/evaluate.py --func grounding|qvh_highlight` reads.
 Everything else (flags, JSONL output format, `--start_idx/--end_idx` sharding, skip-on-unreadable) follows the reference.
 With torchrun, entries are sharded over the ranks (`i % world == rank`) and every rank writes `<output_fname>.rank<r>`.
 """
@@ -42,7 +43,8 @@ def main(argv=None):
             infer.input_video_stream(frames)
             infer.input_query_stream(conversation)
             responses = infer.inference()
-            rec = result_record(ex['question_id'], responses, ex.get('video_duration', len(frames) / infer.frame_fps), infer.debug_data_list)
+            rec = result_record(ex['question_id'], responses, ex.get('video_duration', len(frames) / infer.frame_fps), infer.debug_data_list,
+                                evaluator_format=args.evaluator_format)
             f_out.write(json.dumps(rec) + '\n')
             if n % 5 == 0:
                 f_out.flush()

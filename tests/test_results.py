@@ -1,6 +1,16 @@
 import json
 import torch
-from mmduet_amd.results import result_record, smooth_pred_list, normalize_pred_list, save_frame_features, load_frame_features
+import math, os
+import pytest
+from mmduet_amd.results import (result_record, smooth_pred_list, normalize_pred_list, save_frame_features, load_frame_features,
+                                is_time_in_span, keep_longest_true_span, calculate_iou, calculate_iou_span, qvh_to_charades_format,
+                                grounding_sweep, qvh_saliency_scores, GROUNDING_THRESHOLDS)
+
+GOLD = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'eval_feed.json')))
+
+
+def _same(a, b, tol=1e-12):
+    return (math.isnan(a) and math.isnan(b)) or abs(a - b) <= tol
 
 
 def test_result_record_live_and_legacy_keys():
@@ -10,6 +20,8 @@ def test_result_record_live_and_legacy_keys():
     assert rec['debug_data'][1]['relevance_score_pair'] == [0.75, 0.25]          # the evaluator reads ['relevance_score'][1]-style pairs
     json.dumps(rec)
     assert 'video_time' not in result_record('q', [], 1.0, dbg, legacy_keys=False)['debug_data'][0]
+    ev = result_record('q', [], 1.0, dbg, evaluator_format=True)['debug_data']     # the shape test/evaluate.py:319-325 reads
+    assert ev[1]['relevance_score'] == [0.75, 0.25] and ev[1]['video_time'] == 1.0 and 'time' not in ev[1]
 
 
 def test_score_postprocessing_matches_reference_formulas():
@@ -25,3 +37,37 @@ def test_feature_file_roundtrip(tmp_path):
     save_frame_features(tmp_path / 'v.pt', x)
     y = load_frame_features(tmp_path / 'v.pt', 4, device='cpu')
     assert y.shape == (3, 4, 8) and torch.allclose(y.float(), x.reshape(3, 4, 8), atol=2e-2)
+
+
+@pytest.mark.parametrize('ci', range(len(GOLD['cases'])))
+def test_evaluator_feed_matches_reference_outputs(ci):
+    """Golden: the reference's own helpers run on seeded streams (tests/golden/make_eval_golden.py)."""
+    c = GOLD['cases'][ci]
+    assert [is_time_in_span(t, c['spans']) for t in c['times']] == c['gold']
+    live = [{'time': t, 'informative_score': 0.0, 'relevance_score': s} for t, s in zip(c['times'], c['scores'])]
+    for fmt in ({'legacy_keys': False}, {'legacy_keys': True}, {'evaluator_format': True}):
+        dbg = result_record('q', [], c['times'][-1], live, ndigits=6, **fmt)['debug_data']
+        for w, g in c['windows'].items():
+            w = int(w)
+            sm = smooth_pred_list(c['scores'], w)
+            assert all(_same(a, b) for a, b in zip(sm, g['smooth']))
+            assert all(_same(a, b) for a, b in zip(normalize_pred_list(sm), g['normalized']))
+            sweep = grounding_sweep(dbg, c['spans'], w)
+            assert len(sweep) == len(GROUNDING_THRESHOLDS) == 21
+            for th, iou in sweep.items():
+                assert _same(iou, g['iou'][f'{th:.2f}'])
+            nm = normalize_pred_list(sm)
+            for th, iou in g['iou_longest_span'].items():
+                assert _same(calculate_iou(nm, c['gold'], float(th), pred_get_largest_span=True), iou)
+            sal = qvh_saliency_scores(dbg, w)
+            assert len(sal) == len(g['saliency']) and all(_same(a, b, 1e-9) for a, b in zip(sal, g['saliency']))
+
+
+def test_span_helpers_match_reference_outputs():
+    for e in GOLD['longest_span']:
+        mask, n = keep_longest_true_span(e['in'])
+        assert [mask, n] == e['out']
+    for e in GOLD['span_iou']:
+        assert _same(calculate_iou_span(e['pred'], e['gold']), e['iou'])
+    for e in GOLD['qvh_to_charades']:
+        assert qvh_to_charades_format(json.loads(json.dumps(e['in'])))['timestamps'] == e['timestamps']
