@@ -91,6 +91,13 @@ int mmd_vit_debug_tap(mmd_ctx* ctx, int stage, void* out, int64_t out_elems);
 /* replaces image_processor.preprocess (test/inference.py:203; LLaVA SigLipImageProcessor): uint8 [T,3,R,R] ->
  * PIL-bicubic resize to img x img (bit-exact with Pillow's 8-bit resampler), x/255, (x-.5)/.5 -> ctx dtype. */
 int mmd_preprocess_frames(mmd_ctx* ctx, const uint8_t* frames, int T, int R, void* pixel_values);
+/* replaces the per-frame resize + pad + colour flip of load_video (test/datasets.py:52-71, demo/liveinfer.py:32-51):
+ * decoded frames uint8 [T,H,W,3] (device) -> cv2.resize(INTER_LINEAR, 8-bit fixed point) to the letterbox size ->
+ * cv2.copyMakeBorder(BORDER_CONSTANT, pad_color[3], in SOURCE channel order) -> cv2.cvtColor(BGR2RGB) when flip_channels
+ * -> CHW, out uint8 [T,3,R,R].  Geometry (target size and the four pad widths) as the reference computes it. */
+int mmd_letterbox_geometry(int W, int H, int R, int* new_w, int* new_h, int* top, int* bottom, int* left, int* right);
+int mmd_letterbox_frames(mmd_ctx* ctx, const uint8_t* frames, int T, int H, int W, int R, const uint8_t* pad_color,
+                         int flip_channels, uint8_t* out);
 
 /* ---- language side -------------------------------------------------------------------------------------------- */
 /* replaces model.get_input_embeddings()(ids) (test/inference.py:236,251,259; models/modeling_live.py:76). ids: device int64 */

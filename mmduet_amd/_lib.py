@@ -48,6 +48,8 @@ _SIGS = {
     'mmd_vit_encode': (_I, [_VP, _VP, _I, _VP]),
     'mmd_vit_debug_tap': (_I, [_VP, _I, _VP, _I64]),
     'mmd_preprocess_frames': (_I, [_VP, _VP, _I, _I, _VP]),
+    'mmd_letterbox_geometry': (_I, [_I, _I, _I] + [C.POINTER(_I)] * 6),
+    'mmd_letterbox_frames': (_I, [_VP, _VP, _I, _I, _I, _I, _VP, _I, _VP]),
     'mmd_embed_tokens': (_I, [_VP, _VP, _I, _VP]),
     'mmd_stream_create': (_I, [_VP, _I64, C.POINTER(_VP)]),
     'mmd_stream_destroy': (None, [_VP]),

@@ -127,6 +127,8 @@ hipError_t launch_copy_rows(int dtype, const void* src, int64_t lds_, void* dst,
 hipError_t launch_interleave16(int dtype, const void* a, const void* b, void* out, int rows, int cols, hipStream_t st);
 hipError_t launch_pad_cols(int dtype, const void* src, int rows, int cols, void* dst, int cols_pad, hipStream_t st);
 hipError_t launch_lora_merge(int dtype, void* W, const float* A, const float* B, int out_f, int in_f, int r, float scale, hipStream_t st);
+hipError_t launch_letterbox(const uint8_t* src, int T, int H, int W, int new_w, int new_h, int R, int top, int left, const int32_t* xtab,
+                            const int32_t* ytab, int area2x, int flip, uint32_t pad, uint8_t* dst, hipStream_t st);
 hipError_t launch_preprocess(int dtype, const uint8_t* frames, int T, int R, int size, const int32_t* coef, const int32_t* bounds, int ksize,
                              uint8_t* tmp, void* out, hipStream_t st);
 

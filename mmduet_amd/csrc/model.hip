@@ -7,6 +7,7 @@
 //       mmd_video_heads + mmd_lm_head
 //   fast_greedy_generate (models/modeling_live.py:51-77) -> mmd_greedy_generate
 #include "common.h"
+#include <cfloat>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -67,6 +68,7 @@ struct mmd_ctx {
     // pinned staging
     float* heads_host = 0; int32_t* rows_host = 0; int64_t* tok_host = 0;
     // preprocess tables
+    int lb_W = 0, lb_H = 0, lb_R = 0; int32_t* lb_xtab = 0; int32_t* lb_ytab = 0;      // letterbox tap tables (mmd_letterbox_frames)
     int pp_R = 0; int32_t* pp_coef = 0; int32_t* pp_bounds = 0; int pp_ksize = 0; uint8_t* pp_tmp = 0; size_t pp_tmp_bytes = 0;
     int last_vit_B = 0;
     // graph-captured decode step (one per context; per-call state lives in *step_dev)
@@ -549,6 +551,73 @@ extern "C" int mmd_preprocess_frames(mmd_ctx* c, const uint8_t* frames, int T, i
     }
     ProfScope ps(c, MMD_K_OTHER, 0, 0);
     HIPCHK(c, launch_preprocess(c->cfg.dtype, frames, T, R, size, c->pp_coef, c->pp_bounds, c->pp_ksize, c->pp_tmp, pixel_values, c->stream));
+    return MMD_OK;
+}
+
+// OpenCV's 8-bit INTER_LINEAR tap table for one axis (imgproc/resize.cpp, resize() -> ResizeLinear setup):
+//   f = (float)((d + 0.5) * scale - 0.5); s = floor(f); f -= s; weights = saturate_cast<short>(w * 2048) (round half to even).
+// The x axis clamps the tap pair at the borders (s < 0 -> s = 0, f = 0; s >= n-1 -> s = n-1, f = 0); the y axis keeps f and
+// clips the two row indices instead.  Entry: {s0, s1, w0, w1}.
+static void cv_linear_taps(int src_n, int dst_n, bool x_axis, std::vector<int32_t>& tab) {
+    const double inv_scale = (double)dst_n / src_n, scale = 1.0 / inv_scale;
+    tab.resize((size_t)dst_n * 4);
+    for (int d = 0; d < dst_n; ++d) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = (int)floorf(f);
+        f -= (float)s;
+        int s0, s1;
+        if (x_axis) {
+            if (s < 0) { f = 0.f; s = 0; }
+            if (s >= src_n - 1) { f = 0.f; s = src_n - 1; }
+            s0 = s; s1 = s + 1 < src_n ? s + 1 : src_n - 1;
+        } else {
+            s0 = s < 0 ? 0 : (s < src_n ? s : src_n - 1);
+            s1 = s + 1 < 0 ? 0 : (s + 1 < src_n ? s + 1 : src_n - 1);
+        }
+        const float w0 = (1.f - f) * 2048.f, w1 = f * 2048.f;
+        long r0 = lrintf(w0), r1 = lrintf(w1);
+        r0 = r0 < -32768 ? -32768 : (r0 > 32767 ? 32767 : r0); r1 = r1 < -32768 ? -32768 : (r1 > 32767 ? 32767 : r1);
+        tab[4 * d] = s0; tab[4 * d + 1] = s1; tab[4 * d + 2] = (int32_t)r0; tab[4 * d + 3] = (int32_t)r1;
+    }
+}
+
+extern "C" int mmd_letterbox_geometry(int W, int H, int R, int* new_w, int* new_h, int* top, int* bottom, int* left, int* right) {
+    if (W <= 0 || H <= 0 || R <= 0) return MMD_EINVAL;
+    int nw, nh;
+    if (W > H) { nw = R; nh = (int)(((double)H / (double)W) * R); }       // test/datasets.py:53-60
+    else { nh = R; nw = (int)(((double)W / (double)H) * R); }
+    if (new_w) *new_w = nw; if (new_h) *new_h = nh;
+    if (top) *top = (R - nh) / 2; if (bottom) *bottom = (R - nh + 1) / 2;
+    if (left) *left = (R - nw) / 2; if (right) *right = (R - nw + 1) / 2;
+    return MMD_OK;
+}
+
+extern "C" int mmd_letterbox_frames(mmd_ctx* c, const uint8_t* frames, int T, int H, int W, int R, const uint8_t* pad_color, int flip_channels,
+                                    uint8_t* out) {
+    if (!c || !frames || !out) return MMD_EINVAL;
+    hipSetDevice(c->device);
+    if (T <= 0) return MMD_OK;
+    int nw, nh, top, left;
+    int rc = mmd_letterbox_geometry(W, H, R, &nw, &nh, &top, nullptr, &left, nullptr); if (rc) return rc;
+    if (nw <= 0 || nh <= 0) FAIL(c, MMD_EINVAL, "letterbox: %dx%d frame collapses at resolution %d", W, H, R);
+    if (c->lb_W != W || c->lb_H != H || c->lb_R != R) {
+        std::vector<int32_t> xt, yt;
+        cv_linear_taps(W, nw, true, xt); cv_linear_taps(H, nh, false, yt);
+        if (c->lb_xtab) { dev_free(c, c->lb_xtab); dev_free(c, c->lb_ytab); c->lb_xtab = c->lb_ytab = nullptr; }
+        rc = dev_alloc(c, (void**)&c->lb_xtab, xt.size() * 4); if (rc) return rc;
+        rc = dev_alloc(c, (void**)&c->lb_ytab, yt.size() * 4); if (rc) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->lb_xtab, xt.data(), xt.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->lb_ytab, yt.data(), yt.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->lb_W = W; c->lb_H = H; c->lb_R = R;
+    }
+    // resize.cpp: INTER_LINEAR with both scales exactly 2 is routed to the 2x2 INTER_AREA kernel
+    const double sx = 1.0 / ((double)nw / W), sy = 1.0 / ((double)nh / H);
+    const int area2x = (fabs(sx - 2.0) < DBL_EPSILON && fabs(sy - 2.0) < DBL_EPSILON) ? 1 : 0;
+    uint32_t pad = 0;
+    if (pad_color) pad = (uint32_t)pad_color[0] | ((uint32_t)pad_color[1] << 8) | ((uint32_t)pad_color[2] << 16);
+    ProfScope ps(c, MMD_K_OTHER, 0, 0);
+    HIPCHK(c, launch_letterbox(frames, T, H, W, nw, nh, R, top, left, c->lb_xtab, c->lb_ytab, area2x, flip_channels ? 1 : 0, pad, out, c->stream));
     return MMD_OK;
 }
 

@@ -640,3 +640,57 @@ hipError_t launch_preprocess(int dtype, const uint8_t* frames, int T_, int R, in
     else hipLaunchKernelGGL(resize_v_norm_kernel<bf16_t>, dim3(cdiv(n2, 256)), dim3(256), 0, st, vsrc, R, size, coef, bounds, ksize, (bf16_t*)out, planes, identity);
     return hipGetLastError();
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// letterbox -- the resize + pad + channel flip of the reference's load_video (test/datasets.py:52-71,
+// demo/liveinfer.py:32-51): cv2.resize(frame, (new_w, new_h)) [INTER_LINEAR, 8-bit], cv2.copyMakeBorder(constant),
+// cv2.cvtColor(BGR2RGB), HWC -> CHW.  One thread per output pixel; the resize is OpenCV's published 8-bit fixed-point
+// bilinear (imgproc/resize.cpp: 11-bit tap weights as shorts, horizontal pass kept at 2^11 scale in int, vertical pass
+// ((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2), and its exact-2x shortcut (INTER_LINEAR -> 2x2 INTER_AREA,
+// (a+b+c+d+2)>>2).  Tap tables (xofs/alpha, yofs/beta) are built on the host with OpenCV's float arithmetic (model.hip).
+// src [T][H][W][3] uint8, dst [T][3][R][R] uint8.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void letterbox_kernel(const uint8_t* __restrict__ src, int H, int W, int new_w, int new_h, int R, int top, int left,
+                                 const int32_t* __restrict__ xtab, const int32_t* __restrict__ ytab, int area2x, int flip,
+                                 uint32_t pad, uint8_t* __restrict__ dst, long long total) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int x = (int)(i % R), y = (int)((i / R) % R);
+    const long long t = i / ((long long)R * R);
+    const int rx = x - left, ry = y - top;
+    uint8_t o[3];
+    if (rx < 0 || rx >= new_w || ry < 0 || ry >= new_h) {
+        o[0] = pad & 255; o[1] = (pad >> 8) & 255; o[2] = (pad >> 16) & 255;
+    } else {
+        const uint8_t* f = src + t * (long long)H * W * 3;
+        if (area2x) {
+            const uint8_t* r0 = f + ((long long)(2 * ry) * W + 2 * rx) * 3;
+            const uint8_t* r1 = r0 + (long long)W * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o[c] = (uint8_t)(((int)r0[c] + r0[3 + c] + r1[c] + r1[3 + c] + 2) >> 2);
+        } else {
+            const int sx0 = xtab[4 * rx], sx1 = xtab[4 * rx + 1], a0 = xtab[4 * rx + 2], a1 = xtab[4 * rx + 3];
+            const int sy0 = ytab[4 * ry], sy1 = ytab[4 * ry + 1], b0 = ytab[4 * ry + 2], b1 = ytab[4 * ry + 3];
+            const uint8_t* r0 = f + (long long)sy0 * W * 3;
+            const uint8_t* r1 = f + (long long)sy1 * W * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int h0 = (int)r0[sx0 * 3 + c] * a0 + (int)r0[sx1 * 3 + c] * a1;
+                const int h1 = (int)r1[sx0 * 3 + c] * a0 + (int)r1[sx1 * 3 + c] * a1;
+                const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+                o[c] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+            }
+        }
+    }
+    uint8_t* d = dst + t * 3LL * R * R + (long long)y * R + x;
+    const long long plane = (long long)R * R;
+    d[0] = o[flip ? 2 : 0]; d[plane] = o[1]; d[2 * plane] = o[flip ? 0 : 2];
+}
+hipError_t launch_letterbox(const uint8_t* src, int T_, int H, int W, int new_w, int new_h, int R, int top, int left, const int32_t* xtab,
+                            const int32_t* ytab, int area2x, int flip, uint32_t pad, uint8_t* dst, hipStream_t st) {
+    long long total = (long long)T_ * R * R;
+    if (total <= 0) return hipSuccess;
+    hipLaunchKernelGGL(letterbox_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, src, H, W, new_w, new_h, R, top, left, xtab, ytab, area2x, flip, pad, dst, total);
+    return hipGetLastError();
+}
