@@ -5,6 +5,9 @@ The reference decodes videos with OpenCV inside its dataset class (test/datasets
 package, so `--test_fname` is a JSON list whose entries carry the already sampled, letter-boxed frames:
     {"question_id": ..., "frames": "clip0.npy" (uint8 [T,3,R,R], relative to --input_dir), "fps": 1.0,
      "video_duration": 30.0, "conversation": [{"role": "user", "content": "...", "time": 0.0}, ...]}
+An entry may instead carry the decoder's raw output -- "decoded": "clip0_raw.npy" (uint8 [N,H,W,3] BGR, decode order),
+"input_fps": 29.97[, "frame_count": header value] -- and the reference's sampling + letterbox (test/datasets.py:32-85) runs on the
+GPU (video_input.load_video_frames), `--time_instruction_format` included.
 `--evaluator_format true` writes debug_data in the deprecated shape `test/evaluate.py --func grounding|qvh_highlight` reads.
 Everything else (flags, JSONL output format, `--start_idx/--end_idx` sharding, skip-on-unreadable) follows the reference.
 With torchrun, entries are sharded over the ranks (`i % world == rank`) and every rank writes `<output_fname>.rank<r>`.
@@ -30,14 +33,26 @@ def main(argv=None):
     with open(out_name, 'w') as f_out:
         for n, i in enumerate(mine):
             ex = data[i]
+            conv = [dict(t) for t in ex['conversation']]
             try:
-                frames = torch.from_numpy(np.load(os.path.join(args.input_dir, ex['frames'])))
+                if 'decoded' in ex:
+                    from .video_input import load_video_frames
+                    raw = torch.from_numpy(np.load(os.path.join(args.input_dir, ex['decoded'])))
+                    out = load_video_frames(infer.model, raw, ex['input_fps'], ex.get('frame_count'), output_fps=args.frame_fps,
+                                            resolution=args.frame_resolution, max_num_frames=args.max_num_frames,
+                                            time_instruction_format=args.time_instruction_format)
+                    frames = out[0]
+                    ex = dict(ex, fps=out[1], video_duration=out[2])
+                    if args.time_instruction_format is not None:      # test/datasets.py:97-98
+                        conv[0]['content'] = out[3] + '\n' + conv[0]['content']
+                else:
+                    frames = torch.from_numpy(np.load(os.path.join(args.input_dir, ex['frames'])))
             except Exception as e:      # test/datasets.py:102-104: unreadable videos are skipped
                 print(f"error loading {ex.get('question_id')} due to exception {e}, this example will be skipped", file=sys.stderr)
                 continue
             if args.max_num_frames:
                 frames = frames[:args.max_num_frames]
-            conversation = [{'role': 'system', 'content': args.system_prompt}] + list(ex['conversation'])
+            conversation = [{'role': 'system', 'content': args.system_prompt}] + conv
             infer.reset()
             infer.set_fps(fps=ex.get('fps', args.frame_fps))
             infer.input_video_stream(frames)

@@ -3,7 +3,9 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
-from helpers import hip_model, stream_cases, run_stream_case
+import json
+import numpy as np
+from helpers import hip_model, stream_cases, run_stream_case, tokenizer_for
 from mmduet_amd.inference import LiveInferForBenchmark
 
 META = stream_cases()
@@ -40,3 +42,35 @@ def test_stream_bf16_runs_and_stays_close():
         assert got['informative_score'] == pytest.approx(exp['informative_score'], abs=5e-2)
         assert got['relevance_score'] == pytest.approx(exp['relevance_score'], abs=5e-2)
     assert len(d.past_key_values) == case['final_kv_len']
+
+
+@pytest.mark.gpu
+def test_cli_over_predecoded_and_raw_decoded_entries(tmp_path, monkeypatch):
+    """`python -m mmduet_amd`: both entry kinds (letter-boxed frames / raw decoder output + reference sampling on the GPU), JSONL
+    shape, evaluator_format, time instruction prefix."""
+    import mmduet_amd.inference as inf
+    import mmduet_amd.__main__ as cli
+    from mmduet_amd.results import grounding_sweep
+    model, cfgd, _ = hip_model('A')
+    tok = tokenizer_for(model.config)
+    monkeypatch.setattr(inf, 'build_model_and_tokenizer', lambda **kw: (model, tok))
+    R = model.config.frame_resolution
+    rng = np.random.default_rng(3)
+    np.save(tmp_path / 'clip.npy', rng.integers(0, 256, (5, 3, R, R), dtype=np.uint8))
+    np.save(tmp_path / 'raw.npy', rng.integers(0, 256, (40, 30, 50, 3), dtype=np.uint8))
+    entries = [{'question_id': 'q0', 'frames': 'clip.npy', 'fps': 1.0, 'video_duration': 5.0, 'conversation': [{'role': 'user', 'content': 'what happens?', 'time': 0.0}]},
+               {'question_id': 'q1', 'decoded': 'raw.npy', 'input_fps': 10.0, 'conversation': [{'role': 'user', 'content': 'describe', 'time': 0.0}]},
+               {'question_id': 'q2', 'frames': 'missing.npy', 'conversation': [{'role': 'user', 'content': 'x', 'time': 0.0}]}]
+    json.dump(entries, open(tmp_path / 'test.json', 'w'))
+    out = tmp_path / 'out.jsonl'
+    cli.main(['--live_version', 'test', '--llm_pretrained', 'synthetic:0', '--input_dir', str(tmp_path), '--test_fname', str(tmp_path / 'test.json'),
+              '--output_fname', str(out), '--frame_fps', '2', '--frame_resolution', str(R), '--max_num_frames', '6', '--time_instruction_format', 'vtimellm',
+              '--stream_end_prob_threshold', '0.5', '--evaluator_format', 'true', '--max_new_tokens', '4'])
+    recs = [json.loads(l) for l in open(out)]
+    assert [r['question_id'] for r in recs] == ['q0', 'q1']                       # the unreadable entry is skipped (test/datasets.py:102-104)
+    assert len(recs[0]['debug_data']) == 5 and len(recs[1]['debug_data']) == 6      # 4 s of 10-fps video at 2 fps = 8 frames, cut at max_num_frames
+    assert recs[1]['video_duration'] == 4.0
+    e = recs[1]['debug_data'][1]
+    assert e['video_time'] == 0.5 and len(e['relevance_score']) == 2 and abs(sum(e['relevance_score']) - 1) < 2e-3
+    assert recs[1]['model_response_list'][0]['content'].startswith('This is a video with 6 frames.\n')
+    assert len(grounding_sweep(recs[1]['debug_data'], [[0.5, 1.5]], 1)) == 21
