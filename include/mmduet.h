@@ -126,6 +126,20 @@ int mmd_lm_head(mmd_ctx* ctx, const void* hidden, int M, float* logits);
  * (synchronises the stream). */
 int mmd_frame_step(mmd_ctx* ctx, mmd_stream* s, const void* embeds, int S, const int32_t* head_rows_host, int n_rows,
                    float* head_logits_host);
+
+/* Multi-stream forms (no reference counterpart: the reference runs one video per process, batch 1; SURVEY.md section 7 names
+ * "batch several independent streams per GPU" as the way out of the weight-streaming regime).  Segment j = seg_rows[j]
+ * consecutive rows of `embeds`, extending streams[j] (each stream at most once): the GEMMs run ONCE over all rows -- a stream
+ * that is generating rides with its single row on the other streams' frame chunks -- RoPE/KV append/attention run per
+ * segment on its own arena.  Per-row results equal the single-stream calls up to GEMM accumulation order.
+ * mmd_frame_step_multi adds, after the step: the 4 video-head logits at head_rows -> heads_out_host [n,4] (host, ONE
+ * sync when n_head_rows > 0), the final hidden state at hidden_rows -> hidden_rows_out [n,hidden] (device, ctx dtype) and,
+ * when logits_out != NULL, lm_head over those rows in one pass -> logits_out [n,vocab] fp32 (device). */
+int mmd_llm_step_multi(mmd_ctx* ctx, mmd_stream* const* streams, const int32_t* seg_rows, int n_segs, const void* embeds, void* hidden_out);
+int mmd_frame_step_multi(mmd_ctx* ctx, mmd_stream* const* streams, const int32_t* seg_rows, int n_segs, const void* embeds,
+                         const int32_t* head_rows, int n_head_rows, float* heads_out_host,
+                         const int32_t* hidden_rows, int n_hidden_rows, void* hidden_rows_out, float* logits_out);
+
 /* replaces fast_greedy_generate (models/modeling_live.py:51-77): feeds prompt_embeds [S,hidden], then up to max_new
  * greedy steps.  prev_ids_host / n_prev: the repetition-penalty list persisted across turns (grown in place, capacity
  * prev_cap); rep_penalty <= 0 disables the penalty (and the list is not updated, like the reference).  EOS is written

@@ -706,15 +706,30 @@ static int kv_reserve(mmd_ctx* c, mmd_stream* s, int64_t need) {
 
 // dyn != nullptr: the step is being captured into the decode graph -- position and arena come from device state, no
 // host-side allocation / bookkeeping / event recording may happen here.
-static int llm_step_impl(mmd_ctx* c, mmd_stream* s, const void* embeds, int S, void* hidden_out, const StepState* dyn) {
+// One causal forward over `nseg` video streams: segment j is rows [row0, row0 + rows) of the step and extends stream j's
+// arena; every GEMM / norm runs once over all S rows, RoPE + KV append + attention run per segment on that stream's arena.
+struct StepSeg { mmd_stream* s; int row0; int rows; };
+
+static int llm_step_segs(mmd_ctx* c, const StepSeg* segs, int nseg, const void* embeds, int S, void* hidden_out, const StepState* dyn) {
     NEED_FINAL(c);
-    if (!s || s->ctx != c) FAIL(c, MMD_EINVAL, "stream does not belong to this context");
-    if (S <= 0) return MMD_OK;
+    if (S <= 0 || nseg <= 0) return MMD_OK;
     const mmd_config& g = c->cfg; const int dt = g.dtype; const size_t e = es(c); hipStream_t st = c->stream;
     if (S > g.max_step_tokens) FAIL(c, MMD_ERANGE, "step of %d tokens exceeds max_step_tokens %d", S, g.max_step_tokens);
     int rc = MMD_OK;
-    if (!dyn) { rc = kv_reserve(c, s, s->len + S); if (rc) return rc; }
+    {
+        int at = 0;
+        for (int j = 0; j < nseg; ++j) {
+            if (!segs[j].s || segs[j].s->ctx != c) FAIL(c, MMD_EINVAL, "stream does not belong to this context");
+            if (segs[j].rows <= 0 || segs[j].row0 != at) FAIL(c, MMD_EINVAL, "segments must be non-empty and consecutive");
+            for (int k = 0; k < j; ++k) if (segs[k].s == segs[j].s) FAIL(c, MMD_EINVAL, "a stream may appear once per step");
+            at += segs[j].rows;
+        }
+        if (at != S) FAIL(c, MMD_EINVAL, "segments cover %d rows of a %d-row step", at, S);
+    }
+    if (dyn && nseg != 1) FAIL(c, MMD_EINVAL, "graph decode is single-stream");
+    if (!dyn) for (int j = 0; j < nseg; ++j) { rc = kv_reserve(c, segs[j].s, segs[j].s->len + segs[j].rows); if (rc) return rc; }
     const int H = g.hidden_size, I = g.intermediate_size, nh = g.num_heads, nkv = g.num_kv_heads, d = g.head_dim;
+    mmd_stream* s = segs[0].s;                   // the single-stream (fused) schedule below works on segment 0
     const int64_t n = s->len;
     HIPCHK(c, hipMemcpyAsync(c->l_h, embeds, (size_t)S * H * e, hipMemcpyDeviceToDevice, st));
     const size_t layer_elems = kv_layer_elems(c, s->cap);
@@ -723,7 +738,7 @@ static int llm_step_impl(mmd_ctx* c, mmd_stream* s, const void* embeds, int S, v
     // slabs and the NEXT operator consumes them (reduce + bias + RoPE + KV append; reduce + residual + RMSNorm):
     // 9 launches per layer instead of 12, identical rounding points.
     bool fused = false;
-    if (dt == MMD_BF16 && S <= 64 && H <= 4096 && (H & 3) == 0 && !c->no_fuse) {
+    if (nseg == 1 && dt == MMD_BF16 && S <= 64 && H <= 4096 && (H & 3) == 0 && !c->no_fuse) {
         GemmArgs probe; memset(&probe, 0, sizeof(probe));
         probe.X = c->l_xn; probe.ldx = H; probe.Wp = c->L[0].wqkv_p; probe.M = S; probe.N = c->qkv_w; probe.K = H; probe.epi = EPI_NONE;
         probe.splitk_ws = c->splitk_ws; probe.splitk_ws_bytes = c->splitk_bytes;
@@ -755,16 +770,28 @@ static int llm_step_impl(mmd_ctx* c, mmd_stream* s, const void* embeds, int S, v
             { ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * S * H * e, 0); HIPCHK(c, launch_rmsnorm(dt, c->l_h, L.ln1, c->l_xn, S, H, g.rms_norm_eps, st)); }
             rc = gemm(c, c->l_xn, H, L.wqkv, H, L.bqkv, nullptr, 0, c->l_qkv, c->qkv_w, S, c->qkv_w, H, EPI_NONE, 0, GEMM_AUTO, L.wqkv_p); if (rc) return rc;
             ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * S * c->qkv_w * e, 0);
-            HIPCHK(c, launch_rope_append(dt, c->l_qkv, S, nh, nkv, d, c->inv_freq, n, c->l_q, Kl, Vl, s->cap, 1, st));
+            for (int j = 0; j < nseg; ++j) {
+                mmd_stream* sj = segs[j].s;
+                const size_t le = kv_layer_elems(c, sj->cap);
+                HIPCHK(c, launch_rope_append(dt, (char*)c->l_qkv + (size_t)segs[j].row0 * c->qkv_w * e, segs[j].rows, nh, nkv, d, c->inv_freq, sj->len,
+                                             (char*)c->l_q + (size_t)segs[j].row0 * nh * d * e, (char*)sj->K + (size_t)i * le * e, (char*)sj->V + (size_t)i * le * e,
+                                             sj->cap, 1, st));
+            }
         }
-        {
+        for (int j = 0; j < nseg; ++j) {
+            mmd_stream* sj = segs[j].s;
+            const size_t le = kv_layer_elems(c, sj->cap);
+            const int Sj = segs[j].rows; const int64_t nj = sj->len;
             AttnArgs a; memset(&a, 0, sizeof(a));
-            a.q = c->l_q; a.ldq = (int64_t)nh * d; a.K = Kl; a.V = Vl; a.k_hs = s->cap * d; a.k_ts = d; a.v_hs = s->cap * d; a.v_ts = d;
-            a.out = c->l_attn; a.ldo = (int64_t)nh * d; a.S = S; a.nh = nh; a.nkv = nkv; a.d = d; a.n_ctx = n; a.causal = 1; a.v_transposed = 1;
+            a.q = (char*)c->l_q + (size_t)segs[j].row0 * nh * d * e; a.ldq = (int64_t)nh * d;
+            a.K = (char*)sj->K + (size_t)i * le * e; a.V = (char*)sj->V + (size_t)i * le * e;
+            a.k_hs = sj->cap * d; a.k_ts = d; a.v_hs = sj->cap * d; a.v_ts = d;
+            a.out = (char*)c->l_attn + (size_t)segs[j].row0 * nh * d * e; a.ldo = (int64_t)nh * d;
+            a.S = Sj; a.nh = nh; a.nkv = nkv; a.d = d; a.n_ctx = nj; a.causal = 1; a.v_transposed = 1;
             a.batch = 1; a.ws = c->attn_ws; a.ws_bytes = c->attn_bytes; a.variant = 0;
             a.dyn = dyn; a.layer = i; a.dyn_splits = 64;
-            double kvb = 2.0 * (double)(n + S) * nkv * d * e;
-            ProfScope ps(c, MMD_K_ATTN_LLM, kvb + 2.0 * S * nh * d * e, 4.0 * S * (double)(n + S) * nh * d);
+            double kvb = 2.0 * (double)(nj + Sj) * nkv * d * e;
+            ProfScope ps(c, MMD_K_ATTN_LLM, kvb + 2.0 * Sj * nh * d * e, 4.0 * Sj * (double)(nj + Sj) * nh * d);
             HIPCHK(c, launch_attention(dt, a, st));
         }
         const void* next_norm = (i + 1 < g.num_layers) ? c->L[i + 1].ln1 : c->fnorm;
@@ -786,12 +813,64 @@ static int llm_step_impl(mmd_ctx* c, mmd_stream* s, const void* embeds, int S, v
     }
     if (!fused) { ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * S * H * e, 0); HIPCHK(c, launch_rmsnorm(dt, c->l_h, c->fnorm, c->l_hid, S, H, g.rms_norm_eps, st)); }
     if (hidden_out) HIPCHK(c, hipMemcpyAsync(hidden_out, c->l_hid, (size_t)S * H * e, hipMemcpyDeviceToDevice, st));
-    if (!dyn) s->len = n + S;
+    if (!dyn) for (int j = 0; j < nseg; ++j) segs[j].s->len += segs[j].rows;
     return MMD_OK;
+}
+
+static int llm_step_impl(mmd_ctx* c, mmd_stream* s, const void* embeds, int S, void* hidden_out, const StepState* dyn) {
+    if (!c) return MMD_EINVAL;
+    if (!s || s->ctx != c) FAIL(c, MMD_EINVAL, "stream does not belong to this context");
+    if (S <= 0) return MMD_OK;
+    StepSeg one{s, 0, S};
+    return llm_step_segs(c, &one, 1, embeds, S, hidden_out, dyn);
 }
 
 extern "C" int mmd_llm_step(mmd_ctx* c, mmd_stream* s, const void* embeds, int S, void* hidden_out) {
     return llm_step_impl(c, s, embeds, S, hidden_out, nullptr);
+}
+
+static int build_segs(mmd_ctx* c, mmd_stream* const* streams, const int32_t* seg_rows, int n_segs, std::vector<StepSeg>& segs, int* S_out) {
+    if (!streams || !seg_rows || n_segs <= 0) FAIL(c, MMD_EINVAL, "multi-stream step needs at least one segment");
+    int at = 0;
+    segs.resize(n_segs);
+    for (int j = 0; j < n_segs; ++j) { segs[j] = StepSeg{streams[j], at, seg_rows[j]}; at += seg_rows[j]; }
+    *S_out = at;
+    return MMD_OK;
+}
+
+extern "C" int mmd_llm_step_multi(mmd_ctx* c, mmd_stream* const* streams, const int32_t* seg_rows, int n_segs, const void* embeds, void* hidden_out) {
+    if (!c) return MMD_EINVAL;
+    std::vector<StepSeg> segs; int S = 0;
+    int rc = build_segs(c, streams, seg_rows, n_segs, segs, &S); if (rc) return rc;
+    return llm_step_segs(c, segs.data(), n_segs, embeds, S, hidden_out, nullptr);
+}
+
+extern "C" int mmd_frame_step_multi(mmd_ctx* c, mmd_stream* const* streams, const int32_t* seg_rows, int n_segs, const void* embeds,
+                                    const int32_t* head_rows, int n_head_rows, float* heads_out_host,
+                                    const int32_t* hidden_rows, int n_hidden_rows, void* hidden_rows_out, float* logits_out) {
+    if (!c) return MMD_EINVAL;
+    NEED_FINAL(c);
+    std::vector<StepSeg> segs; int S = 0;
+    int rc = build_segs(c, streams, seg_rows, n_segs, segs, &S); if (rc) return rc;
+    if (n_head_rows < 0 || n_head_rows > S || n_hidden_rows < 0 || n_hidden_rows > S) FAIL(c, MMD_EINVAL, "bad row count");
+    if ((n_head_rows && (!head_rows || !heads_out_host)) || (n_hidden_rows && (!hidden_rows || !hidden_rows_out))) FAIL(c, MMD_EINVAL, "null row/result pointer");
+    for (int i = 0; i < n_head_rows; ++i) if (head_rows[i] < 0 || head_rows[i] >= S) FAIL(c, MMD_ERANGE, "head row %d outside the step", head_rows[i]);
+    for (int i = 0; i < n_hidden_rows; ++i) if (hidden_rows[i] < 0 || hidden_rows[i] >= S) FAIL(c, MMD_ERANGE, "hidden row %d outside the step", hidden_rows[i]);
+    rc = llm_step_segs(c, segs.data(), n_segs, embeds, S, nullptr, nullptr); if (rc) return rc;
+    hipStream_t st = c->stream; const int H = c->cfg.hidden_size; const size_t e = es(c);
+    for (int i = 0; i < n_hidden_rows; ++i)
+        HIPCHK(c, hipMemcpyAsync((char*)hidden_rows_out + (size_t)i * H * e, (char*)c->l_hid + (size_t)hidden_rows[i] * H * e, (size_t)H * e, hipMemcpyDeviceToDevice, st));
+    if (n_hidden_rows && logits_out) { rc = mmd_lm_head(c, hidden_rows_out, n_hidden_rows, logits_out); if (rc) return rc; }
+    if (n_head_rows) {
+        for (int i = 0; i < n_head_rows; ++i) c->rows_host[i] = head_rows[i];
+        HIPCHK(c, hipMemcpyAsync(c->rows_dev, c->rows_host, sizeof(int32_t) * n_head_rows, hipMemcpyHostToDevice, st));
+        { ProfScope ps(c, MMD_K_OTHER, 0, 0);
+          HIPCHK(c, launch_heads(c->cfg.dtype, c->l_hid, H, c->rows_dev, n_head_rows, c->heads4, H, c->heads_dev, st)); }
+        HIPCHK(c, hipMemcpyAsync(c->heads_host, c->heads_dev, sizeof(float) * 4 * n_head_rows, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        memcpy(heads_out_host, c->heads_host, sizeof(float) * 4 * n_head_rows);
+    }
+    return MMD_OK;
 }
 
 extern "C" int mmd_video_heads(mmd_ctx* c, const void* hidden, int M, float* out) {

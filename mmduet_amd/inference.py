@@ -79,6 +79,7 @@ class LiveInferForBenchmark:
         self.frames_per_forward = max(1, int(getattr(args, 'frames_per_forward', 1)))
         self.overlap_vision = bool(getattr(args, 'overlap_vision', True))
         self._vit_stream = None
+        self.vit_lookahead_batches = None      # None: the whole video is queued on the tower stream at once
 
         self.eos_token_id = self.model.config.eos_token_id
         dev = self.device
@@ -113,8 +114,9 @@ class LiveInferForBenchmark:
         self.stream_end_prob_list = list()
         self.stream_end_score_sum = 0
         self.consecutive_n_frames = 0
-        self._frame_ready = {}
-        self._vit_keepalive = None
+        self._frame_batch = {}               # frame embedding (data_ptr) -> tower batch index, overlap mode
+        self._vit_out = self._vit_pixels = None
+        self._vit_batches, self._vit_events, self._vit_waited = [], [], set()
         self.forward_calls = 0              # LLM forwards issued (diagnostics of the chunked schedule)
         self.replayed_frames = 0
 
@@ -131,25 +133,39 @@ class LiveInferForBenchmark:
                 self.frame_embeds_queue.extend(((r + b0) / self.frame_fps, f) for r, f in enumerate(embeds))
             return
         # The tower is MFMA-bound, the LLM steps (weight streaming, token-by-token decoding) are not: encode the frames on a
-        # side HIP stream so that batch i+1 of the tower overlaps the LLM work on batch i.  Every queued frame carries the
-        # event of its batch; the LLM stream waits on it right before the frame is consumed.  Results are unchanged.
+        # side HIP stream so that batch i+1 of the tower overlaps the LLM work on batch i.  Frame embeddings are views of one
+        # pre-allocated buffer; batch b carries an event and the LLM stream waits on it right before a frame of b is
+        # consumed.  `vit_lookahead_batches` = None issues every batch now; an integer n keeps the tower n batches ahead of the
+        # LLM (several streams sharing one tower stream interleave their batches that way).  Results are unchanged.
         if self._vit_stream is None:
             lo, hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, 'priority_range') else (0, -1)
             # lowest priority for the tower: the LLM's short latency-bound kernels go first, tower tiles fill the gaps
             self._vit_stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get('MMDUET_VIT_PRIO', lo)))
         main = torch.cuda.current_stream(self.device)
         side = self._vit_stream
+        T, nt = len(video_frames), self.frame_num_tokens
+        self._vit_out = torch.empty(T * nt, self.hidden_size, dtype=self.torch_dtype, device=self.device)
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            pixel_values = self.image_processor.preprocess(video_frames, return_tensors='pt')['pixel_values'].to(self.torch_dtype)
-            for b0 in range(0, len(pixel_values), VIT_BATCH):
-                embeds = self.model.visual_embed(pixel_values[b0:b0 + VIT_BATCH])
+            self._vit_pixels = self.image_processor.preprocess(video_frames, return_tensors='pt')['pixel_values'].to(self.torch_dtype)
+        self._vit_batches = [(b0, min(T, b0 + VIT_BATCH)) for b0 in range(0, T, VIT_BATCH)]
+        self._vit_events, self._vit_waited = [], set()
+        for r in range(T):
+            f = self._vit_out[r * nt:(r + 1) * nt]
+            self._frame_batch[f.data_ptr()] = r // VIT_BATCH
+            self.frame_embeds_queue.append((r / self.frame_fps, f))
+        self._issue_vit(len(self._vit_batches) if self.vit_lookahead_batches is None else self.vit_lookahead_batches)
+
+    def _issue_vit(self, upto):
+        """Enqueue tower batches [issued, upto) on the side stream."""
+        nt = self.frame_num_tokens
+        while len(self._vit_events) < min(upto, len(self._vit_batches)):
+            b0, b1 = self._vit_batches[len(self._vit_events)]
+            with torch.cuda.stream(self._vit_stream):
+                self.model.visual_embed(self._vit_pixels[b0:b1], out=self._vit_out[b0 * nt:b1 * nt])
                 ev = torch.cuda.Event()
-                ev.record(side)
-                for r, f in enumerate(embeds.split(self.frame_num_tokens)):
-                    self._frame_ready[f.data_ptr()] = ev
-                    self.frame_embeds_queue.append(((r + b0) / self.frame_fps, f))
-            self._vit_keepalive = pixel_values          # freed (on the side stream's allocator pool) at the next reset
+                ev.record(self._vit_stream)
+            self._vit_events.append(ev)
 
     def input_query_stream(self, conversation):
         for turn in conversation:
@@ -174,13 +190,13 @@ class LiveInferForBenchmark:
     def _forward_frames(self, frames):
         """One causal forward over `frames` (list of [frame_num_tokens, hidden]); returns per-frame
         (informative_score, relevance_score) and the KV length at the end of each frame."""
-        if self._frame_ready:
-            waited = set()
-            for f in frames:
-                ev = self._frame_ready.pop(f.data_ptr(), None)
-                if ev is not None and id(ev) not in waited:
-                    torch.cuda.current_stream(self.device).wait_event(ev)
-                    waited.add(id(ev))
+        if self._frame_batch:
+            need = {self._frame_batch[f.data_ptr()] for f in frames if f.data_ptr() in self._frame_batch}
+            if need:
+                self._issue_vit(max(need) + 1 + (self.vit_lookahead_batches or 0))
+                for b in sorted(need - self._vit_waited):
+                    torch.cuda.current_stream(self.device).wait_event(self._vit_events[b])
+                    self._vit_waited.add(b)
         self.last_ids = self._prefix_ids_for_next_frame()
         prefix = self._embed(self.last_ids)
         P = prefix.shape[1]

@@ -308,11 +308,14 @@ class VideoHeadLiveLlavaQwenForCausalLM:
         """models/modeling_live.py:14-20: the tower is always inside this model."""
         return None
 
-    def visual_embed(self, frames: torch.Tensor):
-        """models/modeling_live.py:26-33 -> [B*frame_num_tokens, hidden] in the model dtype."""
+    def visual_embed(self, frames: torch.Tensor, out: torch.Tensor = None):
+        """models/modeling_live.py:26-33 -> [B*frame_num_tokens, hidden] in the model dtype (written into `out` when given)."""
         frames = frames.to(device=self.device, dtype=self.dtype).contiguous()
         B = frames.shape[0]
-        out = torch.empty(B * self.tokens_per_frame, self.config.hidden_size, dtype=self.dtype, device=self.device)
+        if out is None:
+            out = torch.empty(B * self.tokens_per_frame, self.config.hidden_size, dtype=self.dtype, device=self.device)
+        elif out.shape != (B * self.tokens_per_frame, self.config.hidden_size) or out.dtype != self.dtype or not out.is_contiguous():
+            raise ValueError('visual_embed: `out` must be a contiguous [B*frame_num_tokens, hidden] tensor of the model dtype')
         with self._lock:
             self._bind_stream()
             for b0 in range(0, B, self.max_vit_batch):
@@ -428,6 +431,69 @@ class VideoHeadLiveLlavaQwenForCausalLM:
             check(lib().mmd_frame_step(self._ctx, arena.h, _ptr(x), S, rows, len(head_rows), res), self._ctx, 'mmd_frame_step')
             cache = KVCacheHandle(arena, n + S)
         return torch.tensor(list(res), dtype=torch.float32).view(-1, 4), cache
+
+    def multi_step(self, segments, want_logits=True):
+        """ONE causal forward over several video streams (mmd_frame_step_multi): the GEMMs run once over all rows, so a stream that
+        is generating token by token rides on the other streams' frame chunks instead of streaming the weights for itself.
+
+        segments: list of dicts with
+            x          [S_i, H] / [1, S_i, H] input embeddings of this stream's rows
+            cache      its KV handle (or None)
+            head_rows  row indices (relative to the segment) whose 4 video-head logits are wanted
+            hidden     'none' | 'last' | 'all': which final hidden rows to return (and, with want_logits, run lm_head on 'last')
+        Returns, per segment, dict(heads=[n,4] fp32 CPU tensor | None, hidden=[r,H] device tensor | None,
+        logits=[1,V] fp32 device tensor | None, cache=new handle)."""
+        H = self.config.hidden_size
+        xs, seg_rows, head_rows, hid_rows, hid_slices, arenas = [], [], [], [], [], []
+        at = 0
+        for sg in segments:
+            x = sg['x'].reshape(-1, H).to(device=self.device, dtype=self.dtype)
+            S = x.shape[0]
+            if S == 0:
+                raise ValueError('empty segment')
+            xs.append(x); seg_rows.append(S)
+            head_rows += [at + int(r) for r in sg.get('head_rows', ())]
+            want = sg.get('hidden', 'none')
+            rows = [at + S - 1] if want == 'last' else (list(range(at, at + S)) if want == 'all' else [])
+            hid_slices.append((len(hid_rows), len(rows), want))
+            hid_rows += rows
+            at += S
+        if at > self.max_step_tokens:
+            raise ValueError(f'step of {at} tokens exceeds max_step_tokens={self.max_step_tokens}')
+        x_all = torch.cat(xs, dim=0).contiguous() if len(xs) > 1 else xs[0].contiguous()
+        n_seg = len(segments)
+        hidden_out = torch.empty(max(1, len(hid_rows)), H, dtype=self.dtype, device=self.device)
+        last_idx = [i for i, (o, n, w) in enumerate(hid_slices) if w == 'last']
+        # lm_head runs over the 'last' rows only; when 'all' rows are mixed in, it is done per segment afterwards
+        only_last = want_logits and last_idx and all(w in ('last', 'none') for (_, _, w) in hid_slices)
+        logits = torch.empty(len(hid_rows), self.config.vocab_size, dtype=torch.float32, device=self.device) if only_last else None
+        res = (C.c_float * (4 * max(1, len(head_rows))))()
+        with self._lock:
+            for sg in segments:
+                arena, n = self._resolve_cache(sg.get('cache'))
+                if any(a is arena for a, _ in arenas):
+                    raise ValueError('a KV arena may appear once per multi_step')
+                arenas.append((arena, n))
+            self._bind_stream()
+            streams = (C.c_void_p * n_seg)(*[a.h for a, _ in arenas])
+            rows_c = (C.c_int32 * n_seg)(*seg_rows)
+            hr = (C.c_int32 * max(1, len(head_rows)))(*head_rows)
+            hd = (C.c_int32 * max(1, len(hid_rows)))(*hid_rows)
+            check(lib().mmd_frame_step_multi(self._ctx, streams, rows_c, n_seg, _ptr(x_all), hr, len(head_rows), res, hd, len(hid_rows),
+                                             _ptr(hidden_out), _ptr(logits) if logits is not None else None), self._ctx, 'mmd_frame_step_multi')
+            caches = [KVCacheHandle(a, n + S) for (a, n), S in zip(arenas, seg_rows)]
+        heads_all = torch.tensor(list(res)[:4 * len(head_rows)], dtype=torch.float32).view(-1, 4)
+        out, hp = [], 0
+        for i, sg in enumerate(segments):
+            nh = len(sg.get('head_rows', ()))
+            o, n, want = hid_slices[i]
+            hid = hidden_out[o:o + n] if n else None
+            lg = None
+            if want == 'last' and want_logits:
+                lg = logits[o:o + 1] if logits is not None else self.lm_head(hid)
+            out.append(dict(heads=heads_all[hp:hp + nh] if nh else None, hidden=hid, logits=lg, cache=caches[i]))
+            hp += nh
+        return out
 
     def greedy_generate(self, inputs_embeds, past_key_values, eos_token_id, max_new_tokens, repetition_penalty=None,
                         generated_token_ids=None):

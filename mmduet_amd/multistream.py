@@ -1,0 +1,202 @@
+"""Several video streams per GPU, batched into shared LLM forwards.
+
+The reference runs one video per process with batch 1 (test/inference.py:341 `DataLoader(batch_size=1)`); its only seam for
+more is launching more processes.  On MI355X a single stream leaves the machine badly used while it is *generating*: every
+token streams the 14 GB of weights for one row.  With B streams resident (57 KB of KV per token: thousands of streams fit in
+288 GB) the GEMMs of one forward can carry rows of all of them -- frame chunks of the streams that are watching, one row
+of every stream that is talking -- while RoPE / KV append / attention stay per stream (mmd_frame_step_multi).  A generating
+stream then rides on the other streams' chunk GEMMs for the price of its own attention.
+
+`MultiStreamInfer` runs B unmodified `LiveInferForBenchmark` state machines ("slots").  Each slot lives in its own Python
+thread, but exactly ONE thread runs at any time (semaphore hand-off, i.e. coroutines): a slot runs its driver loop until the
+driver calls the model, posts that call as a request and parks; when every live slot is parked the scheduler merges the
+requests into one multi-stream forward, hands the results back and resumes the slots one after the other.  The driver code
+(prompt-prefix rules, thresholds, speculative chunks + replay, KV keep/drop) is the single-stream code, line for line, so
+per-stream results equal the single-stream run up to GEMM accumulation order (tests/test_gpu_multistream.py).
+"""
+import collections
+import threading
+import torch
+from .inference import LiveInferForBenchmark
+from .modeling_live import VideoHeadCausalLMOutputWithPast
+
+
+class _Request:
+    __slots__ = ('kind', 'x', 'cache', 'head_rows', 'result')
+
+    def __init__(self, kind, x, cache, head_rows=()):
+        self.kind, self.x, self.cache, self.head_rows, self.result = kind, x, cache, list(head_rows), None
+
+    @property
+    def rows(self):
+        return self.x.reshape(-1, self.x.shape[-1]).shape[0]
+
+
+class _ModelProxy:
+    """What a slot's driver sees as `model`: the real model, except that LLM forwards are posted to the scheduler."""
+
+    def __init__(self, real, slot, max_step_tokens):
+        self.__dict__.update(_real=real, _slot=slot, max_step_tokens=max_step_tokens)
+
+    def __getattr__(self, name):
+        return getattr(self._real, name)
+
+    def eval(self):
+        return self
+
+    def frame_step(self, inputs_embeds, past_key_values, head_rows):
+        r = self._slot.post(_Request('frames', inputs_embeds, past_key_values, head_rows))
+        return r['heads'], r['cache']
+
+    def __call__(self, input_ids=None, past_key_values=None, inputs_embeds=None, **kw):
+        if inputs_embeds is None:
+            inputs_embeds = self._real.joint_embed(input_ids, kw.get('frames'))
+        r = self._slot.post(_Request('forward', inputs_embeds, past_key_values))
+        return VideoHeadCausalLMOutputWithPast(self._real, r['hidden'], r['cache'])
+
+    forward = __call__
+
+    def greedy_generate(self, inputs_embeds, past_key_values, eos_token_id, max_new_tokens, repetition_penalty=None, generated_token_ids=None):
+        """models/modeling_live.py:51-77 with one scheduler round per token (same rule as mmd_greedy_generate: the EOS token is
+        written but neither fed back nor penalised; HF repetition penalty over every token generated so far in this video)."""
+        pen = float(repetition_penalty) if repetition_penalty is not None else 0.0
+        seen = generated_token_ids if (generated_token_ids is not None and pen > 0) else None
+        x, cache, ids = inputs_embeds, past_key_values, []
+        for _ in range(max_new_tokens):
+            r = self._slot.post(_Request('decode', x, cache))
+            cache = r['cache']
+            scores = r['logits'][0]
+            if seen:
+                idx = torch.as_tensor(seen, dtype=torch.long, device=scores.device)
+                picked = scores[idx]
+                scores = scores.clone()
+                scores[idx] = torch.where(picked < 0, picked * pen, picked / pen)
+            tok = int(scores.argmax(-1))
+            if seen is not None and tok != eos_token_id:
+                seen.append(tok)
+            ids.append(tok)
+            if tok == eos_token_id:
+                break
+            x = self._real.get_input_embeddings()(torch.tensor([[tok]], device=self._real.device))
+        return ids, cache
+
+
+class _Slot(threading.Thread):
+    def __init__(self, sched, index):
+        super().__init__(daemon=True, name=f'mmduet-slot{index}')
+        self.sched, self.index = sched, index
+        self.go = threading.Semaphore(0)
+        self.request, self.finished, self.error = None, False, None
+        self.driver = None
+
+    # -- called on the slot's thread ---------------------------------------------------------------------------------
+    def post(self, request):
+        self.request = request
+        self.sched.parked.release()          # hand the baton to the scheduler ...
+        self.go.acquire()                    # ... and wait for the result
+        self.request = None
+        if isinstance(request.result, BaseException):
+            raise request.result
+        return request.result
+
+    def run(self):
+        self.go.acquire()
+        try:
+            torch.cuda.set_device(self.sched.model.device)
+            with torch.no_grad():
+                while self.sched.todo:
+                    n, video = self.sched.todo.popleft()
+                    d = self.driver = self.sched._make_driver(self, video.get('args') or self.sched.args)
+                    for k, v in (video.get('driver_attrs') or {}).items():
+                        setattr(d, k, v)
+                    if video.get('fps'):
+                        d.set_fps(fps=video['fps'])
+                    d.input_video_stream(video['frames'])
+                    d.input_query_stream(video['conversation'])
+                    responses = d.inference()
+                    self.sched.results[n] = dict(responses=responses, debug_data=list(d.debug_data_list), forward_calls=d.forward_calls,
+                                                 replayed_frames=d.replayed_frames, response_token_ids=list(d.response_token_ids),
+                                                 generated_token_ids=[int(t) for t in d.generated_token_ids],
+                                                 final_kv_len=len(d.past_key_values) if d.past_key_values else 0)
+        except BaseException as e:          # surfaces in MultiStreamInfer.run()
+            self.error = e
+        finally:
+            self.finished = True
+            self.sched.parked.release()
+
+
+class MultiStreamInfer:
+    """B concurrent `LiveInferForBenchmark` streams on one GPU.
+
+    args: the driver's LiveTestArguments (every slot gets the same flags); model / tokenizer as for the single-stream driver.
+    `run(videos)`: videos = list of dict(frames=uint8 [T,3,R,R], conversation=[turns], fps=optional, args=optional per-video
+    LiveTestArguments, driver_attrs=optional dict set on the video's driver); returns, in input order, dict(responses,
+    debug_data, response_token_ids, generated_token_ids, final_kv_len, forward_calls, replayed_frames) per video."""
+
+    def __init__(self, args, model=None, tokenizer=None, n_slots=4, driver_cls=LiveInferForBenchmark, vit_lookahead_batches=2):
+        if n_slots < 1:
+            raise ValueError('n_slots must be >= 1')
+        if model is None:
+            first = driver_cls(args)
+            model, tokenizer = first.model, first.tokenizer
+        self.model, self.tokenizer, self.n_slots = model, tokenizer, n_slots
+        self.args, self.driver_cls = args, driver_cls
+        self.vit_lookahead_batches = vit_lookahead_batches
+        self.per_slot_rows = max(256, model.max_step_tokens // n_slots)
+        self.rounds = self.merged_rows = 0
+        self._vit_stream = None
+
+    def _make_driver(self, slot, args):
+        d = self.driver_cls(args, model=_ModelProxy(self.model, slot, self.per_slot_rows), tokenizer=self.tokenizer)
+        if getattr(d, 'overlap_vision', False):
+            # ONE tower stream for all slots (the tower's workspace is per context), batches issued just ahead of their use
+            if self._vit_stream is None:
+                self._vit_stream = torch.cuda.Stream(device=self.model.device, priority=0)
+            d._vit_stream = self._vit_stream
+            d.vit_lookahead_batches = self.vit_lookahead_batches
+        return d
+
+    def _execute(self, requests):
+        """Merge the parked requests into as few multi-stream forwards as the row budget allows."""
+        budget = self.model.max_step_tokens
+        group, rows = [], 0
+        groups = []
+        for r in requests:
+            if group and rows + r.rows > budget:
+                groups.append(group); group, rows = [], 0
+            group.append(r); rows += r.rows
+        if group:
+            groups.append(group)
+        for group in groups:
+            segs = [dict(x=r.x, cache=r.cache, head_rows=r.head_rows, hidden={'frames': 'none', 'forward': 'all', 'decode': 'last'}[r.kind]) for r in group]
+            try:
+                out = self.model.multi_step(segs)
+                for r, o in zip(group, out):
+                    r.result = o
+            except BaseException as e:
+                for r in group:
+                    r.result = e
+            self.rounds += 1
+            self.merged_rows += sum(r.rows for r in group)
+
+    def run(self, videos):
+        self.todo = collections.deque(enumerate(videos))
+        self.results = [None] * len(videos)
+        self.parked = threading.Semaphore(0)
+        slots = [_Slot(self, i) for i in range(min(self.n_slots, max(1, len(videos))))]
+        for s in slots:
+            s.start()
+        running = list(slots)
+        for s in running:                      # first leg of every slot: up to its first model call
+            s.go.release(); self.parked.acquire()
+        while True:
+            for s in running:
+                if s.error is not None:
+                    raise s.error
+            running = [s for s in running if not s.finished]
+            if not running:
+                break
+            self._execute([s.request for s in running])
+            for s in running:                  # strictly one thread at a time: resume, wait until it parks again or ends
+                s.go.release(); self.parked.acquire()
+        return self.results
