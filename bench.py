@@ -40,6 +40,8 @@ def parse():
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--prof-stride', type=int, default=7, help='bracket every n-th launch of the dominant kernel class with HIP events')
     p.add_argument('--no-prof', action='store_true', help='do not bracket the dominant kernel with HIP events in the timed region')
+    p.add_argument('--multi-stream', type=int, default=4, help='also measure S streams per GPU in shared forwards (reported under "multi_stream"; never the headline value)')
+    p.add_argument('--multi-frames-per-forward', type=int, default=13)
     p.add_argument('--layers', type=int, default=None, help='debug: override LLM layer count (INVALID as a measurement)')
     return p.parse_args()
 
@@ -60,6 +62,8 @@ def build(args, device):
             cfg.num_hidden_layers = args.layers
     k = max(1, args.frames_per_forward)
     step_tokens = max(256, k * cfg.frame_num_tokens + 192)
+    if getattr(args, 'multi_stream', 0):
+        step_tokens = max(step_tokens, args.multi_stream * (args.multi_frames_per_forward * cfg.frame_num_tokens + 192))
     model = VideoHeadLiveLlavaQwenForCausalLM(cfg, torch_dtype=torch.bfloat16, device=device, max_vit_batch=32, max_step_tokens=step_tokens,
                                               kv_initial_tokens=args.frames * cfg.frame_num_tokens + 4096)
     tok = build_live_tokenizer_and_update_config('synthetic:bench', cfg)
@@ -69,26 +73,57 @@ def build(args, device):
     return model, tok, cfg
 
 
-def make_driver(args, model, tok, threshold, forced=()):
-    from mmduet_amd.arguments_live import LiveTestArguments
+def bench_driver_class():
     from mmduet_amd.inference import LiveInferForBenchmark
 
     class BenchDriver(LiveInferForBenchmark):
         """The per-frame decision rule runs unchanged (score vs threshold on the host, every frame); because random-init
         heads make the number of firing frames arbitrary, the frames that respond are pinned to a fixed schedule so the
         workload (300 frame steps + R responses x max_new_tokens tokens) is the same for every build and schedule."""
-        forced_frames = frozenset(forced)
+        forced_frames = frozenset()
 
         def _decide(self, video_scores):
             fired = super()._decide(video_scores)
             return fired or (self.frame_idx in self.forced_frames)
-    a = LiveTestArguments(llm_pretrained='synthetic:bench', frame_fps=1.0, bf16=True, stream_end_prob_threshold=threshold,
-                          score_heads='informative_score', max_new_tokens=args.max_new_tokens,
-                          frames_per_forward=args.frames_per_forward, overlap_vision=not args.no_overlap,
-                          system_prompt='A multimodal AI assistant is helping users with some activities.')
-    d = BenchDriver(a, model=model, tokenizer=tok)
+    return BenchDriver
+
+
+def driver_args(args, threshold, frames_per_forward=None):
+    from mmduet_amd.arguments_live import LiveTestArguments
+    return LiveTestArguments(llm_pretrained='synthetic:bench', frame_fps=1.0, bf16=True, stream_end_prob_threshold=threshold,
+                             score_heads='informative_score', max_new_tokens=args.max_new_tokens,
+                             frames_per_forward=frames_per_forward or args.frames_per_forward, overlap_vision=not args.no_overlap,
+                             system_prompt='A multimodal AI assistant is helping users with some activities.')
+
+
+def make_driver(args, model, tok, threshold, forced=()):
+    d = bench_driver_class()(driver_args(args, threshold), model=model, tokenizer=tok)
+    d.forced_frames = frozenset(forced)
     d.eos_token_id = -1            # random weights: let every response run to the cap so the work per response is fixed
     return d
+
+
+def run_multi_stream(args, model, tok, frames, query, n_streams, frames_per_forward, steps, warmup, device):
+    """S streams per GPU through mmduet_amd.multistream (shared forwards); every stream responds at its own 4 seeded frames.
+    Returns (frames/s, ms per step, scheduler rounds per step)."""
+    from mmduet_amd.multistream import MultiStreamInfer
+    T = frames.shape[0]
+    a = driver_args(args, 1.0, frames_per_forward)
+    videos = [dict(frames=frames, conversation=[{'role': 'user', 'content': query, 'time': 0.0}],
+                   driver_attrs=dict(forced_frames=frozenset(random.Random(s).sample(range(1, T + 1), args.responses)) if args.responses > 0 else frozenset(),
+                                     eos_token_id=-1)) for s in range(n_streams)]
+    ms = MultiStreamInfer(a, model=model, tokenizer=tok, n_slots=n_streams, driver_cls=bench_driver_class())
+    for _ in range(warmup):
+        ms.run(videos)
+    torch.cuda.synchronize(device)
+    ms.rounds = 0; ms.exec_seconds = 0.0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = ms.run(videos)
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    assert all(len(r['debug_data']) == T and len(r['response_token_ids']) == args.responses for r in res)
+    return n_streams * steps * T / dt, dt / steps * 1e3, ms.rounds // steps, sum(r['replayed_frames'] for r in res), ms.exec_seconds / dt
 
 
 def run_stream(driver, frames, query):
@@ -212,6 +247,15 @@ def main():
             roof['sampling_stride'] = args.prof_stride
             roof['per_class_ms_untimed_pass'] = {k: round(v['ms'], 1) for k, v in prof_all.items()}
         cpu = None if (args.no_cpu_baseline or args.tiny or world > 1) else cpu_baseline()
+    multi = None
+    if args.multi_stream > 1:
+        # secondary measurement, outside the timed region and never the headline: S streams per GPU in shared forwards
+        fps, ms_step, rounds, replay, frac = run_multi_stream(args, model, tok, frames, query, args.multi_stream, args.multi_frames_per_forward,
+                                                              steps=1, warmup=1, device=device)
+        multi = dict(streams_per_gpu=args.multi_stream, frames_per_forward=args.multi_frames_per_forward, value=round(fps, 2), unit='frames/s (this GPU)',
+                     ms_per_step=round(ms_step, 1), forwards_per_step=rounds, replayed_frames=replay, time_in_forwards_frac=round(frac, 3),
+                     note='mmduet_amd.multistream: one LLM forward carries frame chunks and decode rows of all streams; per-stream results as single-stream')
+    if rank == 0:
         line = {
             'metric': 'video frames/sec (stream decode, 1fps 336px)', 'value': round(value, 2), 'unit': 'frames/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 2),
@@ -223,7 +267,7 @@ def main():
                        'kv_tokens_end': int(len(driver.past_key_values)), 'weights': 'random init N(0,0.02), true shapes' if not args.tiny else 'tiny',
                        'parallelism': f'dp{world} (one stream per GPU, RCCL all-gather of scores)',
                        'layers_override': args.layers},
-            'roofline': roof, 'cpu_baseline': cpu,
+            'roofline': roof, 'cpu_baseline': cpu, 'multi_stream': multi,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

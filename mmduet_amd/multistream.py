@@ -16,6 +16,7 @@ per-stream results equal the single-stream run up to GEMM accumulation order (te
 """
 import collections
 import threading
+import time
 import torch
 from .inference import LiveInferForBenchmark
 from .modeling_live import VideoHeadCausalLMOutputWithPast
@@ -77,7 +78,7 @@ class _ModelProxy:
             ids.append(tok)
             if tok == eos_token_id:
                 break
-            x = self._real.get_input_embeddings()(torch.tensor([[tok]], device=self._real.device))
+            x = self._real.get_input_embeddings()(torch.tensor([[tok]], device=getattr(self._real, 'device', 'cpu')))
         return ids, cache
 
 
@@ -102,7 +103,8 @@ class _Slot(threading.Thread):
     def run(self):
         self.go.acquire()
         try:
-            torch.cuda.set_device(self.sched.model.device)
+            if getattr(self.sched.model.device, 'type', 'cpu') == 'cuda':
+                torch.cuda.set_device(self.sched.model.device)
             with torch.no_grad():
                 while self.sched.todo:
                     n, video = self.sched.todo.popleft()
@@ -144,13 +146,14 @@ class MultiStreamInfer:
         self.vit_lookahead_batches = vit_lookahead_batches
         self.per_slot_rows = max(256, model.max_step_tokens // n_slots)
         self.rounds = self.merged_rows = 0
+        self.exec_seconds = 0.0               # time inside the merged forwards (launch + the one sync), the rest is driver host work
         self._vit_stream = None
 
     def _make_driver(self, slot, args):
         d = self.driver_cls(args, model=_ModelProxy(self.model, slot, self.per_slot_rows), tokenizer=self.tokenizer)
         if getattr(d, 'overlap_vision', False):
             # ONE tower stream for all slots (the tower's workspace is per context), batches issued just ahead of their use
-            if self._vit_stream is None:
+            if self._vit_stream is None and self.model.device.type == 'cuda':
                 self._vit_stream = torch.cuda.Stream(device=self.model.device, priority=0)
             d._vit_stream = self._vit_stream
             d.vit_lookahead_batches = self.vit_lookahead_batches
@@ -167,6 +170,7 @@ class MultiStreamInfer:
             group.append(r); rows += r.rows
         if group:
             groups.append(group)
+        t0 = time.perf_counter()
         for group in groups:
             segs = [dict(x=r.x, cache=r.cache, head_rows=r.head_rows, hidden={'frames': 'none', 'forward': 'all', 'decode': 'last'}[r.kind]) for r in group]
             try:
@@ -178,6 +182,7 @@ class MultiStreamInfer:
                     r.result = e
             self.rounds += 1
             self.merged_rows += sum(r.rows for r in group)
+        self.exec_seconds += time.perf_counter() - t0
 
     def run(self, videos):
         self.todo = collections.deque(enumerate(videos))

@@ -79,3 +79,81 @@ def test_chunk_size_respects_model_step_capacity():
     assert d._chunk_size() == 3
     d.inference()
     assert len(d.debug_data_list) == 10 and d.forward_calls == 4
+
+
+# ---- several streams in shared forwards: the scheduler's host logic, on CPU around the oracle ------------------------------
+class _OracleWithMultiStep:
+    """The oracle model plus a `multi_step` that simply loops over the segments (what mmd_frame_step_multi does in one forward)."""
+
+    def __init__(self, model):
+        self.__dict__['_m'] = model
+        self.__dict__['max_step_tokens'] = 4096
+        self.__dict__['device'] = torch.device('cpu')
+        self.__dict__['multi_calls'] = []
+
+    def __getattr__(self, name):
+        return getattr(self._m, name)
+
+    def __call__(self, *a, **k):
+        return self._m(*a, **k)
+
+    def multi_step(self, segments, want_logits=True):
+        self.multi_calls.append([s['x'].reshape(-1, s['x'].shape[-1]).shape[0] for s in segments])
+        out = []
+        for s in segments:
+            x = s['x'].reshape(1, -1, s['x'].shape[-1])
+            r = self._m(inputs_embeds=x, past_key_values=s['cache'], use_cache=True, return_dict=True)
+            rows = list(s.get('head_rows', ()))
+            heads = torch.cat([r.informative_logits[0, rows], r.relevance_logits[0, rows]], dim=-1).float() if rows else None
+            want = s.get('hidden', 'none')
+            hid = r.hidden_states[0] if want == 'all' else (r.hidden_states[0, -1:] if want == 'last' else None)
+            out.append(dict(heads=heads, hidden=hid, logits=r.logits[0, -1:].float() if want == 'last' else None, cache=r.past_key_values))
+        return out
+
+
+@pytest.mark.parametrize('n_slots,k', [(1, 1), (3, 1), (6, 3), (4, 2)])
+def test_multistream_scheduler_matches_reference_driver(n_slots, k):
+    from mmduet_amd.multistream import MultiStreamInfer
+    from helpers import stream_frames
+    base, _, _ = oracle_model('A')
+    model = _OracleWithMultiStep(base)
+    tok = tokenizer_for(base.config)
+    base.config.eos_token_id = META['eos_token_id']
+    names = list(META['cases'])
+    videos = []
+    for n in names:
+        case, opts = META['cases'][n], META['cases'][n]['opts']
+        a = make_args(frame_fps=case['fps'], system_prompt=META['system_prompt'], max_new_tokens=12,
+                      stream_end_prob_threshold=opts.get('stream_end_prob_threshold'), stream_end_score_sum_threshold=opts.get('stream_end_score_sum_threshold'),
+                      score_heads=opts.get('score_heads', 'informative_score'), remove_assistant_turns=opts.get('remove_assistant_turns', False),
+                      repetition_penalty=opts.get('repetition_penalty'), running_list_length=opts.get('running_list_length', 20), frames_per_forward=k)
+        videos.append(dict(frames=stream_frames(n), conversation=case['conversation'], args=a))
+    ms = MultiStreamInfer(videos[0]['args'], model=model, tokenizer=tok, n_slots=n_slots)
+    results = ms.run(videos)
+    for n, res in zip(names, results):
+        case = META['cases'][n]
+        assert len(res['debug_data']) == case['T']
+        for got, exp in zip(res['debug_data'], case['debug_data']):
+            assert got['informative_score'] == pytest.approx(exp['informative_score'], abs=2e-5) and got['relevance_score'] == pytest.approx(exp['relevance_score'], abs=2e-5)
+        assert res['response_token_ids'] == case['generated'] and res['final_kv_len'] == case['final_kv_len'] and res['generated_token_ids'] == case['penalty_ids']
+        assert [(r['role'], r['content']) for r in res['responses']] == [(r['role'], r['content']) for r in case['responses']]
+    widths = [len(c) for c in model.multi_calls]
+    assert max(widths) == min(n_slots, len(names))                       # the forwards really carried one segment per live slot
+    if n_slots > 1:
+        assert any(1 in c and max(c) > 1 for c in model.multi_calls)     # a generating stream (1 row) rode with other streams' rows
+    assert ms.rounds == len(model.multi_calls)
+
+
+def test_multistream_scheduler_propagates_errors():
+    from mmduet_amd.multistream import MultiStreamInfer
+    from helpers import stream_frames
+    base, _, _ = oracle_model('A')
+    model = _OracleWithMultiStep(base)
+    def boom(segments, want_logits=True):
+        raise RuntimeError('device fault')
+    model.__dict__['multi_step'] = boom
+    case = META['cases']['grounding_q0']
+    a = make_args(frame_fps=case['fps'], system_prompt=META['system_prompt'], stream_end_prob_threshold=2.0)
+    ms = MultiStreamInfer(a, model=model, tokenizer=tokenizer_for(base.config), n_slots=2)
+    with pytest.raises(RuntimeError, match='device fault'):
+        ms.run([dict(frames=stream_frames('grounding_q0'), conversation=case['conversation'])] * 2)
