@@ -10,6 +10,7 @@ An entry may instead carry the decoder's raw output -- "decoded": "clip0_raw.npy
 GPU (video_input.load_video_frames), `--time_instruction_format` included.
 `--evaluator_format true` writes debug_data in the deprecated shape `test/evaluate.py --func grounding|qvh_highlight` reads.
 Everything else (flags, JSONL output format, `--start_idx/--end_idx` sharding, skip-on-unreadable) follows the reference.
+`--streams_per_gpu S` runs S videos at a time through shared LLM forwards (mmduet_amd/multistream.py), same records.
 With torchrun, entries are sharded over the ranks (`i % world == rank`) and every rank writes `<output_fname>.rank<r>`.
 """
 import json, os, sys
@@ -30,36 +31,54 @@ def main(argv=None):
     mine = shard_indices(len(data), rank, world)
     infer = LiveInferForBenchmark(args)
     out_name = args.output_fname if world == 1 else f'{args.output_fname}.rank{rank}'
+    def load(ex):
+        """One test entry -> (frames uint8 [T,3,R,R], fps, duration, conversation) or None when unreadable (test/datasets.py:102-104)."""
+        conv = [dict(t) for t in ex['conversation']]
+        try:
+            if 'decoded' in ex:
+                from .video_input import load_video_frames
+                raw = torch.from_numpy(np.load(os.path.join(args.input_dir, ex['decoded'])))
+                out = load_video_frames(infer.model, raw, ex['input_fps'], ex.get('frame_count'), output_fps=args.frame_fps,
+                                        resolution=args.frame_resolution, max_num_frames=args.max_num_frames,
+                                        time_instruction_format=args.time_instruction_format)
+                frames, fps, duration = out[0], out[1], out[2]
+                if args.time_instruction_format is not None:      # test/datasets.py:97-98
+                    conv[0]['content'] = out[3] + '\n' + conv[0]['content']
+            else:
+                frames = torch.from_numpy(np.load(os.path.join(args.input_dir, ex['frames'])))
+                fps = ex.get('fps', args.frame_fps)
+                duration = ex.get('video_duration', len(frames) / fps)
+        except Exception as e:
+            print(f"error loading {ex.get('question_id')} due to exception {e}, this example will be skipped", file=sys.stderr)
+            return None
+        if args.max_num_frames:
+            frames = frames[:args.max_num_frames]
+        return frames, fps, duration, [{'role': 'system', 'content': args.system_prompt}] + conv
+
     with open(out_name, 'w') as f_out:
+        if args.streams_per_gpu > 1:
+            # several videos share every LLM forward; records are written in input order once the batch of videos is done
+            from .multistream import MultiStreamInfer
+            loaded = [(data[i], load(data[i])) for i in mine]
+            loaded = [(ex, v) for ex, v in loaded if v is not None]
+            ms = MultiStreamInfer(args, model=infer.model, tokenizer=infer.tokenizer, n_slots=args.streams_per_gpu)
+            results = ms.run([dict(frames=v[0], fps=v[1], conversation=v[3]) for _, v in loaded])
+            for (ex, v), res in zip(loaded, results):
+                rec = result_record(ex['question_id'], res['responses'], v[2], res['debug_data'], evaluator_format=args.evaluator_format)
+                f_out.write(json.dumps(rec) + '\n')
+            return
         for n, i in enumerate(mine):
             ex = data[i]
-            conv = [dict(t) for t in ex['conversation']]
-            try:
-                if 'decoded' in ex:
-                    from .video_input import load_video_frames
-                    raw = torch.from_numpy(np.load(os.path.join(args.input_dir, ex['decoded'])))
-                    out = load_video_frames(infer.model, raw, ex['input_fps'], ex.get('frame_count'), output_fps=args.frame_fps,
-                                            resolution=args.frame_resolution, max_num_frames=args.max_num_frames,
-                                            time_instruction_format=args.time_instruction_format)
-                    frames = out[0]
-                    ex = dict(ex, fps=out[1], video_duration=out[2])
-                    if args.time_instruction_format is not None:      # test/datasets.py:97-98
-                        conv[0]['content'] = out[3] + '\n' + conv[0]['content']
-                else:
-                    frames = torch.from_numpy(np.load(os.path.join(args.input_dir, ex['frames'])))
-            except Exception as e:      # test/datasets.py:102-104: unreadable videos are skipped
-                print(f"error loading {ex.get('question_id')} due to exception {e}, this example will be skipped", file=sys.stderr)
+            v = load(ex)
+            if v is None:
                 continue
-            if args.max_num_frames:
-                frames = frames[:args.max_num_frames]
-            conversation = [{'role': 'system', 'content': args.system_prompt}] + conv
+            frames, fps, duration, conversation = v
             infer.reset()
-            infer.set_fps(fps=ex.get('fps', args.frame_fps))
+            infer.set_fps(fps=fps)
             infer.input_video_stream(frames)
             infer.input_query_stream(conversation)
             responses = infer.inference()
-            rec = result_record(ex['question_id'], responses, ex.get('video_duration', len(frames) / infer.frame_fps), infer.debug_data_list,
-                                evaluator_format=args.evaluator_format)
+            rec = result_record(ex['question_id'], responses, duration, infer.debug_data_list, evaluator_format=args.evaluator_format)
             f_out.write(json.dumps(rec) + '\n')
             if n % 5 == 0:
                 f_out.flush()

@@ -36,10 +36,10 @@ class LiveInferForBenchmark:
         if model is None:
             kw = asdict(args)
             fpf, kvcap = kw.pop('frames_per_forward', 1) or 1, kw.pop('kv_capacity_tokens', 0)
-            for k in ('max_new_tokens', 'overlap_vision', 'evaluator_format'):
+            for k in ('max_new_tokens', 'overlap_vision', 'evaluator_format', 'streams_per_gpu'):
                 kw.pop(k, None)
             # workspace rows of one LLM forward follow the chunk size; the KV arena follows the flags (build_live sizes the rest)
-            kw['max_step_tokens'] = max(1024, int(fpf) * int(kw.get('frame_num_tokens', 49) or 49) + 256)
+            kw['max_step_tokens'] = max(1024, int(getattr(args, 'streams_per_gpu', 1) or 1) * (int(fpf) * int(kw.get('frame_num_tokens', 49) or 49) + 256))
             if kvcap:
                 kw['kv_initial_tokens'] = int(kvcap)
             model, tokenizer = build_model_and_tokenizer(is_training=False, set_vision_inside=True, torch_dtype=self.torch_dtype, **kw)

@@ -74,3 +74,14 @@ def test_cli_over_predecoded_and_raw_decoded_entries(tmp_path, monkeypatch):
     assert e['video_time'] == 0.5 and len(e['relevance_score']) == 2 and abs(sum(e['relevance_score']) - 1) < 2e-3
     assert recs[1]['model_response_list'][0]['content'].startswith('This is a video with 6 frames.\n')
     assert len(grounding_sweep(recs[1]['debug_data'], [[0.5, 1.5]], 1)) == 21
+    # the same entries, two videos at a time in shared forwards: same records (fp32 tiny model: scores to 1e-3 after the 3-digit rounding)
+    out2 = tmp_path / 'out2.jsonl'
+    cli.main(['--live_version', 'test', '--llm_pretrained', 'synthetic:0', '--input_dir', str(tmp_path), '--test_fname', str(tmp_path / 'test.json'),
+              '--output_fname', str(out2), '--frame_fps', '2', '--frame_resolution', str(R), '--max_num_frames', '6', '--time_instruction_format', 'vtimellm',
+              '--stream_end_prob_threshold', '0.5', '--evaluator_format', 'true', '--max_new_tokens', '4', '--streams_per_gpu', '2'])
+    recs2 = [json.loads(l) for l in open(out2)]
+    assert [r['question_id'] for r in recs2] == ['q0', 'q1']
+    for a, b in zip(recs, recs2):
+        assert a['model_response_list'] == b['model_response_list'] and len(a['debug_data']) == len(b['debug_data'])
+        for x, y in zip(a['debug_data'], b['debug_data']):
+            assert x['video_time'] == y['video_time'] and abs(x['relevance_score'][1] - y['relevance_score'][1]) <= 1.5e-3
