@@ -25,6 +25,24 @@ HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 
 MFMA_BF16_PEAK_TF = 2500.0      # dense bf16 MFMA peak
 
 
+def effective_cpus():
+    """Host cores this process may actually use: the affinity mask capped by the cgroup CPU quota (a pool box shows all
+    256 hardware threads but grants a fraction; torch would otherwise start one spinning worker per visible thread)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read()); p = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    return n
+
+
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
@@ -163,6 +181,7 @@ def cpu_baseline(budget_s=25.0):
 
 def main():
     args = parse()
+    torch.set_num_threads(max(1, effective_cpus() // max(1, int(os.environ.get('WORLD_SIZE', '1')))))   # host-side torch ops (and the CPU baseline) use the cores this process really has
     from mmduet_amd.distributed import init_distributed, gather_scores
     import torch.distributed as dist
     rank, world, local = init_distributed()

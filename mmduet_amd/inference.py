@@ -27,6 +27,12 @@ from .tokenization_live import chat_ids
 VIT_BATCH = 32          # test/inference.py:208
 
 
+def _p1(l0, l1):
+    """softmax([l0, l1])[1] (test/inference.py:243-244), evaluated in double precision and stable for any logit gap."""
+    d = l0 - l1
+    return 1.0 / (1.0 + math.exp(d)) if d < 700.0 else 0.0
+
+
 class LiveInferForBenchmark:
     def __init__(self, args, model=None, tokenizer=None) -> None:
         assert not (args.bf16 and args.fp16), "only one of --bf16 true and --fp16 true can be set"
@@ -211,8 +217,11 @@ class LiveInferForBenchmark:
             head_logits = torch.cat([out.informative_logits[0, rows], out.relevance_logits[0, rows]], dim=-1).float().cpu()
             cache = out.past_key_values
         self.forward_calls += 1
-        probs_inf = head_logits[:, 0:2].softmax(dim=-1)[:, 1].tolist()
-        probs_rel = head_logits[:, 2:4].softmax(dim=-1)[:, 1].tolist()
+        # 2-way softmax of the head logits on the host, in plain Python: a CPU torch op here wakes torch's intra-op thread pool
+        # (one spinning thread per visible core), which on a CPU-quota'd box gets the process throttled for tens of ms at a time
+        probs_inf, probs_rel = [], []
+        for l0, l1, r0, r1 in head_logits.tolist():
+            probs_inf.append(_p1(l0, l1)); probs_rel.append(_p1(r0, r1))
         ends = [n0 + P + (j + 1) * nt for j in range(len(frames))]
         return list(zip(probs_inf, probs_rel)), ends, cache
 
