@@ -135,12 +135,22 @@ def run_multi_stream(args, model, tok, frames, query, n_streams, frames_per_forw
         ms.run(videos)
     torch.cuda.synchronize(device)
     ms.rounds = 0; ms.exec_seconds = 0.0
+    if os.environ.get('MMDUET_ROUND_LOG'):
+        ms.round_log = []
     t0 = time.perf_counter()
     for _ in range(steps):
         res = ms.run(videos)
     torch.cuda.synchronize(device)
     dt = time.perf_counter() - t0
     assert all(len(r['debug_data']) == T and len(r['response_token_ids']) == args.responses for r in res)
+    if ms.round_log:
+        import collections
+        agg = collections.defaultdict(lambda: [0, 0.0, 0])
+        prev = 0.0
+        for nseg, rows, t in ms.round_log:
+            b = agg[(nseg, 'decode-only' if rows <= nseg else ('<=256' if rows <= 256 else ('<=1024' if rows <= 1024 else '>1024')))]
+            b[0] += 1; b[2] += rows
+        print('round log (segments, rows class): count, rows', {k: (v[0], v[2]) for k, v in sorted(agg.items())}, file=sys.stderr)
     return n_streams * steps * T / dt, dt / steps * 1e3, ms.rounds // steps, sum(r['replayed_frames'] for r in res), ms.exec_seconds / dt
 
 

@@ -161,7 +161,7 @@ int mmd_prof_reset(mmd_ctx* ctx);
 /* ---- raw operator entry points (parity tests call the kernels through these) ------------------------------------ */
 /* Y[M,N] = epilogue(X[M,K] . W[N,K]^T + bias).  epi: 0 none, 1 gelu(tanh), 2 gelu(erf), 3 add residual R[M,N],
  * 4 SwiGLU (W rows interleaved gate/up in blocks of 16 -> Y[M,N/2]).  out_f32 != 0 writes fp32. variant: 0 auto,
- * 1 generic tile, 2 skinny/split-K, 3 large tile. */
+ * 1 generic tile, 2 skinny/split-K, 3 large tile, 4 DMA 128-row tile, 5 skinny slabs, 6 256x256 ring. */
 int mmd_op_gemm(mmd_ctx* ctx, const void* X, const void* W, const void* bias, const void* R, void* Y, int M, int N, int K,
                 int epi, int out_f32, int variant);
 /* micro-benchmark of one GEMM shape (HIP events on the context's stream); avg ms per call incl. any split-K reduce */

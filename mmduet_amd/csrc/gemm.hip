@@ -11,6 +11,7 @@
 // Rounding points follow eager bf16 execution of the reference: linear output rounded to the storage type before the
 // activation / residual add / gate*up product (no-ops in fp32).
 #include "common.h"
+#include <type_traits>
 
 #define MMD_BAR() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 
@@ -689,25 +690,26 @@ static void launch_big(const GemmP& p, const GemmArgs& a, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// gemm_big256_kernel: 256 x 256 block tile, 8 waves (2 x 4, wave tile 128 x 64), BK = 64, two 64 KB LDS stages (128 KB).
-// Per MFMA the 256^2 tile needs half the DMA instructions and 25 % fewer LDS fragment bytes of the 128^2 kernel; the
-// remaining latency is hidden by running the two wave groups of a SIMD (waves w and w+4 share a SIMD) half a phase
-// apart: each K-tile is four phases (C quadrants of 64 x 32, 16 MFMAs each); a phase is a LOAD segment (ds_read the
-// fragments of the quadrant, issue this wave's share of the NEXT tile's DMA) and an MFMA segment, each closed by a raw
-// s_barrier.  Group 1 enters the loop one barrier late, so while one group issues MFMAs its SIMD partner reads LDS /
-// issues DMA.  DMA completion is waited per wave with s_waitcnt vmcnt(0) two barriers before any wave reads the stage
-// (group 0 at the end of its MFMA phase 3, group 1 at the end of its MFMA phase 2); a stage is refilled at the earliest
-// two barriers after its last fragment read.  One __shared__ array, no __syncthreads() (it would drain the DMA queue).
+// gemm_ring256_kernel: 256 x 256 block tile, 8 waves (2 x 4, wave tile 128 x 64: 25 % fewer LDS fragment bytes per MFMA
+// and half the DMA instructions of the 128^2 kernel).  Every wave is software-pipelined against itself and the block
+// meets at ONE barrier per BK = 32 slice.  (Its predecessor ran four barrier-separated phases per 64-wide K tile with
+// the two wave groups of a SIMD half a phase apart: 1.1-1.2 PF steady state; this loop: 1.4-1.55 PF.)  K advances through a 3-slot DMA ring (32 KB per slot): in iteration s a wave issues the 32 MFMAs of slice s
+// from registers while (a) the fragments of slice s+1 arrive -- B into the other register set, A in place (row i of A is
+// dead once its 4 MFMAs are issued) -- and (b) its 4 global_load_lds of slice s+3 refill the slot slice s just vacated;
+// the streams are interleaved explicitly with sched_group_barrier.  One s_waitcnt vmcnt(4) lgkmcnt(0) + raw s_barrier
+// per slice makes slice s+1 visible.  X pieces are 16 rows x 64 B with the 16-byte chunk index XOR-ed by g[(row>>2)&3],
+// g = {0,3,2,1} (conflict-free b128 fragment reads), W pieces are the packed MFMA fragment tiles.
+// (A 4-wave variant with 128 x 128 wave tiles -- a third fewer LDS bytes per MFMA -- needs all 256 AGPRs for its
+// accumulators and the compiler spills inside the loop; not kept.)
 // ------------------------------------------------------------------------------------------------------------------
-
 template <int EPI>
-__global__ __launch_bounds__(512) void gemm_big256_kernel(GemmP p, int KT) {
-    constexpr int BM = 256, BN = 256, BK = 64;
-    constexpr int XE = BM * BK, WE = BN * BK;                 // elements per stage image
+__global__ __launch_bounds__(512) void gemm_ring256_kernel(GemmP p, int KT) {
+    constexpr int BM = 256, BN = 256, BK = 32;
+    constexpr int XE = BM * BK, WE = BN * BK, SE = XE + WE;    // 16384 elements = 32 KB per slot
     extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4;
-    const int wr = wave >> 2, wc = wave & 3;                  // wr = wave group (M half), wc = N quarter
+    const int wr = wave >> 2, wc = wave & 3;
     const int nbx = gridDim.x, nby = gridDim.y;
     int bid = blockIdx.y * nbx + blockIdx.x;
     const int nblk = nbx * nby;
@@ -723,29 +725,29 @@ __global__ __launch_bounds__(512) void gemm_big256_kernel(GemmP p, int KT) {
     const bf16_t* Wp = (const bf16_t*)p.W;
     const int nsteps = p.K / BK;
 
-    // this wave's share of a stage: 4 X pieces (8 rows x 128 B each) + 4 W pieces (fragment tiles); `part` 0/1 issues 2 + 2
-    auto stage_part = [&](int buf, int step, int part) {
-        bf16_t* xs = lds + buf * (XE + WE);
+    const int srow = lane >> 2, spos = lane & 3;
+    const int sswz = (0x1230 >> (((srow >> 2) & 3) * 4)) & 3;
+    // per-wave DMA sources of slice 0 (2 X pieces + 2 W pieces) as 32-bit element offsets; a slice advances X by 32
+    // elements and W by one k-tile (512 elements)
+    int xo[2], wo[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int pi = wave + 8 * j;
+        int row = m0 + pi * 16 + srow; row = row < p.M ? row : p.M - 1;
+        xo[j] = row * (int)p.ldx + ((spos ^ sswz) * 8);
+        int ntile = n0 / 16 + pi; ntile = ntile < ntiles ? ntile : ntiles - 1;
+        wo[j] = (ntile * KT * 64 + lane) * 8;
+    }
+    auto stage = [&](int slot, int step) {
+        bf16_t* xs = lds + slot * SE;
         bf16_t* ws = xs + XE;
-        const int k0 = step * BK;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int pi = wave + 8 * (part * 2 + j);          // 32 X pieces
-            int row = m0 + pi * 8 + (lane >> 3);
-            row = row < p.M ? row : p.M - 1;
-            const int chunk = (lane & 7) ^ (lane >> 3);
-            const bf16_t* src = X + (long long)row * p.ldx + k0 + chunk * 8;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+            const int pi = wave + 8 * j;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + (long long)xo[j] + step * BK),
                                              (__attribute__((address_space(3))) void*)(xs + pi * 512), 16, 0, 0);
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int wi = wave + 8 * (part * 2 + j);          // 32 W pieces: (n-tile wi>>1, k-tile wi&1)
-            int ntile = n0 / 16 + (wi >> 1);
-            ntile = ntile < ntiles ? ntile : ntiles - 1;       // N tail: clamp (results masked at the store)
-            const bf16_t* src = Wp + (((long long)ntile * KT + (k0 >> 5) + (wi & 1)) * 64 + lane) * 8;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(ws + wi * 512), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wp + (long long)wo[j] + (long long)step * 512),
+                                             (__attribute__((address_space(3))) void*)(ws + pi * 512), 16, 0, 0);
         }
     };
 
@@ -754,71 +756,79 @@ __global__ __launch_bounds__(512) void gemm_big256_kernel(GemmP p, int KT) {
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0, 0, 0, 0};
-    bf16x8_t a[4][2], b0[2][2], b1[2][2];
 
-    auto load_a = [&](const bf16_t* xs, int mh) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt) {
-                const int mtile = wr * 8 + mh * 4 + i, c = kt * 4 + lq;
-                a[i][kt] = *reinterpret_cast<const bf16x8_t*>(xs + (mtile * 2 + (lr >> 3)) * 512 + (lr & 7) * 64 + ((c ^ (lr & 7)) * 8));
-            }
-    };
-    auto load_b = [&](const bf16_t* ws, int nh, bf16x8_t (&b)[2][2]) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt) b[j][kt] = *reinterpret_cast<const bf16x8_t*>(ws + ((wc * 4 + nh * 2 + j) * 2 + kt) * 512 + lane * 8);
-    };
-    auto mma = [&](int mh, int nh, const bf16x8_t (&b)[2][2]) {
+    const int rswz = (0x1230 >> (((lr >> 2) & 3) * 4)) & 3;
+    const int aoff = (wr * 8) * 512 + lr * 32 + ((lq ^ rswz) * 8);
+    const int boff = XE + (wc * 4) * 512 + lane * 8;
+    bf16x8_t a[8], b0[4], b1[4];
+    // STEADY = every condition is known true (s + 3 < nsteps): the body is ONE basic block, so the scheduler can interleave.
+    auto step = [&](auto steady, int s, int slot, const bf16x8_t (&b)[4], bf16x8_t (&bn)[4]) {
+        constexpr bool STEADY = decltype(steady)::value;
+        if (STEADY || s + 2 < nsteps) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        MMD_BAR();
+        const bool refill = STEADY || s + 3 < nsteps;
+        const bool more = STEADY || s + 1 < nsteps;
+        const bf16_t* nbase = lds + (slot == 2 ? 0 : slot + 1) * SE;
+        bf16_t* xs = lds + slot * SE;
+        bf16x8_t a6n, a7n;                 // rows 6 and 7 of the next slice travel in spare registers (issued early, see below)
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+        for (int i = 0; i < 8; ++i) {
+            // row i: its 4 MFMAs first (everything they read was waited for at the top), then -- fenced, so the scheduler cannot
+            // hoist a load above MFMAs and make the waitcnt pass drain it -- this row's share of the traffic: rows 0-5 refresh
+            // their own A row in place, rows 0-3 fetch one B fragment, rows 0-1 fetch A rows 6/7 early so the last LDS read is
+            // two rows old at the next barrier, rows 4-7 issue one DMA of slice s+3 each.
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[mh * 4 + i][nh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][kt], a[i][kt], acc[mh * 4 + i][nh * 2 + j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) {
+                if (i < 6) a[i] = *reinterpret_cast<const bf16x8_t*>(nbase + aoff + i * 512);
+                if (i < 4) bn[i] = *reinterpret_cast<const bf16x8_t*>(nbase + boff + i * 512);
+                if (i == 0) a6n = *reinterpret_cast<const bf16x8_t*>(nbase + aoff + 6 * 512);
+                if (i == 1) a7n = *reinterpret_cast<const bf16x8_t*>(nbase + aoff + 7 * 512);
+            }
+            if (refill && i >= 4) {
+                const int j = (i - 4) >> 1, pi = wave + 8 * j;
+                if ((i & 1) == 0)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + (long long)xo[j] + (s + 3) * BK),
+                                                     (__attribute__((address_space(3))) void*)(xs + pi * 512), 16, 0, 0);
+                else
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wp + (long long)wo[j] + (long long)(s + 3) * 512),
+                                                     (__attribute__((address_space(3))) void*)(xs + XE + pi * 512), 16, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (more) { a[6] = a6n; a[7] = a7n; }
         __builtin_amdgcn_s_setprio(0);
     };
 
-    // prologue: everyone stages tile 0, waits for its own DMA, one common barrier
-    stage_part(0, 0, 0); stage_part(0, 0, 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stage(0, 0);
+    if (nsteps > 1) stage(1, 1);
+    if (nsteps > 2) stage(2, 2);
+    if (nsteps > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (nsteps > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     MMD_BAR();
-    if (wr == 1) MMD_BAR();                                    // group 1 runs one barrier behind group 0
-
-    for (int t = 0; t < nsteps; ++t) {
-        const int cur = t & 1;
-        const bf16_t* xs = lds + cur * (XE + WE);
-        const bf16_t* ws = xs + XE;
-        const bool more = t + 1 < nsteps;
-        // phase 0: quadrant (m half 0, n half 0)
-        load_a(xs, 0); load_b(ws, 0, b0);
-        if (more) stage_part(cur ^ 1, t + 1, 0);
-        MMD_BAR();
-        mma(0, 0, b0);
-        MMD_BAR();
-        // phase 1: (m0, n1)
-        load_b(ws, 1, b1);
-        if (more) stage_part(cur ^ 1, t + 1, 1);
-        MMD_BAR();
-        mma(0, 1, b1);
-        MMD_BAR();
-        // phase 2: (m1, n1)
-        load_a(xs, 1);
-        MMD_BAR();
-        mma(1, 1, b1);
-        if (wr == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        MMD_BAR();
-        // phase 3: (m1, n0) -- fragments already resident
-        MMD_BAR();
-        mma(1, 0, b0);
-        if (wr == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        MMD_BAR();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(lds + aoff + i * 512);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b0[j] = *reinterpret_cast<const bf16x8_t*>(lds + boff + j * 512);
+    int slot = 0, s = 0;
+    for (; s + 4 < nsteps; s += 2) {               // steady state: both slices have s + 3 < nsteps
+        step(std::true_type{}, s, slot, b0, b1);
+        slot = slot == 2 ? 0 : slot + 1;
+        step(std::true_type{}, s + 1, slot, b1, b0);
+        slot = slot == 2 ? 0 : slot + 1;
     }
-    if (wr == 0) MMD_BAR();                                    // match group 1's extra barrier
+    for (; s < nsteps; s += 2) {                   // the last slices: conditions evaluated
+        step(std::false_type{}, s, slot, b0, b1);
+        slot = slot == 2 ? 0 : slot + 1;
+        if (s + 1 < nsteps) {
+            step(std::false_type{}, s + 1, slot, b1, b0);
+            slot = slot == 2 ? 0 : slot + 1;
+        }
+    }
 
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -833,25 +843,25 @@ __global__ __launch_bounds__(512) void gemm_big256_kernel(GemmP p, int KT) {
     }
 }
 
-static hipError_t launch_big256(const GemmP& p, const GemmArgs& a, hipStream_t st) {
+static hipError_t launch_ring256(const GemmP& p, const GemmArgs& a, hipStream_t st) {
     dim3 grid(cdiv(a.N, 256), cdiv(a.M, 256));
     const int KT = a.K >> 5;
-    const size_t smem = 2 * (256 * 64 + 256 * 64) * sizeof(bf16_t);          // 128 KB
+    const size_t smem = 3 * (256 * 32 + 256 * 32) * sizeof(bf16_t);          // 96 KB
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)gemm_big256_kernel<EPI_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipFuncSetAttribute((const void*)gemm_big256_kernel<EPI_GELU_TANH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipFuncSetAttribute((const void*)gemm_big256_kernel<EPI_GELU_ERF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipFuncSetAttribute((const void*)gemm_big256_kernel<EPI_RESID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipFuncSetAttribute((const void*)gemm_big256_kernel<EPI_SWIGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipFuncSetAttribute((const void*)gemm_ring256_kernel<EPI_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipFuncSetAttribute((const void*)gemm_ring256_kernel<EPI_GELU_TANH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipFuncSetAttribute((const void*)gemm_ring256_kernel<EPI_GELU_ERF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipFuncSetAttribute((const void*)gemm_ring256_kernel<EPI_RESID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipFuncSetAttribute((const void*)gemm_ring256_kernel<EPI_SWIGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_set = true;
     }
     switch (a.epi) {
-        case EPI_GELU_TANH: hipLaunchKernelGGL((gemm_big256_kernel<EPI_GELU_TANH>), grid, dim3(512), smem, st, p, KT); break;
-        case EPI_GELU_ERF: hipLaunchKernelGGL((gemm_big256_kernel<EPI_GELU_ERF>), grid, dim3(512), smem, st, p, KT); break;
-        case EPI_RESID: hipLaunchKernelGGL((gemm_big256_kernel<EPI_RESID>), grid, dim3(512), smem, st, p, KT); break;
-        case EPI_SWIGLU: hipLaunchKernelGGL((gemm_big256_kernel<EPI_SWIGLU>), grid, dim3(512), smem, st, p, KT); break;
-        default: hipLaunchKernelGGL((gemm_big256_kernel<EPI_NONE>), grid, dim3(512), smem, st, p, KT); break;
+        case EPI_GELU_TANH: hipLaunchKernelGGL((gemm_ring256_kernel<EPI_GELU_TANH>), grid, dim3(512), smem, st, p, KT); break;
+        case EPI_GELU_ERF: hipLaunchKernelGGL((gemm_ring256_kernel<EPI_GELU_ERF>), grid, dim3(512), smem, st, p, KT); break;
+        case EPI_RESID: hipLaunchKernelGGL((gemm_ring256_kernel<EPI_RESID>), grid, dim3(512), smem, st, p, KT); break;
+        case EPI_SWIGLU: hipLaunchKernelGGL((gemm_ring256_kernel<EPI_SWIGLU>), grid, dim3(512), smem, st, p, KT); break;
+        default: hipLaunchKernelGGL((gemm_ring256_kernel<EPI_NONE>), grid, dim3(512), smem, st, p, KT); break;
     }
     return hipGetLastError();
 }
@@ -881,13 +891,13 @@ static hipError_t launch_t(const GemmArgs& a, hipStream_t st, int* kind_out) {
     bool large = (variant == GEMM_LARGE) || (variant == GEMM_AUTO && a.M >= 256 && a.N >= 128);
     if (kind_out) *kind_out = skinny ? MMD_K_GEMM_SKINNY : MMD_K_GEMM_TILE;
     if constexpr (sizeof(T) == 2) {
-        // 256^2 tiles pay once there are >= 2 full block waves of them (ViT qkv / fc1 / projector, gate_up of a >= 1000-row chunk)
-        if (variant == GEMM_BIG256 || (variant == GEMM_AUTO && a.M >= 512 && (a.N % 32) == 0 && big_packed_ok(MMD_BF16, a, 16) &&
-                                       (long long)cdiv(a.M, 256) * cdiv(a.N, 256) >= 512 && !getenv("MMDUET_NO_BIG256"))) {
+        // 256^2 tiles pay once there are ~1.5 block waves of them (every ViT / projector GEMM, gate_up of a >= 600-row chunk)
+        if (variant == GEMM_RING256 || (variant == GEMM_AUTO && a.M >= 512 && (a.N % 32) == 0 && big_packed_ok(MMD_BF16, a, 16) &&
+                                        (long long)cdiv(a.M, 256) * cdiv(a.N, 256) >= 400 && !getenv("MMDUET_NO_RING256"))) {
             if (!big_packed_ok(MMD_BF16, a, 16) || (a.N % 32) != 0) return hipErrorInvalidValue;
             p.W = a.Wp;
             if (kind_out) *kind_out = MMD_K_GEMM_TILE;
-            return launch_big256(p, a, st);
+            return launch_ring256(p, a, st);
         }
         const bool want_big = variant == GEMM_BIG || (variant == GEMM_AUTO && a.M > 64);
         if (want_big) {

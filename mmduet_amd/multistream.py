@@ -146,6 +146,7 @@ class MultiStreamInfer:
         self.vit_lookahead_batches = vit_lookahead_batches
         self.per_slot_rows = max(256, model.max_step_tokens // n_slots)
         self.rounds = self.merged_rows = 0
+        self.round_log = None                 # set to a list to record (segments, rows, seconds) per merged forward
         self.exec_seconds = 0.0               # time inside the merged forwards (launch + the one sync), the rest is driver host work
         self._vit_stream = None
 
@@ -182,6 +183,8 @@ class MultiStreamInfer:
                     r.result = e
             self.rounds += 1
             self.merged_rows += sum(r.rows for r in group)
+            if self.round_log is not None:
+                self.round_log.append((len(group), sum(r.rows for r in group), time.perf_counter() - t0))
         self.exec_seconds += time.perf_counter() - t0
 
     def run(self, videos):
