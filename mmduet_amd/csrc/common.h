@@ -81,7 +81,7 @@ struct StepState { long long n_ctx; long long cap; void* K; void* V; int n_prev;
 
 // ---- epilogues of the GEMM family ------------------------------------------------------------------------------
 enum { EPI_NONE = 0, EPI_GELU_TANH = 1, EPI_GELU_ERF = 2, EPI_RESID = 3, EPI_SWIGLU = 4 };
-enum { GEMM_AUTO = 0, GEMM_GENERIC = 1, GEMM_SKINNY = 2, GEMM_LARGE = 3, GEMM_BIG = 4, GEMM_SLAB = 5, GEMM_RING256 = 6 };
+enum { GEMM_AUTO = 0, GEMM_GENERIC = 1, GEMM_SKINNY = 2, GEMM_LARGE = 3, GEMM_BIG = 4, GEMM_SLAB = 5, GEMM_RING256 = 6, GEMM_RING256_SPLIT = 7 };
 
 struct GemmArgs {
     const void* X; int64_t ldx;      // [M,K]

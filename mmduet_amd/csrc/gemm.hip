@@ -723,7 +723,11 @@ __global__ __launch_bounds__(512) void gemm_ring256_kernel(GemmP p, int KT) {
     const int ntiles = p.N >> 4;
     const bf16_t* X = (const bf16_t*)p.X;
     const bf16_t* Wp = (const bf16_t*)p.W;
-    const int nsteps = p.K / BK;
+    // split-K: block z covers slices [t0, t0 + nsteps) and leaves an fp32 slab for splitk_reduce_kernel
+    const int nsteps_all = p.K / BK;
+    const int zsteps = (nsteps_all + gridDim.z - 1) / gridDim.z;
+    const int t0 = blockIdx.z * zsteps;
+    const int nsteps = min(nsteps_all, t0 + zsteps) - t0;
 
     const int srow = lane >> 2, spos = lane & 3;
     const int sswz = (0x1230 >> (((srow >> 2) & 3) * 4)) & 3;
@@ -734,9 +738,9 @@ __global__ __launch_bounds__(512) void gemm_ring256_kernel(GemmP p, int KT) {
     for (int j = 0; j < 2; ++j) {
         const int pi = wave + 8 * j;
         int row = m0 + pi * 16 + srow; row = row < p.M ? row : p.M - 1;
-        xo[j] = row * (int)p.ldx + ((spos ^ sswz) * 8);
+        xo[j] = row * (int)p.ldx + ((spos ^ sswz) * 8) + t0 * BK;
         int ntile = n0 / 16 + pi; ntile = ntile < ntiles ? ntile : ntiles - 1;
-        wo[j] = (ntile * KT * 64 + lane) * 8;
+        wo[j] = (ntile * KT * 64 + lane) * 8 + t0 * 512;
     }
     auto stage = [&](int slot, int step) {
         bf16_t* xs = lds + slot * SE;
@@ -830,6 +834,18 @@ __global__ __launch_bounds__(512) void gemm_ring256_kernel(GemmP p, int KT) {
         }
     }
 
+    if (gridDim.z > 1) {
+        float* wsl = p.ws + (long long)blockIdx.z * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int m = m0 + wr * 128 + i * 16 + lr;
+            if (m < p.M) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const int nb = n0 + wc * 64 + j * 16; if (nb + 16 <= p.N) *reinterpret_cast<f32x4_t*>(wsl + (long long)m * p.N + nb + lq * 4) = acc[i][j]; }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int m = m0 + wr * 128 + i * 16 + lr;
@@ -843,8 +859,9 @@ __global__ __launch_bounds__(512) void gemm_ring256_kernel(GemmP p, int KT) {
     }
 }
 
-static hipError_t launch_ring256(const GemmP& p, const GemmArgs& a, hipStream_t st) {
-    dim3 grid(cdiv(a.N, 256), cdiv(a.M, 256));
+static hipError_t launch_ring256(const GemmP& p, const GemmArgs& a, hipStream_t st, int splits = 1) {
+    while (splits > 1 && (a.epi == EPI_SWIGLU || !a.splitk_ws || (size_t)splits * a.M * a.N * sizeof(float) > a.splitk_ws_bytes)) --splits;
+    dim3 grid(cdiv(a.N, 256), cdiv(a.M, 256), splits);
     const int KT = a.K >> 5;
     const size_t smem = 3 * (256 * 32 + 256 * 32) * sizeof(bf16_t);          // 96 KB
     static bool attr_set = false;
@@ -862,6 +879,10 @@ static hipError_t launch_ring256(const GemmP& p, const GemmArgs& a, hipStream_t 
         case EPI_RESID: hipLaunchKernelGGL((gemm_ring256_kernel<EPI_RESID>), grid, dim3(512), smem, st, p, KT); break;
         case EPI_SWIGLU: hipLaunchKernelGGL((gemm_ring256_kernel<EPI_SWIGLU>), grid, dim3(512), smem, st, p, KT); break;
         default: hipLaunchKernelGGL((gemm_ring256_kernel<EPI_NONE>), grid, dim3(512), smem, st, p, KT); break;
+    }
+    if (splits > 1) {
+        long long work = (long long)a.M * ((a.N + 3) / 4);
+        hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), dim3(cdiv(work, 256)), dim3(256), 0, st, p, splits);
     }
     return hipGetLastError();
 }
@@ -898,6 +919,21 @@ static hipError_t launch_t(const GemmArgs& a, hipStream_t st, int* kind_out) {
             p.W = a.Wp;
             if (kind_out) *kind_out = MMD_K_GEMM_TILE;
             return launch_ring256(p, a, st);
+        }
+        // long K with under one block wave of 256^2 tiles (down_proj of a chunk): split K across grid.z so ~one block per CU runs a
+        // long steady state (1.05 PF at M = 1274 against 0.84 PF for the 128-row kernel's 3-way split); K = 3584 shapes lose to it
+        const bool ring_split_ok = big_packed_ok(MMD_BF16, a, 16) && (a.N % 32) == 0 && a.epi != EPI_SWIGLU && a.splitk_ws != nullptr;
+        if (variant == GEMM_RING256_SPLIT || (variant == GEMM_AUTO && a.M >= 512 && a.K >= 8192 && ring_split_ok && !getenv("MMDUET_NO_RING256"))) {
+            if (variant == GEMM_RING256_SPLIT && (!big_packed_ok(MMD_BF16, a, 16) || (a.N % 32) != 0)) return hipErrorInvalidValue;
+            const int t256 = cdiv(a.M, 256) * cdiv(a.N, 256);
+            int sp = 256 / t256; if (sp < 1) sp = 1;
+            while (sp > 1 && a.K / sp < 1024) --sp;
+            while (sp > 1 && (size_t)sp * a.M * a.N * sizeof(float) > a.splitk_ws_bytes) --sp;
+            if (variant == GEMM_RING256_SPLIT || sp >= 2) {
+                p.W = a.Wp;
+                if (kind_out) *kind_out = MMD_K_GEMM_TILE;
+                return launch_ring256(p, a, st, sp);
+            }
         }
         const bool want_big = variant == GEMM_BIG || (variant == GEMM_AUTO && a.M > 64);
         if (want_big) {

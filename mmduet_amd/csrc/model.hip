@@ -141,7 +141,7 @@ static int gemm(mmd_ctx* c, const void* X, int64_t ldx, const void* W, int64_t l
     a.X = X; a.ldx = ldx; a.W = W; a.ldw = ldw; a.Wp = Wp; a.bias = bias; a.R = R; a.ldr = ldr; a.Y = Y; a.ldy = ldy;
     a.M = M; a.N = N; a.K = K; a.epi = epi; a.out_f32 = out_f32; a.variant = variant;
     a.splitk_ws = c->splitk_ws; a.splitk_ws_bytes = c->splitk_bytes;
-    int kind = (variant == GEMM_SKINNY || (variant != GEMM_BIG && variant != GEMM_RING256 && variant != GEMM_LARGE && variant != GEMM_GENERIC && M <= 64)) ? MMD_K_GEMM_SKINNY : MMD_K_GEMM_TILE;
+    int kind = (variant == GEMM_SKINNY || (variant != GEMM_BIG && variant != GEMM_RING256 && variant != GEMM_RING256_SPLIT && variant != GEMM_LARGE && variant != GEMM_GENERIC && M <= 64)) ? MMD_K_GEMM_SKINNY : MMD_K_GEMM_TILE;
     double e = (double)es(c);
     double bytes = ((double)M * K + (double)N * K) * e + (double)M * (epi == EPI_SWIGLU ? N / 2 : N) * (out_f32 ? 4.0 : e);
     ProfScope ps(c, kind, bytes, 2.0 * M * N * K);
@@ -1020,7 +1020,7 @@ extern "C" int mmd_op_gemm(mmd_ctx* c, const void* X, const void* W, const void*
     if (!c->splitk_ws) { c->splitk_bytes = (size_t)64 << 20; int rc = dev_alloc(c, (void**)&c->splitk_ws, c->splitk_bytes); if (rc) return rc; }
     int NO = epi == EPI_SWIGLU ? N / 2 : N;
     void* Wp = nullptr;
-    if (variant == GEMM_SKINNY || variant == GEMM_BIG || variant == GEMM_RING256) { int rc = make_packed(c, W, N, K, &Wp); if (rc) return rc; }
+    if (variant == GEMM_SKINNY || variant == GEMM_BIG || variant == GEMM_RING256 || variant == GEMM_RING256_SPLIT) { int rc = make_packed(c, W, N, K, &Wp); if (rc) return rc; }
     int rc = gemm(c, X, K, W, K, bias, R, NO, Y, NO, M, N, K, epi, out_f32, variant, Wp);
     if (Wp) { hipStreamSynchronize(c->stream); dev_free(c, Wp); }
     return rc;

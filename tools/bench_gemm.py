@@ -30,6 +30,6 @@ if __name__ == '__main__':
         for M in (392, 784, 980, 1274, 23328):
             shapes = (LLM[:4] if M < 2000 else VIT)
             for name, N, K, epi in shapes:
-                for variant, vn in ((4, 'big'), (6, 'ring256')):
+                for variant, vn in ((0, 'auto'), (4, 'big'), (6, 'ring256'), (7, 'ring256-splitK')):
                     ms = run(ops, M, N, K, epi, variant, iters=10)
                     print(f'M={M:6d} {name:8s} N={N:6d} K={K:6d} {vn:10s} {ms*1e3:9.1f} us  {2*M*N*K/ms/1e9:7.1f} TF', flush=True)
