@@ -6,7 +6,7 @@
 
 One "step" = one pass of the hot path over one synthetic video stream per GPU (BASELINE.json configs[1]):
 T 1-fps uint8 frames [T,3,336,336] already resident in HBM -> device preprocess (Pillow-exact bicubic to 384, normalise)
--> SigLIP tower + projector + bilinear pooling (batches of 32 frames) -> per-frame causal LLaVA-OV-Qwen2-7B steps over the
+-> SigLIP tower + projector + bilinear pooling (batches of 35 frames) -> per-frame causal LLaVA-OV-Qwen2-7B steps over the
 growing interleaved KV arena (one user query at t=0) -> informative/relevance head logits -> greedy per-frame response
 decision on the host -> greedy text generation (capped) when a frame fires.  Weights: seeded random init at the true
 shapes, bf16 (no checkpoints exist offline).  With N > 1 every rank runs its own stream (weak scaling) and the per-frame
@@ -82,7 +82,7 @@ def build(args, device):
     step_tokens = max(256, k * cfg.frame_num_tokens + 192)
     if getattr(args, 'multi_stream', 0):
         step_tokens = max(step_tokens, args.multi_stream * (args.multi_frames_per_forward * cfg.frame_num_tokens + 192))
-    model = VideoHeadLiveLlavaQwenForCausalLM(cfg, torch_dtype=torch.bfloat16, device=device, max_vit_batch=32, max_step_tokens=step_tokens,
+    model = VideoHeadLiveLlavaQwenForCausalLM(cfg, torch_dtype=torch.bfloat16, device=device, max_vit_batch=35, max_step_tokens=step_tokens,
                                               kv_initial_tokens=args.frames * cfg.frame_num_tokens + 4096)
     tok = build_live_tokenizer_and_update_config('synthetic:bench', cfg)
     for name, t in synthetic_weights(cfg, seed=0, device=device, dtype=torch.bfloat16, scale='init02'):

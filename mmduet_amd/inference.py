@@ -24,7 +24,15 @@ import torch
 from .modeling_live import build_model_and_tokenizer, fast_greedy_generate
 from .tokenization_live import chat_ids
 
-VIT_BATCH = 32          # test/inference.py:208
+VIT_BATCH = 32          # test/inference.py:208 (frames per tower call; results do not depend on it)
+
+
+def _tower_batch(model):
+    """Frames per tower call.  The reference's 32 is not special; on MI355X the tower's 256x256 GEMM tiles quantise over 256 CUs and
+    35 frames (M = 25 515 rows) fill the last block wave of qkv / fc1 / fc2 best (934 us per frame against 973 at 32,
+    tools/vit_batch_sweep.py).  Bounded by the model's tower workspace."""
+    cap = getattr(model, 'max_vit_batch', None)
+    return VIT_BATCH if not cap else (35 if cap >= 35 else min(VIT_BATCH, cap))
 
 
 def _p1(l0, l1):
@@ -134,8 +142,9 @@ class LiveInferForBenchmark:
         if not overlap:
             pixel_values = self.image_processor.preprocess(video_frames, return_tensors='pt')['pixel_values']
             pixel_values = pixel_values.to(self.device).to(self.torch_dtype)
-            for b0 in range(0, len(pixel_values), VIT_BATCH):
-                embeds = self.model.visual_embed(pixel_values[b0:b0 + VIT_BATCH]).split(self.frame_num_tokens)
+            vb = _tower_batch(self.model)
+            for b0 in range(0, len(pixel_values), vb):
+                embeds = self.model.visual_embed(pixel_values[b0:b0 + vb]).split(self.frame_num_tokens)
                 self.frame_embeds_queue.extend(((r + b0) / self.frame_fps, f) for r, f in enumerate(embeds))
             return
         # The tower is MFMA-bound, the LLM steps (weight streaming, token-by-token decoding) are not: encode the frames on a
@@ -154,11 +163,12 @@ class LiveInferForBenchmark:
         side.wait_stream(main)
         with torch.cuda.stream(side):
             self._vit_pixels = self.image_processor.preprocess(video_frames, return_tensors='pt')['pixel_values'].to(self.torch_dtype)
-        self._vit_batches = [(b0, min(T, b0 + VIT_BATCH)) for b0 in range(0, T, VIT_BATCH)]
+        vb = _tower_batch(self.model)
+        self._vit_batches = [(b0, min(T, b0 + vb)) for b0 in range(0, T, vb)]
         self._vit_events, self._vit_waited = [], set()
         for r in range(T):
             f = self._vit_out[r * nt:(r + 1) * nt]
-            self._frame_batch[f.data_ptr()] = r // VIT_BATCH
+            self._frame_batch[f.data_ptr()] = r // vb
             self.frame_embeds_queue.append((r / self.frame_fps, f))
         self._issue_vit(len(self._vit_batches) if self.vit_lookahead_batches is None else self.vit_lookahead_batches)
 

@@ -187,7 +187,7 @@ class VideoHeadLiveLlavaQwenForCausalLM:
     config_class = VideoHeadLiveLlavaQwenConfig
 
     def __init__(self, config: VideoHeadLiveLlavaQwenConfig, torch_dtype=torch.bfloat16, device=None,
-                 max_vit_batch=32, max_step_tokens=1024, kv_initial_tokens=32768):
+                 max_vit_batch=35, max_step_tokens=1024, kv_initial_tokens=32768):
         if torch_dtype not in _TORCH2MMD:
             raise ValueError(f'torch_dtype must be bfloat16 or float32 on this implementation, got {torch_dtype}')
         if not torch.cuda.is_available():
