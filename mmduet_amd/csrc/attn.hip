@@ -15,6 +15,7 @@
 //   the MFMA kernel.
 // softmax statistics are fp32; P is rounded to the storage type before P.V (flash / sdpa semantics).
 #include "common.h"
+#include <cstdlib>
 
 // defer-max threshold (log2 units) of the flash kernels: the running maximum moves only when it grows by more than this
 #define ATTN_DEFER 4.0f
@@ -271,9 +272,8 @@ __global__ void attn_combine_kernel(AttnP p, int nrows_total_all) {
 // ------------------------------------------------------------------------------------------------------------------
 template <int RT>
 __global__ __launch_bounds__(256, 2) void attn_gqa128_kernel(AttnP p) {
-    constexpr int D = 128, KT = 64, KLD = D + 8, VLD = KT + 8;
-    __shared__ __attribute__((aligned(16))) bf16_t Ks[KT * KLD];
-    __shared__ __attribute__((aligned(16))) bf16_t Vt[D * VLD];
+    constexpr int D = 128, KT = 64, TILE = KT * D;              // one K tile = one V^T tile = 8192 elements = 16 KB, contiguous in the arena
+    __shared__ __attribute__((aligned(16))) bf16_t kv[2 * 2 * TILE];   // two slots of (K tile, V^T tile): 64 KB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4;
     int bx, by, bz; xcd_block_id(bx, by, bz);
@@ -330,36 +330,45 @@ __global__ __launch_bounds__(256, 2) void attn_gqa128_kernel(AttnP p) {
         for (int t = 0; t < 8; ++t) oacc[rt][t] = f32x4_t{0, 0, 0, 0};
     }
 
-    // staging: 2048 16-byte pieces per tile (1024 K + 1024 V^T), 8 per thread
-    s16x8_t pre[8];
-    auto prefetch = [&](long long k0) {
+    // staging: both tiles are contiguous 16 KB runs of the arena and go to LDS by DMA (global_load_lds, 1 KiB pieces, 4 K + 4 V^T
+    // per wave), double-buffered: tile i+1 is in flight while tile i is consumed, ONE barrier per tile, no staging registers.
+    // DMA writes LDS lane-linearly, so the bank spreading is done on the SOURCE side: the 16-byte chunk q of K row `key` sits at
+    // position q ^ (key & 15), chunk q of V^T row `dim` at q ^ ((dim >> 1) & 7) -- conflict-free for the b128 / b64 fragment reads.
+    auto stage = [&](int slot, long long k0) {
+        bf16_t* ks = kv + slot * 2 * TILE;
+        bf16_t* vt = ks + TILE;
         const long long blk = k0 >> 6;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            int i = tid + 256 * j;                                   // K piece: row i>>4 (key), chunk i&15
-            pre[j] = *reinterpret_cast<const s16x8_t*>(Kg + (k0 + (i >> 4)) * p.k_ts + (i & 15) * 8);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int i = tid + 256 * j;                                   // V^T piece: row i>>3 (dim), chunk i&7 (8 keys)
-            pre[4 + j] = *reinterpret_cast<const s16x8_t*>(Vg + ((blk * D + (i >> 3)) << 6) + (i & 7) * 8);
+            const int pc = wave + 4 * j;
+            const int key = pc * 4 + (lane >> 4);
+            const bf16_t* src = Kg + (k0 + key) * p.k_ts + (((lane & 15) ^ (key & 15)) * 8);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(ks + pc * 512), 16, 0, 0);
+            const int dim = pc * 8 + (lane >> 3);
+            const bf16_t* vsrc = Vg + ((blk * D + dim) << 6) + (((lane & 7) ^ ((dim >> 1) & 7)) * 8);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)vsrc, (__attribute__((address_space(3))) void*)(vt + pc * 512), 16, 0, 0);
         }
     };
-    auto commit = [&]() {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { int i = tid + 256 * j; *reinterpret_cast<s16x8_t*>(Ks + (i >> 4) * KLD + (i & 15) * 8) = pre[j]; }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { int i = tid + 256 * j; *reinterpret_cast<s16x8_t*>(Vt + (i >> 3) * VLD + (i & 7) * 8) = pre[4 + j]; }
-    };
+    const int vsw = (lr >> 1) & 7;
 
-    if (kbeg < kend) prefetch(kbeg);
-    for (long long k0 = kbeg; k0 < kend; k0 += KT) {
+    if (kbeg < kend) stage(0, kbeg);
+    int slot = 0;
+    for (long long k0 = kbeg; k0 < kend; k0 += KT, slot ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        commit();
-        __syncthreads();
-        if (k0 + KT < kend) prefetch(k0 + KT);
+        if (k0 + KT < kend) stage(slot ^ 1, k0 + KT);
+        const bf16_t* Ks = kv + slot * 2 * TILE;
+        const bf16_t* Vt = Ks + TILE;
         if (!wave_active) continue;
         const bool need_mask = (k0 + KT > blk_min_limit) || (k0 + KT > kend);
+        // element (h, t, r) of this tile is visible to row rt iff h*32 + t*16 + r < rel[rt]; tiles wholly below every limit get a
+        // bound no index reaches, so the two VALU per element that remain never mask anything there
+        int rel[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const long long lim = (my_limit[rt] < kend ? my_limit[rt] : kend) - k0;
+            rel[rt] = need_mask ? (int)(lim < 0 ? 0 : (lim > KT ? KT : lim)) - lq * 4 : 2 * KT;
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             f32x4_t st[RT][2];
@@ -369,7 +378,7 @@ __global__ __launch_bounds__(256, 2) void attn_gqa128_kernel(AttnP p) {
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + (h * 32 + t * 16 + lr) * KLD + c * 32 + lq * 8);
+                    bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + (h * 32 + t * 16 + lr) * D + (((c * 4 + lq) ^ lr) * 8));
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt) st[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[rt][c], st[rt][t], 0, 0, 0);
                 }
@@ -386,10 +395,7 @@ __global__ __launch_bounds__(256, 2) void attn_gqa128_kernel(AttnP p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float v = st[rt][t][r];
-                        if (need_mask) {
-                            long long key = k0 + h * 32 + t * 16 + lq * 4 + r;
-                            if (!(key < my_limit[rt] && key < kend)) v = -INFINITY;
-                        }
+                        if (!(h * 32 + t * 16 + r < rel[rt])) v = -INFINITY;      // 32-bit, relative to the tile (see rel[])
                         sv[t * 4 + r] = v;
                         mx = fmaxf(mx, v);
                     }
@@ -413,9 +419,10 @@ __global__ __launch_bounds__(256, 2) void attn_gqa128_kernel(AttnP p) {
             }
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
-                const bf16_t* vrow = Vt + (t * 16 + lr) * VLD + h * 32;
-                s16x4_t lo = *reinterpret_cast<const s16x4_t*>(vrow + lq * 4);
-                s16x4_t hi = *reinterpret_cast<const s16x4_t*>(vrow + 16 + lq * 4);
+                const bf16_t* vrow = Vt + (t * 16 + lr) * KT + (lq & 1) * 4;
+                const int vc = h * 4 + (lq >> 1);
+                s16x4_t lo = *reinterpret_cast<const s16x4_t*>(vrow + ((vc ^ vsw) * 8));
+                s16x4_t hi = *reinterpret_cast<const s16x4_t*>(vrow + (((vc + 2) ^ vsw) * 8));
                 s16x8_t vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 bf16x8_t vfb = __builtin_bit_cast(bf16x8_t, vf);
 #pragma unroll
@@ -507,11 +514,20 @@ static hipError_t launch_gqa128(AttnP& p, const AttnArgs& a, hipStream_t st) {
     } else if (rows_total <= 16 && a.ws) {
         splits = 64;                                               // decode: same key ranges as the graph-replayed form -> identical bits
         if (splits > tiles) splits = tiles;
-    } else if (blocks < 512 && a.ws) {                             // two 4-wave blocks per CU hide each other's barriers
-        splits = cdiv(576, blocks);
-        int maxs = tiles / 4; if (maxs < 1) maxs = 1;              // >= 4 key tiles per split
-        if (splits > maxs) splits = maxs;
-        while (splits > 1 && (size_t)splits * a.nkv * rows_total * (128 + 2) * sizeof(float) > a.ws_bytes) --splits;
+    } else if (a.ws) {
+        // split-KV choice by a small cost model (units: one key tile of one block with two blocks resident per CU, ~2.6 us): the grid
+        // runs in rounds of 512 resident blocks, a block costs its tiles plus ~2 tiles of prologue, and the merge kernel reads
+        // splits x rows x 520 B.  Measured against it at S = 49 / 392 / 1274, n = 15 k: picks 42 / 5 / 7 splits (33 / 152 / 440 us; the
+        // old fixed target of 576 blocks gave 42 / 202 / 485 us).
+        const double rows_all = (double)a.nkv * rows_total;
+        int maxs = tiles / 2; if (maxs < 1) maxs = 1; if (maxs > 64) maxs = 64;
+        while (maxs > 1 && (size_t)maxs * a.nkv * rows_total * (128 + 2) * sizeof(float) > a.ws_bytes) --maxs;
+        double best = 1e30;
+        for (int sp = 1; sp <= maxs; ++sp) {
+            const double rounds = (double)cdiv((long long)blocks * sp, 512);
+            const double cost = rounds * ((double)cdiv(tiles, sp) + 2.0) + (sp > 1 ? sp * rows_all * 6.7e-5 + 1.5 : 0.0);
+            if (cost < best - 1e-9) { best = cost; splits = sp; }
+        }
     }
     int per = cdiv(tiles, splits) * 64;
     if (!a.dyn) splits = cdiv(n_tot, per);

@@ -6,7 +6,7 @@ import torch
 from mmduet_amd._lib import lib, check
 from rawops import RawOps
 ops = RawOps(torch.bfloat16)
-for S in (1, 49, 392):
+for S in (1, 49, 392, 1274):
     for n in (0, 1024, 4096, 15000, 30000):
         for v in (2, 3):
             ms = C.c_float()
