@@ -333,7 +333,9 @@ __global__ __launch_bounds__(256, 2) void attn_gqa128_kernel(AttnP p) {
     // staging: both tiles are contiguous 16 KB runs of the arena and go to LDS by DMA (global_load_lds, 1 KiB pieces, 4 K + 4 V^T
     // per wave), double-buffered: tile i+1 is in flight while tile i is consumed, ONE barrier per tile, no staging registers.
     // DMA writes LDS lane-linearly, so the bank spreading is done on the SOURCE side: the 16-byte chunk q of K row `key` sits at
-    // position q ^ (key & 15), chunk q of V^T row `dim` at q ^ ((dim >> 1) & 7) -- conflict-free for the b128 / b64 fragment reads.
+    // position q ^ f(key), f = ((key >> 3) & 3) * 4 + (key & 3), chunk q of V^T row `dim` at q ^ ((dim >> 1) & 7) -- conflict-free for the
+    // b128 fragment reads.  MFMA row i of S^T tile t is key (i >> 2) * 8 + t * 4 + (i & 3) of the 32-key half (not t * 16 + i): a lane's
+    // eight P values then belong to eight CONSECUTIVE keys, so its V^T operand is one 16-byte read instead of two 8-byte reads + repack.
     auto stage = [&](int slot, long long k0) {
         bf16_t* ks = kv + slot * 2 * TILE;
         bf16_t* vt = ks + TILE;
@@ -342,7 +344,7 @@ __global__ __launch_bounds__(256, 2) void attn_gqa128_kernel(AttnP p) {
         for (int j = 0; j < 4; ++j) {
             const int pc = wave + 4 * j;
             const int key = pc * 4 + (lane >> 4);
-            const bf16_t* src = Kg + (k0 + key) * p.k_ts + (((lane & 15) ^ (key & 15)) * 8);
+            const bf16_t* src = Kg + (k0 + key) * p.k_ts + (((lane & 15) ^ ((((key >> 3) & 3) << 2) | (key & 3))) * 8);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(ks + pc * 512), 16, 0, 0);
             const int dim = pc * 8 + (lane >> 3);
             const bf16_t* vsrc = Vg + ((blk * D + dim) << 6) + (((lane & 7) ^ ((dim >> 1) & 7)) * 8);
@@ -361,13 +363,13 @@ __global__ __launch_bounds__(256, 2) void attn_gqa128_kernel(AttnP p) {
         const bf16_t* Vt = Ks + TILE;
         if (!wave_active) continue;
         const bool need_mask = (k0 + KT > blk_min_limit) || (k0 + KT > kend);
-        // element (h, t, r) of this tile is visible to row rt iff h*32 + t*16 + r < rel[rt]; tiles wholly below every limit get a
+        // element (h, t, r) of this tile (key h*32 + lq*8 + t*4 + r) is visible to row rt iff h*32 + t*4 + r < rel[rt]; tiles wholly below every limit get a
         // bound no index reaches, so the two VALU per element that remain never mask anything there
         int rel[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             const long long lim = (my_limit[rt] < kend ? my_limit[rt] : kend) - k0;
-            rel[rt] = need_mask ? (int)(lim < 0 ? 0 : (lim > KT ? KT : lim)) - lq * 4 : 2 * KT;
+            rel[rt] = need_mask ? (int)(lim < 0 ? 0 : (lim > KT ? KT : lim)) - lq * 8 : 2 * KT;
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -378,7 +380,7 @@ __global__ __launch_bounds__(256, 2) void attn_gqa128_kernel(AttnP p) {
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + (h * 32 + t * 16 + lr) * D + (((c * 4 + lq) ^ lr) * 8));
+                    bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + (h * 32 + (lr >> 2) * 8 + t * 4 + (lr & 3)) * D + (((c * 4 + lq) ^ lr) * 8));
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt) st[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[rt][c], st[rt][t], 0, 0, 0);
                 }
@@ -395,7 +397,7 @@ __global__ __launch_bounds__(256, 2) void attn_gqa128_kernel(AttnP p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float v = st[rt][t][r];
-                        if (!(h * 32 + t * 16 + r < rel[rt])) v = -INFINITY;      // 32-bit, relative to the tile (see rel[])
+                        if (!(h * 32 + t * 4 + r < rel[rt])) v = -INFINITY;       // 32-bit, relative to the tile (see rel[]); key = h*32 + lq*8 + t*4 + r
                         sv[t * 4 + r] = v;
                         mx = fmaxf(mx, v);
                     }
@@ -419,12 +421,7 @@ __global__ __launch_bounds__(256, 2) void attn_gqa128_kernel(AttnP p) {
             }
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
-                const bf16_t* vrow = Vt + (t * 16 + lr) * KT + (lq & 1) * 4;
-                const int vc = h * 4 + (lq >> 1);
-                s16x4_t lo = *reinterpret_cast<const s16x4_t*>(vrow + ((vc ^ vsw) * 8));
-                s16x4_t hi = *reinterpret_cast<const s16x4_t*>(vrow + (((vc + 2) ^ vsw) * 8));
-                s16x8_t vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                bf16x8_t vfb = __builtin_bit_cast(bf16x8_t, vf);
+                const bf16x8_t vfb = *reinterpret_cast<const bf16x8_t*>(Vt + (t * 16 + lr) * KT + (((h * 4 + lq) ^ vsw) * 8));
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) oacc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfb, pf[rt], oacc[rt][t], 0, 0, 0);
             }
