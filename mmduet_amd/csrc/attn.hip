@@ -363,13 +363,12 @@ __global__ __launch_bounds__(256, 2) void attn_gqa128_kernel(AttnP p) {
         const bf16_t* Vt = Ks + TILE;
         if (!wave_active) continue;
         const bool need_mask = (k0 + KT > blk_min_limit) || (k0 + KT > kend);
-        // element (h, t, r) of this tile (key h*32 + lq*8 + t*4 + r) is visible to row rt iff h*32 + t*4 + r < rel[rt]; tiles wholly below every limit get a
-        // bound no index reaches, so the two VALU per element that remain never mask anything there
+        // element (h, t, r) of this tile (key h*32 + lq*8 + t*4 + r) is visible to row rt iff h*32 + t*4 + r < rel[rt]
         int rel[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             const long long lim = (my_limit[rt] < kend ? my_limit[rt] : kend) - k0;
-            rel[rt] = need_mask ? (int)(lim < 0 ? 0 : (lim > KT ? KT : lim)) - lq * 8 : 2 * KT;
+            rel[rt] = (int)(lim < 0 ? 0 : (lim > KT ? KT : lim)) - lq * 8;
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -391,16 +390,18 @@ __global__ __launch_bounds__(256, 2) void attn_gqa128_kernel(AttnP p) {
                 // maximum is only moved (O and l rescaled) when it grows by more than 2^DEFER -- P then ranges up to 2^DEFER
                 // instead of 1, which bf16 P / fp32 O and l absorb; saves ~30 VALU per 16 MFMAs in a VALU-bound loop
                 float sv[8];
-                float mx = -INFINITY;
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float v = st[rt][t][r];
-                        if (!(h * 32 + t * 4 + r < rel[rt])) v = -INFINITY;       // 32-bit, relative to the tile (see rel[]); key = h*32 + lq*8 + t*4 + r
-                        sv[t * 4 + r] = v;
-                        mx = fmaxf(mx, v);
-                    }
+                    for (int r = 0; r < 4; ++r) sv[t * 4 + r] = st[rt][t][r];
+                if (need_mask) {                  // wave-uniform: only tiles on the causal diagonal / at the end of the split pay for it
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (!(h * 32 + t * 4 + r < rel[rt])) sv[t * 4 + r] = -INFINITY;     // key = h*32 + lq*8 + t*4 + r, 32-bit, tile-relative
+                }
+                float mx = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
                 mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
                 mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
                 mx *= p.scale_log2;                                   // scale > 0: max commutes with it
