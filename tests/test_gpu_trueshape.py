@@ -146,3 +146,29 @@ print("RES " + json.dumps(res))
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(json.loads([l for l in r.stdout.splitlines() if l.startswith('RES ')][0][4:]))
     assert outs[0] == outs[1]           # bit-identical: same reduction order, same rounding points
+
+
+def test_multi_stream_step_true_shape(true_shape):
+    """bf16 at the 7B widths: one forward over three arenas (a 98-row frame chunk, a 49-row frame, one decode row) against the oracle
+    run stream by stream -- the merged forward takes the tile-GEMM path where the single-stream steps take the weight-streaming one."""
+    m, om, cfg = true_shape
+    g = torch.Generator().manual_seed(7)
+    ctxs = [(torch.randn(1, n, 3584, generator=g) * 0.5).to(torch.bfloat16) for n in (130, 64, 200)]
+    news = [(torch.randn(1, n, 3584, generator=g) * 0.5).to(torch.bfloat16) for n in (98, 49, 1)]
+    caches, ocaches = [], []
+    for c in ctxs:
+        caches.append(m(inputs_embeds=c.cuda()).past_key_values)
+        ocaches.append(om(inputs_embeds=c).past_key_values)
+    out = m.multi_step([dict(x=news[0].cuda(), cache=caches[0], head_rows=[48, 97]), dict(x=news[1].cuda(), cache=caches[1], head_rows=[48]),
+                        dict(x=news[2].cuda(), cache=caches[2], hidden='last')])
+    refs = [om(inputs_embeds=x, past_key_values=oc) for x, oc in zip(news, ocaches)]
+    for o, r, rows in ((out[0], refs[0], [48, 97]), (out[1], refs[1], [48])):
+        want = torch.cat([r.informative_logits[0, rows], r.relevance_logits[0, rows]], dim=-1)
+        assert maxerr(o['heads'], want) < TOL
+    assert maxerr(out[2]['logits'][0], refs[2].logits[0, -1]) < 2 * TOL
+    assert [len(o['cache']) for o in out] == [228, 113, 201]
+    # every stream continues from its own arena afterwards
+    nxt = (torch.randn(1, 5, 3584, generator=g) * 0.5).to(torch.bfloat16)
+    for o, r in zip(out, refs):
+        a = m(inputs_embeds=nxt.cuda(), past_key_values=o['cache']); b = om(inputs_embeds=nxt, past_key_values=r.past_key_values)
+        assert maxerr(a.informative_logits[0, -1], b.informative_logits[0, -1]) < TOL
