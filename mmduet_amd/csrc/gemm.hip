@@ -710,16 +710,19 @@ __global__ __launch_bounds__(512) void gemm_ring256_kernel(GemmP p, int KT) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4;
     const int wr = wave >> 2, wc = wave & 3;
-    const int nbx = gridDim.x, nby = gridDim.y;
-    int bid = blockIdx.y * nbx + blockIdx.x;
+    // persistent over tiles: block b takes the logical tiles b, b + G, b + 2G, ... (G = gridDim.x, a multiple of 8 or the tile count,
+    // so a block stays on its XCD's share of the bijective XCD remap); while it converts and stores tile i, the first three
+    // slices of tile i+1 are already in flight
+    const int nbx = (p.N + BN - 1) / BN, nby = (p.M + BM - 1) / BM;
     const int nblk = nbx * nby;
-    {
+    int m0 = 0, n0 = 0;
+    auto tile_origin = [&](int bid) {
         const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    int mt, nt;
-    if (p.N > p.M) { nt = bid / nby; mt = bid % nby; } else { mt = bid / nbx; nt = bid % nbx; }
-    const int m0 = mt * BM, n0 = nt * BN;
+        int mt, nt;
+        if (p.N > p.M) { nt = bid / nby; mt = bid % nby; } else { mt = bid / nbx; nt = bid % nbx; }
+        m0 = mt * BM; n0 = nt * BN;
+    };
     const int ntiles = p.N >> 4;
     const bf16_t* X = (const bf16_t*)p.X;
     const bf16_t* Wp = (const bf16_t*)p.W;
@@ -734,14 +737,16 @@ __global__ __launch_bounds__(512) void gemm_ring256_kernel(GemmP p, int KT) {
     // per-wave DMA sources of slice 0 (2 X pieces + 2 W pieces) as 32-bit element offsets; a slice advances X by 32
     // elements and W by one k-tile (512 elements)
     int xo[2], wo[2];
+    auto tile_sources = [&]() {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int pi = wave + 8 * j;
-        int row = m0 + pi * 16 + srow; row = row < p.M ? row : p.M - 1;
-        xo[j] = row * (int)p.ldx + ((spos ^ sswz) * 8) + t0 * BK;
-        int ntile = n0 / 16 + pi; ntile = ntile < ntiles ? ntile : ntiles - 1;
-        wo[j] = (ntile * KT * 64 + lane) * 8 + t0 * 512;
-    }
+        for (int j = 0; j < 2; ++j) {
+            const int pi = wave + 8 * j;
+            int row = m0 + pi * 16 + srow; row = row < p.M ? row : p.M - 1;
+            xo[j] = row * (int)p.ldx + ((spos ^ sswz) * 8) + t0 * BK;
+            int ntile = n0 / 16 + pi; ntile = ntile < ntiles ? ntile : ntiles - 1;
+            wo[j] = (ntile * KT * 64 + lane) * 8 + t0 * 512;
+        }
+    };
     auto stage = [&](int slot, int step) {
         bf16_t* xs = lds + slot * SE;
         bf16_t* ws = xs + XE;
@@ -807,61 +812,74 @@ __global__ __launch_bounds__(512) void gemm_ring256_kernel(GemmP p, int KT) {
         __builtin_amdgcn_s_setprio(0);
     };
 
-    stage(0, 0);
-    if (nsteps > 1) stage(1, 1);
-    if (nsteps > 2) stage(2, 2);
-    if (nsteps > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (nsteps > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    MMD_BAR();
-#pragma unroll
-    for (int i = 0; i < 8; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(lds + aoff + i * 512);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) b0[j] = *reinterpret_cast<const bf16x8_t*>(lds + boff + j * 512);
-    int slot = 0, s = 0;
-    for (; s + 4 < nsteps; s += 2) {               // steady state: both slices have s + 3 < nsteps
-        step(std::true_type{}, s, slot, b0, b1);
-        slot = slot == 2 ? 0 : slot + 1;
-        step(std::true_type{}, s + 1, slot, b1, b0);
-        slot = slot == 2 ? 0 : slot + 1;
-    }
-    for (; s < nsteps; s += 2) {                   // the last slices: conditions evaluated
-        step(std::false_type{}, s, slot, b0, b1);
-        slot = slot == 2 ? 0 : slot + 1;
-        if (s + 1 < nsteps) {
-            step(std::false_type{}, s + 1, slot, b1, b0);
+    auto prologue = [&]() { stage(0, 0); if (nsteps > 1) stage(1, 1); if (nsteps > 2) stage(2, 2); };
+    const int G = gridDim.x;
+    int tile = blockIdx.x;
+    tile_origin(tile); tile_sources(); prologue();
+    for (; tile < nblk; tile += G) {
+        if (nsteps > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (nsteps > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        MMD_BAR();
+    #pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(lds + aoff + i * 512);
+    #pragma unroll
+        for (int j = 0; j < 4; ++j) b0[j] = *reinterpret_cast<const bf16x8_t*>(lds + boff + j * 512);
+        int slot = 0, s = 0;
+        for (; s + 4 < nsteps; s += 2) {               // steady state: both slices have s + 3 < nsteps
+            step(std::true_type{}, s, slot, b0, b1);
+            slot = slot == 2 ? 0 : slot + 1;
+            step(std::true_type{}, s + 1, slot, b1, b0);
             slot = slot == 2 ? 0 : slot + 1;
         }
-    }
-
-    if (gridDim.z > 1) {
-        float* wsl = p.ws + (long long)blockIdx.z * p.M * p.N;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int m = m0 + wr * 128 + i * 16 + lr;
-            if (m < p.M) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { const int nb = n0 + wc * 64 + j * 16; if (nb + 16 <= p.N) *reinterpret_cast<f32x4_t*>(wsl + (long long)m * p.N + nb + lq * 4) = acc[i][j]; }
+        for (; s < nsteps; s += 2) {                   // the last slices: conditions evaluated
+            step(std::false_type{}, s, slot, b0, b1);
+            slot = slot == 2 ? 0 : slot + 1;
+            if (s + 1 < nsteps) {
+                step(std::false_type{}, s + 1, slot, b1, b0);
+                slot = slot == 2 ? 0 : slot + 1;
             }
         }
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int m = m0 + wr * 128 + i * 16 + lr;
-        if constexpr (EPI == EPI_SWIGLU) {
-#pragma unroll
-            for (int j = 0; j < 4; j += 2) { const int nb = n0 + wc * 64 + j * 16; if (nb + 32 <= p.N) big_store_swiglu(p, m, nb + lq * 4, acc[i][j], acc[i][j + 1]); }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { const int nb = n0 + wc * 64 + j * 16; if (nb + 16 <= p.N) big_store<EPI>(p, m, nb + lq * 4, acc[i][j]); }
+
+        // tile done: every fragment read was waited for before the last barrier, so the ring is free -- start the next tile's
+        // first slices NOW and let them fly while this tile's accumulators are converted and stored
+        const int em0 = m0, en0 = n0;
+        if (tile + G < nblk) { tile_origin(tile + G); tile_sources(); prologue(); }
+        if (gridDim.z > 1) {
+            float* wsl = p.ws + (long long)blockIdx.z * p.M * p.N;
+    #pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int m = em0 + wr * 128 + i * 16 + lr;
+                if (m < p.M) {
+    #pragma unroll
+                    for (int j = 0; j < 4; ++j) { const int nb = en0 + wc * 64 + j * 16; if (nb + 16 <= p.N) *reinterpret_cast<f32x4_t*>(wsl + (long long)m * p.N + nb + lq * 4) = acc[i][j]; }
+                }
+            }
+            return;
         }
+    #pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int m = em0 + wr * 128 + i * 16 + lr;
+            if constexpr (EPI == EPI_SWIGLU) {
+    #pragma unroll
+                for (int j = 0; j < 4; j += 2) { const int nb = en0 + wc * 64 + j * 16; if (nb + 32 <= p.N) big_store_swiglu(p, m, nb + lq * 4, acc[i][j], acc[i][j + 1]); }
+            } else {
+    #pragma unroll
+                for (int j = 0; j < 4; ++j) { const int nb = en0 + wc * 64 + j * 16; if (nb + 16 <= p.N) big_store<EPI>(p, m, nb + lq * 4, acc[i][j]); }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0, 0, 0, 0};
     }
 }
 
 static hipError_t launch_ring256(const GemmP& p, const GemmArgs& a, hipStream_t st, int splits = 1) {
     while (splits > 1 && (a.epi == EPI_SWIGLU || !a.splitk_ws || (size_t)splits * a.M * a.N * sizeof(float) > a.splitk_ws_bytes)) --splits;
-    dim3 grid(cdiv(a.N, 256), cdiv(a.M, 256), splits);
+    const int tiles = cdiv(a.N, 256) * cdiv(a.M, 256);
+    // one block per CU, looping over its tiles (split-K launches keep one tile per block: their blocks already fill the machine once)
+    dim3 grid(splits > 1 || tiles <= 256 ? tiles : 256, 1, splits);
     const int KT = a.K >> 5;
     const size_t smem = 3 * (256 * 32 + 256 * 32) * sizeof(bf16_t);          // 96 KB
     static bool attr_set = false;
