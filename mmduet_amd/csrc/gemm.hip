@@ -519,8 +519,7 @@ static void launch_skinny_mt(const GemmP& p, const GemmArgs& a, hipStream_t st) 
 // guard-free epilogue of the big-tile kernel: N % BN == 0, ldy/ldr % 4 == 0 (dispatch conditions), one 8-byte access
 // per operand and tile; EPI is a compile-time constant so no per-element branches survive.
 template <int EPI>
-__device__ __forceinline__ void big_store(const GemmP& p, int m, int n, const f32x4_t& a) {
-    if (m >= p.M) return;
+__device__ __forceinline__ s16x4_t big_value(const GemmP& p, int m, int n, const f32x4_t& a) {      // m < p.M
     float v[4] = {a[0], a[1], a[2], a[3]};
     if (p.bias) {
         s16x4_t b = *reinterpret_cast<const s16x4_t*>((const bf16_t*)p.bias + n);
@@ -538,12 +537,14 @@ __device__ __forceinline__ void big_store(const GemmP& p, int m, int n, const f3
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = bf2f(f2bf(v[r])) + bf2f((bf16_t)rr[r]);
     }
-    s16x4_t o = {(short)f2bf(v[0]), (short)f2bf(v[1]), (short)f2bf(v[2]), (short)f2bf(v[3])};
-    *reinterpret_cast<s16x4_t*>((bf16_t*)p.Y + (long long)m * p.ldy + n) = o;
+    return s16x4_t{(short)f2bf(v[0]), (short)f2bf(v[1]), (short)f2bf(v[2]), (short)f2bf(v[3])};
 }
-__device__ __forceinline__ void big_store_swiglu(const GemmP& p, int m, int n_gate, const f32x4_t& g, const f32x4_t& u) {
+template <int EPI>
+__device__ __forceinline__ void big_store(const GemmP& p, int m, int n, const f32x4_t& a) {
     if (m >= p.M) return;
-    const int oc = (n_gate >> 5) * 16 + (n_gate & 15);
+    *reinterpret_cast<s16x4_t*>((bf16_t*)p.Y + (long long)m * p.ldy + n) = big_value<EPI>(p, m, n, a);
+}
+__device__ __forceinline__ s16x4_t big_value_swiglu(const f32x4_t& g, const f32x4_t& u) {
     s16x4_t o;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -551,7 +552,22 @@ __device__ __forceinline__ void big_store_swiglu(const GemmP& p, int m, int n_ga
         float sl = bf2f(f2bf(gg * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-gg * 1.4426950408889634f))));
         o[r] = (short)f2bf(sl * uu);
     }
-    *reinterpret_cast<s16x4_t*>((bf16_t*)p.Y + (long long)m * p.ldy + oc) = o;
+    return o;
+}
+// Two neighbouring 16-column tiles, each lane holding 4 columns (lq*4..) of both: one v_permlane16_swap per dword turns that into
+// 8 consecutive columns of ONE tile per lane (tile lq&1, columns (lq>>1)*8..), i.e. a 16-byte store per lane and 64 contiguous
+// bytes per output row and instruction instead of 2 x 32.
+__device__ __forceinline__ s16x8_t pair_to_row8(const s16x4_t& ta, const s16x4_t& tb) {
+    const uint2 a = __builtin_bit_cast(uint2, ta), b = __builtin_bit_cast(uint2, tb);
+    const auto x = __builtin_amdgcn_permlane16_swap(a.x, b.x, false, false);
+    const auto y = __builtin_amdgcn_permlane16_swap(a.y, b.y, false, false);
+    const uint4 o = {x[0], y[0], x[1], y[1]};
+    return __builtin_bit_cast(s16x8_t, o);
+}
+__device__ __forceinline__ void big_store_swiglu(const GemmP& p, int m, int n_gate, const f32x4_t& g, const f32x4_t& u) {
+    if (m >= p.M) return;
+    const int oc = (n_gate >> 5) * 16 + (n_gate & 15);
+    *reinterpret_cast<s16x4_t*>((bf16_t*)p.Y + (long long)m * p.ldy + oc) = big_value_swiglu(g, u);
 }
 
 template <int BN, int EPI>
@@ -656,12 +672,23 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(GemmP p, int KT) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + wm + i * 16 + lr;
+        const int mc = m < p.M ? m : p.M - 1;                                       // rows past M compute on a valid row and are not stored
         if constexpr (EPI == EPI_SWIGLU) {
+            if constexpr (TN == 4) {                                                // two output tiles: row-contiguous 16-byte stores (pair_to_row8)
+                const int nb = n0 + wn, ob = (nb >> 5) * 16;
+                const s16x8_t v = pair_to_row8(big_value_swiglu(acc[i][0], acc[i][1]), big_value_swiglu(acc[i][2], acc[i][3]));
+                if (m < p.M) *reinterpret_cast<s16x8_t*>((bf16_t*)p.Y + (long long)m * p.ldy + ob + (lq & 1) * 16 + (lq >> 1) * 8) = v;
+            } else {
 #pragma unroll
-            for (int j = 0; j < TN; j += 2) big_store_swiglu(p, m, n0 + wn + j * 16 + lq * 4, acc[i][j], acc[i][j + 1]);
+                for (int j = 0; j < TN; j += 2) big_store_swiglu(p, m, n0 + wn + j * 16 + lq * 4, acc[i][j], acc[i][j + 1]);
+            }
         } else {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) big_store<EPI>(p, m, n0 + wn + j * 16 + lq * 4, acc[i][j]);
+            for (int j = 0; j < TN; j += 2) {
+                const int nb = n0 + wn + j * 16;
+                const s16x8_t v = pair_to_row8(big_value<EPI>(p, mc, nb + lq * 4, acc[i][j]), big_value<EPI>(p, mc, nb + 16 + lq * 4, acc[i][j + 1]));
+                if (m < p.M) *reinterpret_cast<s16x8_t*>((bf16_t*)p.Y + (long long)m * p.ldy + nb + (lq & 1) * 16 + (lq >> 1) * 8) = v;
+            }
         }
     }
 }
@@ -860,12 +887,20 @@ __global__ __launch_bounds__(512) void gemm_ring256_kernel(GemmP p, int KT) {
     #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int m = em0 + wr * 128 + i * 16 + lr;
+            const int mc = m < p.M ? m : p.M - 1;                                   // rows past M compute on a valid row and are not stored
             if constexpr (EPI == EPI_SWIGLU) {
-    #pragma unroll
-                for (int j = 0; j < 4; j += 2) { const int nb = en0 + wc * 64 + j * 16; if (nb + 32 <= p.N) big_store_swiglu(p, m, nb + lq * 4, acc[i][j], acc[i][j + 1]); }
+                const int nb = en0 + wc * 64;                                       // gate/up pairs (0,1) and (2,3) -> two neighbouring output tiles
+                const int ob = (nb >> 5) * 16;
+                const s16x8_t v = pair_to_row8(big_value_swiglu(acc[i][0], acc[i][1]), big_value_swiglu(acc[i][2], acc[i][3]));
+                if (m < p.M && nb + 32 * (lq & 1) + 32 <= p.N) *reinterpret_cast<s16x8_t*>((bf16_t*)p.Y + (long long)m * p.ldy + ob + (lq & 1) * 16 + (lq >> 1) * 8) = v;
             } else {
     #pragma unroll
-                for (int j = 0; j < 4; ++j) { const int nb = en0 + wc * 64 + j * 16; if (nb + 16 <= p.N) big_store<EPI>(p, m, nb + lq * 4, acc[i][j]); }
+                for (int j = 0; j < 4; j += 2) {
+                    const int nb = en0 + wc * 64 + j * 16;
+                    const int na = nb + 16 <= p.N ? nb : p.N - 16, nc = nb + 32 <= p.N ? nb + 16 : p.N - 16;      // N tail: clamp the reads
+                    const s16x8_t v = pair_to_row8(big_value<EPI>(p, mc, na + lq * 4, acc[i][j]), big_value<EPI>(p, mc, nc + lq * 4, acc[i][j + 1]));
+                    if (m < p.M && nb + 16 * (lq & 1) + 16 <= p.N) *reinterpret_cast<s16x8_t*>((bf16_t*)p.Y + (long long)m * p.ldy + nb + (lq & 1) * 16 + (lq >> 1) * 8) = v;
+                }
             }
         }
 #pragma unroll
