@@ -1,21 +1,26 @@
 #!/usr/bin/env python
 """bench.py -- frames/sec of the streaming video-text-duet forward path on MI355X.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a torchrun environment: bench.py launches its own
+                                                            N ranks through torch.distributed.run before touching a GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-One "step" = one pass of the hot path over one synthetic video stream per GPU (BASELINE.json configs[1]):
-T 1-fps uint8 frames [T,3,336,336] already resident in HBM -> device preprocess (Pillow-exact bicubic to 384, normalise)
--> SigLIP tower + projector + bilinear pooling (batches of 35 frames) -> per-frame causal LLaVA-OV-Qwen2-7B steps over the
-growing interleaved KV arena (one user query at t=0) -> informative/relevance head logits -> greedy per-frame response
-decision on the host -> greedy text generation (capped) when a frame fires.  Weights: seeded random init at the true
-shapes, bf16 (no checkpoints exist offline).  With N > 1 every rank runs its own stream (weak scaling) and the per-frame
-scores are all-gathered over RCCL inside the timed region.
+One "step" = one pass of the hot path over one synthetic video stream per GPU.  `--config`:
+  stream300  (default; BASELINE.json configs[1]) T = 300 1-fps uint8 frames [T,3,336,336] resident in HBM -> device preprocess
+             (Pillow-exact bicubic to 384, normalise) -> SigLIP tower + projector + bilinear pooling (batches of 35 frames) ->
+             causal LLaVA-OV-Qwen2-7B steps over the growing interleaved KV arena (one user query at t=0) -> informative /
+             relevance head logits -> greedy per-frame response decision on the host -> greedy text generation when a frame fires.
+  ground600  (configs[2]) 600 frames, grounding mode (`--stream_end_prob_threshold 1`: scores only, never generates,
+             scripts/inference/charades.sh:8-12).
+  qvh        (configs[3]) 150-frame grounding streams (QVHighlights clips, scripts/inference/qvh.sh:12), `--streams-per-gpu`
+             concurrent streams per rank in shared forwards, scores of all ranks met by ONE RCCL all-gather.
+Weights: seeded random init at the true shapes, bf16 (no checkpoints exist offline).  With N > 1 every rank runs its own
+streams (weak scaling) and the per-frame scores are all-gathered over RCCL inside the timed region.
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP events on the launch stream) and `cpu_baseline`
 (the oracle on the host cores, bounded sample).
 """
-import argparse, json, math, os, random, sys, time
+import argparse, json, math, os, random, socket, subprocess, sys, time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -23,6 +28,17 @@ import torch
 
 HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_BF16_PEAK_TF = 2500.0      # dense bf16 MFMA peak
+PMC_TRAFFIC = ('profiles/r02_pmc_traffic.json', 'profiles/r01_pmc_traffic.json')      # newest first
+
+CONFIGS = {
+    # name: (frames, responses, frames_per_forward, streams_per_gpu, workload text)
+    'stream300': dict(frames=300, responses=4, k=26, streams=1, mode='response',
+                      text='query at t=0, greedy per-frame response decision'),
+    'ground600': dict(frames=600, responses=0, k=26, streams=1, mode='grounding',
+                      text='grounding mode (threshold 1: scores only, no generation), KV grows to 29.4 k tokens'),
+    'qvh': dict(frames=150, responses=0, k=30, streams=1, mode='grounding',
+                text='QVHighlights-style 150-frame grounding streams, scores all-gathered over RCCL'),
+}
 
 
 def effective_cpus():
@@ -43,25 +59,66 @@ def effective_cpus():
     return n
 
 
-def parse():
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except Exception:
+        pass
+    return 'unknown'
+
+
+def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
     p.add_argument('--steps', type=int, default=2)
     p.add_argument('--warmup', type=int, default=1)
-    p.add_argument('--frames', type=int, default=300)
+    p.add_argument('--config', choices=sorted(CONFIGS), default='stream300')
+    p.add_argument('--frames', type=int, default=None)
     p.add_argument('--resolution', type=int, default=336)
-    p.add_argument('--frames-per-forward', type=int, default=26, help='frames per causal LLM forward (1 = the reference schedule; results agree up to fp reduction order)')
-    p.add_argument('--responses', type=int, default=4, help='responses per stream, forced at frames drawn once from random.Random(0) (random-init heads carry no signal)')
+    p.add_argument('--frames-per-forward', type=int, default=None, help='frames per causal LLM forward (1 = the reference schedule; results agree up to fp reduction order)')
+    p.add_argument('--responses', type=int, default=None, help='responses per stream, forced at frames drawn once from random.Random(0) (random-init heads carry no signal)')
+    p.add_argument('--streams-per-gpu', type=int, default=None, help='concurrent streams per rank inside the timed region (shared forwards, mmduet_amd/multistream.py)')
     p.add_argument('--max-new-tokens', type=int, default=32)
     p.add_argument('--tiny', action='store_true', help='tiny model (plumbing check, not a valid measurement)')
     p.add_argument('--no-overlap', action='store_true', help='run the vision tower and the LLM steps on one stream')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--prof-stride', type=int, default=7, help='bracket every n-th launch of the dominant kernel class with HIP events')
     p.add_argument('--no-prof', action='store_true', help='do not bracket the dominant kernel with HIP events in the timed region')
-    p.add_argument('--multi-stream', type=int, default=4, help='also measure S streams per GPU in shared forwards (reported under "multi_stream"; never the headline value)')
+    p.add_argument('--multi-stream', type=int, default=4, help='also measure S streams per GPU in shared forwards (reported under "multi_stream"; never the headline value; 0 = skip)')
     p.add_argument('--multi-frames-per-forward', type=int, default=13)
+    p.add_argument('--weights', choices=['bf16', 'fp8'], default='bf16', help='fp8 = e4m3 per-output-channel scaled LLM weights (BASELINE configs[4]); reported with dtype fp8, never the bf16 headline')
     p.add_argument('--layers', type=int, default=None, help='debug: override LLM layer count (INVALID as a measurement)')
-    return p.parse_args()
+    a = p.parse_args(argv)
+    c = CONFIGS[a.config]
+    if a.frames is None: a.frames = c['frames']
+    if a.responses is None: a.responses = c['responses']
+    if a.frames_per_forward is None: a.frames_per_forward = c['k']
+    if a.streams_per_gpu is None: a.streams_per_gpu = c['streams']
+    a.mode = c['mode']
+    if a.mode == 'grounding':
+        a.responses = 0
+    return a
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def launch_ranks_if_needed(args):
+    """`python bench.py --gpus N` (no torchrun environment): start N ranks as a CHILD process tree and exit with its code.  Done before
+    anything touches a GPU (`device_count()` does not initialise HIP on this image); never an exec from a process that has."""
+    if args.gpus <= 1 or 'RANK' in os.environ or 'WORLD_SIZE' in os.environ:
+        return
+    n = torch.cuda.device_count()
+    if n < args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but only {n} GPU(s) are visible')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 def build(args, device):
@@ -78,8 +135,10 @@ def build(args, device):
         cfg = VideoHeadLiveLlavaQwenConfig(frame_num_tokens=49, frame_resolution=384, v_placeholder='<image>')
         if args.layers:
             cfg.num_hidden_layers = args.layers
+    if args.weights == 'fp8':
+        cfg.weight_dtype = 'fp8_e4m3'
     k = max(1, args.frames_per_forward)
-    step_tokens = max(256, k * cfg.frame_num_tokens + 192)
+    step_tokens = max(256, max(1, args.streams_per_gpu) * (k * cfg.frame_num_tokens + 192))
     if getattr(args, 'multi_stream', 0):
         step_tokens = max(step_tokens, args.multi_stream * (args.multi_frames_per_forward * cfg.frame_num_tokens + 192))
     model = VideoHeadLiveLlavaQwenForCausalLM(cfg, torch_dtype=torch.bfloat16, device=device, max_vit_batch=35, max_step_tokens=step_tokens,
@@ -97,7 +156,7 @@ def bench_driver_class():
     class BenchDriver(LiveInferForBenchmark):
         """The per-frame decision rule runs unchanged (score vs threshold on the host, every frame); because random-init
         heads make the number of firing frames arbitrary, the frames that respond are pinned to a fixed schedule so the
-        workload (300 frame steps + R responses x max_new_tokens tokens) is the same for every build and schedule."""
+        workload (T frame steps + R responses x max_new_tokens tokens) is the same for every build and schedule."""
         forced_frames = frozenset()
 
         def _decide(self, video_scores):
@@ -109,7 +168,7 @@ def bench_driver_class():
 def driver_args(args, threshold, frames_per_forward=None):
     from mmduet_amd.arguments_live import LiveTestArguments
     return LiveTestArguments(llm_pretrained='synthetic:bench', frame_fps=1.0, bf16=True, stream_end_prob_threshold=threshold,
-                             score_heads='informative_score', max_new_tokens=args.max_new_tokens,
+                             score_heads='informative_score', max_new_tokens=args.max_new_tokens, grounding_mode=(args.mode == 'grounding'),
                              frames_per_forward=frames_per_forward or args.frames_per_forward, overlap_vision=not args.no_overlap,
                              system_prompt='A multimodal AI assistant is helping users with some activities.')
 
@@ -121,37 +180,39 @@ def make_driver(args, model, tok, threshold, forced=()):
     return d
 
 
+class MultiRunner:
+    """S streams per GPU through mmduet_amd.multistream (shared forwards); every stream responds at its own seeded frames."""
+
+    def __init__(self, args, model, tok, frames, query, n_streams, frames_per_forward):
+        from mmduet_amd.multistream import MultiStreamInfer
+        T = frames.shape[0]
+        a = driver_args(args, 1.0, frames_per_forward)
+        self.videos = [dict(frames=frames, conversation=[{'role': 'user', 'content': query, 'time': 0.0}],
+                            driver_attrs=dict(forced_frames=frozenset(random.Random(s).sample(range(1, T + 1), args.responses)) if args.responses > 0 else frozenset(),
+                                              eos_token_id=-1)) for s in range(n_streams)]
+        self.ms = MultiStreamInfer(a, model=model, tokenizer=tok, n_slots=n_streams, driver_cls=bench_driver_class())
+        self.T, self.n, self.responses = T, n_streams, args.responses
+
+    def run(self):
+        res = self.ms.run(self.videos)
+        assert all(len(r['debug_data']) == self.T and len(r['response_token_ids']) == self.responses for r in res)
+        self.last = res
+        return [torch.tensor([[x['informative_score'], x['relevance_score']] for x in r['debug_data']], dtype=torch.float32) for r in res]
+
+
 def run_multi_stream(args, model, tok, frames, query, n_streams, frames_per_forward, steps, warmup, device):
-    """S streams per GPU through mmduet_amd.multistream (shared forwards); every stream responds at its own 4 seeded frames.
-    Returns (frames/s, ms per step, scheduler rounds per step)."""
-    from mmduet_amd.multistream import MultiStreamInfer
-    T = frames.shape[0]
-    a = driver_args(args, 1.0, frames_per_forward)
-    videos = [dict(frames=frames, conversation=[{'role': 'user', 'content': query, 'time': 0.0}],
-                   driver_attrs=dict(forced_frames=frozenset(random.Random(s).sample(range(1, T + 1), args.responses)) if args.responses > 0 else frozenset(),
-                                     eos_token_id=-1)) for s in range(n_streams)]
-    ms = MultiStreamInfer(a, model=model, tokenizer=tok, n_slots=n_streams, driver_cls=bench_driver_class())
+    """Secondary measurement: returns (frames/s, ms per step, scheduler rounds per step, replayed frames, time-in-forwards fraction)."""
+    r = MultiRunner(args, model, tok, frames, query, n_streams, frames_per_forward)
     for _ in range(warmup):
-        ms.run(videos)
+        r.run()
     torch.cuda.synchronize(device)
-    ms.rounds = 0; ms.exec_seconds = 0.0
-    if os.environ.get('MMDUET_ROUND_LOG'):
-        ms.round_log = []
+    r.ms.rounds = 0; r.ms.exec_seconds = 0.0
     t0 = time.perf_counter()
     for _ in range(steps):
-        res = ms.run(videos)
+        r.run()
     torch.cuda.synchronize(device)
     dt = time.perf_counter() - t0
-    assert all(len(r['debug_data']) == T and len(r['response_token_ids']) == args.responses for r in res)
-    if ms.round_log:
-        import collections
-        agg = collections.defaultdict(lambda: [0, 0.0, 0])
-        prev = 0.0
-        for nseg, rows, t in ms.round_log:
-            b = agg[(nseg, 'decode-only' if rows <= nseg else ('<=256' if rows <= 256 else ('<=1024' if rows <= 1024 else '>1024')))]
-            b[0] += 1; b[2] += rows
-        print('round log (segments, rows class): count, rows', {k: (v[0], v[2]) for k, v in sorted(agg.items())}, file=sys.stderr)
-    return n_streams * steps * T / dt, dt / steps * 1e3, ms.rounds // steps, sum(r['replayed_frames'] for r in res), ms.exec_seconds / dt
+    return n_streams * steps * r.T / dt, dt / steps * 1e3, r.ms.rounds // steps, sum(x['replayed_frames'] for x in r.last), r.ms.exec_seconds / dt
 
 
 def run_stream(driver, frames, query):
@@ -164,54 +225,101 @@ def run_stream(driver, frames, query):
     return scores, n_resp
 
 
-def cpu_baseline(budget_s=25.0):
-    """The oracle (CPU restatement of the reference path) on the host cores, true layer shapes, bounded sample:
-    1 frame through patch-embed + 2 ViT layers + projector + pooling and one 49-token LLM step through 2 decoder
-    layers (+ final norm + heads), fp32; per-frame cost extrapolated to 26 ViT / 28 LLM layers."""
+def cpu_baseline():
+    """The oracle (CPU restatement of the reference path, sdpa) on the host cores, bounded sample (~15-25 s):
+      (a) BASELINE configs[0]: the 30-frame 336-px clip through the oracle stream driver on the tiny plumbing model, fp32;
+      (b) the true layer shapes: 1 frame through patch-embed + 1 of 26 SigLIP layers + projector + pooling and one 49-token step
+          through 1 of 28 Qwen2-7B decoder layers (KV context 7 350 tokens = the mean of a 300-frame stream), timed in fp32 AND bf16
+          and extrapolated linearly in layer count.  `value` is the faster of the two."""
     from oracle import duet_oracle as O
     torch.manual_seed(0)
     cores = torch.get_num_threads()
-    cfg = O.OracleConfig(num_hidden_layers=2, vit_layers=2, vocab_size=1024)
-    w = {}
-    for name, shape in O.weight_shapes(cfg).items():
-        w[name] = (torch.randn(shape) * 0.02) if len(shape) >= 2 else (torch.ones(shape) if name.endswith('weight') else torch.zeros(shape))
-    px = torch.randn(1, 3, 384, 384)
-    t0 = time.perf_counter(); O.vit_patch_embed(w, cfg, px); t_embed = time.perf_counter() - t0
-    t0 = time.perf_counter(); h = O.vit_forward(w, cfg, px); t_vit2 = time.perf_counter() - t0 - t_embed
-    t0 = time.perf_counter(); e = O.post_projector_pooling(cfg, O.connector(w, h)); t_proj = time.perf_counter() - t0
-    x = e.reshape(-1, cfg.hidden_size)
-    t0 = time.perf_counter(); hid, cache = O.llm_forward(w, cfg, x, None); t_llm2 = time.perf_counter() - t0
-    t0 = time.perf_counter(); hid, cache = O.llm_forward(w, cfg, x, cache); t_llm2 = min(t_llm2, time.perf_counter() - t0)
-    per_frame = t_embed + t_vit2 / 2 * 26 + t_proj + t_llm2 / 2 * 28
-    return dict(value=round(1.0 / per_frame, 4), unit='frames/s', cores=cores, kind='port',
-                sample=('oracle (oracle/duet_oracle.py), fp32, true layer shapes, empty KV: 1 frame x (patch-embed + 2 of 26 ViT layers + '
-                        'projector + pool) + one 49-token step x 2 of 28 decoder layers; per-frame time extrapolated linearly in layer count'),
-                per_frame_s=round(per_frame, 3))
+    out = dict(unit='frames/s', cores=cores, kind='port', cpu_model=cpu_model(), nproc=os.cpu_count())
+    # (a) configs[0] plumbing run
+    try:
+        sys.path.insert(0, os.path.join(ROOT, 'tests'))
+        from helpers import oracle_model, make_args, tokenizer_for, stream_cases
+        from mmduet_amd.inference import LiveInferForBenchmark
+        om, _, _ = oracle_model('A')
+        meta = stream_cases()
+        R = om.config.frame_resolution if hasattr(om.config, 'frame_resolution') else 56
+        frames = torch.randint(0, 256, (30, 3, 336, 336), dtype=torch.uint8, generator=torch.Generator().manual_seed(0))
+        frames = torch.nn.functional.interpolate(frames.float(), size=(R, R), mode='nearest').to(torch.uint8)     # the tiny tower's resolution
+        d = LiveInferForBenchmark(make_args(system_prompt=meta['system_prompt'], stream_end_prob_threshold=1.0), model=om, tokenizer=tokenizer_for(om.config))
+        t0 = time.perf_counter()
+        d.input_video_stream(frames); d.inference()
+        out['config1_tiny_fp32_frames_per_s'] = round(30 / (time.perf_counter() - t0), 1)
+    except Exception as e:                                   # the plumbing leg never blocks the line
+        out['config1_tiny_fp32_frames_per_s'] = f'error: {type(e).__name__}: {e}'
+    # (b) true layer shapes
+    per = {}
+    for dt_name, dt in (('fp32', torch.float32), ('bf16', torch.bfloat16)):
+        cfg = O.OracleConfig(num_hidden_layers=1, vit_layers=1, vocab_size=1024)
+        w = {}
+        g = torch.Generator().manual_seed(0)
+        for name, shape in O.weight_shapes(cfg).items():
+            t = (torch.randn(shape, generator=g) * 0.02) if len(shape) >= 2 else (torch.ones(shape) if name.endswith('weight') else torch.zeros(shape))
+            w[name] = t.to(dt)
+        px = torch.randn(1, 3, 384, 384, generator=g).to(dt)
+        # KV context of 7350 tokens (the mean over a 300-frame stream) as random K / V: computing it would be a 7350-row prefill
+        cache = O.KVHandle([(torch.randn(cfg.num_key_value_heads, 7350, cfg.head_dim, generator=g) * 0.5).to(dt)],
+                           [(torch.randn(cfg.num_key_value_heads, 7350, cfg.head_dim, generator=g) * 0.5).to(dt)])
+        best = None
+        for rep in range(2):                                # first repetition pays page faults / kernel selection
+            t0 = time.perf_counter(); O.vit_patch_embed(w, cfg, px); t_embed = time.perf_counter() - t0
+            t0 = time.perf_counter(); h = O.vit_forward(w, cfg, px); t_vit1 = time.perf_counter() - t0 - t_embed
+            t0 = time.perf_counter(); e = O.post_projector_pooling(cfg, O.connector(w, h)); t_proj = time.perf_counter() - t0
+            x = e.reshape(-1, cfg.hidden_size)
+            t0 = time.perf_counter(); O.llm_forward(w, cfg, x, cache); t_llm1 = time.perf_counter() - t0
+            pf = t_embed + max(t_vit1, 0.0) * 26 + t_proj + t_llm1 * 28
+            best = pf if best is None else min(best, pf)
+        per[dt_name] = best
+    pf = min(per.values())
+    out.update(value=round(1.0 / pf, 4), per_frame_s={k: round(v, 3) for k, v in per.items()},
+               sample=('oracle (oracle/duet_oracle.py, torch CPU sdpa): (a) configs[0] 30-frame clip through the oracle stream driver, tiny plumbing model, fp32; '
+                       '(b) true layer shapes, 1 frame x (patch-embed + 1 of 26 ViT layers + projector + pool) + one 49-token step x 1 of 28 decoder layers over a '
+                       '7350-token KV context, fp32 and bf16, per-frame time extrapolated linearly in layer count; value = 1 / min(per_frame_s)'))
+    return out
 
 
 def main():
     args = parse()
+    launch_ranks_if_needed(args)
     torch.set_num_threads(max(1, effective_cpus() // max(1, int(os.environ.get('WORLD_SIZE', '1')))))   # host-side torch ops (and the CPU baseline) use the cores this process really has
-    from mmduet_amd.distributed import init_distributed, gather_scores
+    from mmduet_amd.distributed import init_distributed, gather_scores, NativeScoreGather
     import torch.distributed as dist
     rank, world, local = init_distributed()
-    if world != args.gpus and world > 1:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but the launch environment has WORLD_SIZE={world}')
     device = torch.device('cuda', local)
     torch.cuda.set_device(device)
+    rccl_ranks = 1
+    if world > 1:
+        one = torch.ones(1, device=device)
+        dist.all_reduce(one)                                # RCCL all-reduce: every rank really is in the communicator
+        rccl_ranks = int(one.item())
+        if rccl_ranks != args.gpus:
+            raise SystemExit(f'bench.py: RCCL communicator has {rccl_ranks} ranks, --gpus {args.gpus}')
     model, tok, cfg = build(args, device)
     R = args.resolution if not args.tiny else 48
     g = torch.Generator().manual_seed(1 + rank)
     frames = torch.randint(0, 256, (args.frames, 3, R, R), dtype=torch.uint8, generator=g).to(device)     # resident in HBM
     query = 'Please narrate the video in real time.'[:24]
-
-    # untimed pass with every kernel class bracketed: finds the dominant kernel class of this schedule
-    T = args.frames
+    T, S = args.frames, max(1, args.streams_per_gpu)
     forced = sorted(random.Random(0).sample(range(1, T + 1), args.responses)) if args.responses > 0 else []   # fixed pseudo-random frames
     threshold = 1.0          # informative probability never exceeds 1: the rule is evaluated every frame but responses follow `forced`
     driver = make_driver(args, model, tok, threshold, forced)
+    multi_runner = MultiRunner(args, model, tok, frames, query, S, args.frames_per_forward) if S > 1 else None
+
+    def one_step():
+        if multi_runner is not None:
+            return multi_runner.run(), args.responses
+        sc, n_resp = run_stream(driver, frames, query)
+        return [sc], n_resp
+
+    # untimed pass with every kernel class bracketed: finds the dominant kernel class of this schedule
     model.prof_reset(); model.prof_enable(True)
-    run_stream(driver, frames, query)
+    one_step()
     model.prof_enable(False)
     prof_all = model.prof_read()
     dom = max(prof_all, key=lambda k: prof_all[k]['ms'])
@@ -222,10 +330,23 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
+    # the C-ABI gather (mmd_gather_scores: ncclAllGather issued by libmmduet_hip) is checked against torch.distributed's outside
+    # the timed region; the timed region uses the torch.distributed transport
+    native = None
     n_resp = 0
-    for _ in range(args.warmup):
-        sc, n_resp = run_stream(driver, frames, query)
-        gather_scores([sc])
+    for w in range(max(1, args.warmup) if world > 1 else args.warmup):
+        scs, n_resp = one_step()
+        allsc, lens = gather_scores(scs, t_max=T, n_max=S)
+        if w == 0:
+            try:
+                ng = NativeScoreGather(device)
+                a2, l2 = ng.gather(scs[0].to(device), T)
+                torch.cuda.synchronize(device)
+                ok = torch.equal(l2.cpu(), lens[:, 0].cpu()) and torch.equal(torch.nan_to_num(a2.cpu()), torch.nan_to_num(allsc[:, 0].cpu()))
+                native = 'ok' if ok else 'MISMATCH vs torch.distributed'
+                ng.close()
+            except Exception as e:
+                native = f'error: {type(e).__name__}: {e}'
     prof_on = not args.no_prof
     model.prof_reset()
     model.prof_set_stride(args.prof_stride)                 # every 7th launch of the class carries the two HIP events (sampling)
@@ -234,9 +355,9 @@ def main():
     t0 = time.perf_counter()
     fwd = 0
     for _ in range(args.steps):
-        sc, n_resp = run_stream(driver, frames, query)
-        allsc, lens = gather_scores([sc])
-        fwd += driver.forward_calls
+        scs, n_resp = one_step()
+        allsc, lens = gather_scores(scs, t_max=T, n_max=S)                 # ONE RCCL all-gather of the padded score block
+        fwd += driver.forward_calls if multi_runner is None else multi_runner.ms.rounds
     sync()
     dt = time.perf_counter() - t0
     model.prof_enable(False)
@@ -245,39 +366,53 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     prof = model.prof_read()
+    assert allsc.shape == (world, S, T, 2) and int(lens.min()) == T
 
-    if rank == 0:
-        total_frames = world * args.steps * args.frames
-        value = total_frames / dt
-        # dominant kernel class by accumulated time
-        if not prof_on:
-            dom = None
-        roof = None
-        if dom and prof[dom]['launches'] > 0:
-            p = prof[dom]
-            avg_ms = p['ms'] / p['launches']
-            if dom in ('gemm_tile', 'attn_vit'):
-                ach = p['flops'] / p['launches'] / (avg_ms * 1e-3) / 1e12
-                roof = dict(bound='mfma', kernel=dom, achieved=round(ach, 2), peak=MFMA_BF16_PEAK_TF, unit='TFLOP/s', frac=round(ach / MFMA_BF16_PEAK_TF, 4), traffic=None)
-            else:
-                ach = p['bytes'] / p['launches'] / (avg_ms * 1e-3) / 1e9
-                roof = dict(bound='hbm', kernel=dom, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(ach / HBM_PEAK_GBS, 4), traffic=None)
-            # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
-            # runs of this same workload; gfx950 FETCH_SIZE correction applied) -- not re-measured here
+    def roof_from(p, name):
+        avg_ms = p['ms'] / p['launches']
+        if name in ('gemm_tile', 'attn_vit'):
+            ach = p['flops'] / p['launches'] / (avg_ms * 1e-3) / 1e12
+            r = dict(bound='mfma', kernel=name, achieved=round(ach, 2), peak=MFMA_BF16_PEAK_TF, unit='TFLOP/s', frac=round(ach / MFMA_BF16_PEAK_TF, 4), traffic=None)
+        else:
+            ach = p['bytes'] / p['launches'] / (avg_ms * 1e-3) / 1e9
+            r = dict(bound='hbm', kernel=name, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(ach / HBM_PEAK_GBS, 4), traffic=None)
+        r['avg_launch_us'] = round(avg_ms * 1e3, 2)
+        r['launches_timed'] = int(p['launches'])
+        return r
+
+    roof = None
+    if prof_on and prof[dom]['launches'] > 0:
+        roof = roof_from(prof[dom], dom)
+        roof['sampling_stride'] = args.prof_stride
+        # the tower runs on a side stream next to the LLM steps: two MFMA-bound kernels then share the CUs and every launch of the
+        # class reads longer than it would alone.  One more untimed pass on ONE stream gives the per-kernel figure.
+        if not args.no_overlap and multi_runner is None:
+            d2 = make_driver(argparse.Namespace(**{**vars(args), 'no_overlap': True}), model, tok, threshold, forced)
+            model.prof_reset(); model.prof_set_stride(1); model.prof_enable([dom])
+            run_stream(d2, frames, query)
+            model.prof_enable(False)
+            p2 = model.prof_read()[dom]
+            if p2['launches'] > 0:
+                r2 = roof_from(p2, dom)
+                roof['single_stream_pass'] = dict(achieved=r2['achieved'], frac=r2['frac'], avg_launch_us=r2['avg_launch_us'], launches=r2['launches_timed'],
+                                                  note='same stream, tower and LLM on one HIP stream, every launch of the class bracketed, untimed')
+        # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
+        # runs of this same workload; gfx950 FETCH_SIZE correction applied) -- not re-measured here
+        for path in PMC_TRAFFIC:
             try:
-                tr = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json'))).get(dom)
+                tr = json.load(open(os.path.join(ROOT, path))).get(dom)
                 if tr:
                     roof['traffic'] = round(tr['hbm_bytes_per_launch'])
-                    roof['traffic_source'] = 'profiles/r01_pmc_traffic.json'
+                    roof['traffic_source'] = path
+                    break
             except Exception:
                 pass
-            roof['avg_launch_us'] = round(avg_ms * 1e3, 2)
-            roof['launches_timed'] = int(p['launches'])
-            roof['sampling_stride'] = args.prof_stride
-            roof['per_class_ms_untimed_pass'] = {k: round(v['ms'], 1) for k, v in prof_all.items()}
-        cpu = None if (args.no_cpu_baseline or args.tiny or world > 1) else cpu_baseline()
+        roof['per_class_ms_untimed_pass'] = {k: round(v['ms'], 1) for k, v in prof_all.items()}
+    cpu = None
+    if rank == 0 and not (args.no_cpu_baseline or args.tiny or world > 1):
+        cpu = cpu_baseline()
     multi = None
-    if args.multi_stream > 1:
+    if args.multi_stream > 1 and multi_runner is None and args.mode == 'response':
         # secondary measurement, outside the timed region and never the headline: S streams per GPU in shared forwards
         fps, ms_step, rounds, replay, frac = run_multi_stream(args, model, tok, frames, query, args.multi_stream, args.multi_frames_per_forward,
                                                               steps=1, warmup=1, device=device)
@@ -285,17 +420,21 @@ def main():
                      ms_per_step=round(ms_step, 1), forwards_per_step=rounds, replayed_frames=replay, time_in_forwards_frac=round(frac, 3),
                      note='mmduet_amd.multistream: one LLM forward carries frame chunks and decode rows of all streams; per-stream results as single-stream')
     if rank == 0:
+        total_frames = world * S * args.steps * args.frames
+        value = total_frames / dt
+        kv_end = int(len(driver.past_key_values)) if multi_runner is None else int(multi_runner.last[0]['final_kv_len'])
         line = {
             'metric': 'video frames/sec (stream decode, 1fps 336px)', 'value': round(value, 2), 'unit': 'frames/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 2),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16' if args.weights == 'bf16' else 'fp8_e4m3 weights x bf16 activations',
+            'data': 'synthetic', 'rccl_ranks': rccl_ranks,
             'config': {'workload': ('tiny-plumbing' if args.tiny else 'llava-onevision-qwen2-7b + siglip-so400m-384') +
-                       f', {args.frames}-frame 1fps {R}px stream per GPU, query at t=0, greedy per-frame response decision',
-                       'frames_per_forward': args.frames_per_forward, 'responses_per_stream': int(n_resp),
+                       f', {args.frames}-frame 1fps {R}px stream{"s" if S > 1 else ""} ({S} per GPU), ' + CONFIGS[args.config]['text'],
+                       'name': args.config, 'frames_per_forward': args.frames_per_forward, 'streams_per_gpu': S, 'responses_per_stream': int(n_resp),
                        'max_new_tokens': args.max_new_tokens, 'response_frames': forced, 'llm_forwards_per_step': fwd // max(1, args.steps),
-                       'kv_tokens_end': int(len(driver.past_key_values)), 'weights': 'random init N(0,0.02), true shapes' if not args.tiny else 'tiny',
-                       'parallelism': f'dp{world} (one stream per GPU, RCCL all-gather of scores)',
-                       'layers_override': args.layers},
+                       'kv_tokens_end': kv_end, 'weights': ('random init N(0,0.02), true shapes' if not args.tiny else 'tiny') + ('' if args.weights == 'bf16' else ', LLM matrices quantised to fp8 e4m3 per output channel'),
+                       'parallelism': f'dp{world} ({S} stream(s) per GPU, one RCCL all-gather of the [{world},{S},{T}+1,2] score block per step)',
+                       'native_gather_check': native, 'tower_overlap': not args.no_overlap, 'layers_override': args.layers},
             'roofline': roof, 'cpu_baseline': cpu, 'multi_stream': multi,
         }
         print(json.dumps(line), flush=True)

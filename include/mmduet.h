@@ -109,8 +109,9 @@ int mmd_stream_create(mmd_ctx* ctx, int64_t initial_tokens, mmd_stream** out);
 void mmd_stream_destroy(mmd_stream* s);
 int64_t mmd_kv_len(const mmd_stream* s);
 int64_t mmd_kv_capacity(const mmd_stream* s);
-int mmd_kv_truncate(mmd_stream* s, int64_t new_len);
-int mmd_kv_debug_set_len(mmd_stream* s, int64_t n);       /* measurement aid: mark n slots live without computing them */     /* rollback: remove_assistant_turns (test/inference.py:265-269), speculative chunks */
+int mmd_kv_truncate(mmd_stream* s, int64_t new_len);      /* rollback: remove_assistant_turns (test/inference.py:265-269), speculative chunks */
+int mmd_stream_reset(mmd_stream* s);                      /* LiveInferForBenchmark.reset (test/inference.py:169-183: past_key_values = None): length 0, arena kept */
+int mmd_kv_debug_set_len(mmd_stream* s, int64_t n);       /* measurement aid: mark n slots live without computing them */
 
 /* replaces VideoHeadLiveLlavaQwenForCausalLM.forward body (models/live_llava/video_head_live_llava_qwen.py:141) ==
  * Qwen2Model.forward for batch 1: embeds [S, hidden] are appended at positions kv_len..kv_len+S-1; hidden_out
@@ -147,6 +148,22 @@ int mmd_frame_step_multi(mmd_ctx* ctx, mmd_stream* const* streams, const int32_t
 int mmd_greedy_generate(mmd_ctx* ctx, mmd_stream* s, const void* prompt_embeds, int S, int64_t eos_id, float rep_penalty,
                         int64_t* prev_ids_host, int* n_prev, int prev_cap, int64_t* out_ids_host, int max_new, int* n_out);
 
+/* ---- multi-GPU: the one collective of the path ------------------------------------------------------------------ */
+/* The reference shards videos over N manually launched processes (--start_idx/--end_idx, test/inference.py:337) and has no
+ * collective; here one process per GPU gathers the per-frame head scores of its streams with ONE RCCL all-gather over xGMI.
+ * Rank 0 draws an id (mmd_comm_unique_id, host bytes), the launcher's rendezvous store hands it to every rank, each rank calls
+ * mmd_comm_create (collective).  mmd_gather_scores: local [T,2] fp32 (device; informative, relevance probability per frame)
+ * -> all [world, t_max+1, 2] fp32 (device): row 0 of every rank's block = (T, 0), rows 1..T the scores, NaN beyond.  Enqueued
+ * on the communicator's stream, no host synchronisation. */
+#define MMD_COMM_ID_BYTES 128
+typedef struct mmd_comm mmd_comm;
+int mmd_comm_unique_id(uint8_t* id_out_host);
+int mmd_comm_create(const uint8_t* id_host, int rank, int world, int device, void* hip_stream, mmd_comm** out);
+void mmd_comm_destroy(mmd_comm* comm);
+int mmd_comm_world(const mmd_comm* comm);
+const char* mmd_comm_last_error(const mmd_comm* comm);    /* comm may be NULL: error of the last failed create / unique_id */
+int mmd_gather_scores(mmd_comm* comm, const float* local, int T, int t_max, float* all);
+
 /* ---- measurement ---------------------------------------------------------------------------------------------- */
 /* HIP-event timing of kernel classes on the context's stream (bench.py `roofline`).  While enabled every launch of a
  * enabled class is bracketed by events; mmd_prof_read returns accumulated ms and launch counts. */
@@ -164,8 +181,12 @@ int mmd_prof_reset(mmd_ctx* ctx);
  * 1 generic tile, 2 skinny/split-K, 3 large tile, 4 DMA 128-row tile, 5 skinny slabs, 6 256x256 ring. */
 int mmd_op_gemm(mmd_ctx* ctx, const void* X, const void* W, const void* bias, const void* R, void* Y, int M, int N, int K,
                 int epi, int out_f32, int variant);
-/* micro-benchmark of one GEMM shape (HIP events on the context's stream); avg ms per call incl. any split-K reduce */
-int mmd_op_gemm_bench(mmd_ctx* ctx, int M, int N, int K, int epi, int variant, int iters, float* avg_ms_out);
+/* what the dispatcher chose for the most recent GEMM of this context: out4 = {kernel (0 tile64, 1 tile128, 2 skinny, 3 gemv16, 4 big64,
+ * 5 big128, 6 ring256), output tiles, K splits, blocks launched} */
+int mmd_op_gemm_last_plan(mmd_ctx* ctx, int* out4);
+/* micro-benchmark of one GEMM shape (HIP events on the context's stream); avg ms per call incl. any split-K reduce.  X [M,K] / W [N,K]
+ * (device, ctx dtype) supply the operand VALUES (random data: operand bits set the chip's clock); NULL = a constant fill */
+int mmd_op_gemm_bench(mmd_ctx* ctx, int M, int N, int K, int epi, int variant, int iters, float* avg_ms_out, const void* X, const void* W);
 int mmd_op_rmsnorm(mmd_ctx* ctx, const void* x, const void* w, void* y, int M, int H, float eps);
 int mmd_op_layernorm(mmd_ctx* ctx, const void* x, const void* w, const void* b, void* y, int M, int H, float eps);
 /* q [S, nh*d] (rotated in place), k/v [S, nkv*d] appended rotated/unrotated at pos0.. into Kc/Vc [nkv, cap, d] */

@@ -57,6 +57,13 @@ _SIGS = {
     'mmd_kv_capacity': (_I64, [_VP]),
     'mmd_kv_truncate': (_I, [_VP, _I64]),
     'mmd_kv_debug_set_len': (_I, [_VP, _I64]),
+    'mmd_stream_reset': (_I, [_VP]),
+    'mmd_comm_unique_id': (_I, [_VP]),
+    'mmd_comm_create': (_I, [_VP, _I, _I, _I, _VP, C.POINTER(_VP)]),
+    'mmd_comm_destroy': (None, [_VP]),
+    'mmd_comm_world': (_I, [_VP]),
+    'mmd_comm_last_error': (C.c_char_p, [_VP]),
+    'mmd_gather_scores': (_I, [_VP, _VP, _I, _I, _VP]),
     'mmd_llm_step': (_I, [_VP, _VP, _VP, _I, _VP]),
     'mmd_video_heads': (_I, [_VP, _VP, _I, _VP]),
     'mmd_lm_head': (_I, [_VP, _VP, _I, _VP]),
@@ -69,7 +76,8 @@ _SIGS = {
     'mmd_prof_read': (_I, [_VP, _VP, _VP, _VP, _VP]),
     'mmd_prof_reset': (_I, [_VP]),
     'mmd_op_gemm': (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _I]),
-    'mmd_op_gemm_bench': (_I, [_VP, _I, _I, _I, _I, _I, _I, C.POINTER(_F)]),
+    'mmd_op_gemm_bench': (_I, [_VP, _I, _I, _I, _I, _I, _I, C.POINTER(_F), _VP, _VP]),
+    'mmd_op_gemm_last_plan': (_I, [_VP, C.POINTER(_I)]),
     'mmd_op_rmsnorm': (_I, [_VP, _VP, _VP, _VP, _I, _I, _F]),
     'mmd_op_layernorm': (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _F]),
     'mmd_op_rope_append': (_I, [_VP, _VP, _I, _I, _I, _I, _F, _I64, _VP, _VP, _VP, _I64]),

@@ -97,7 +97,10 @@ struct GemmArgs {
     int no_gemv = 0;                            // A/B switch: use the LDS-staged skinny kernel also for M <= 16
     int* slabs_out = nullptr;                   // if set (packed skinny path only): leave [splits][M][N] fp32 slabs in splitk_ws, no
                                                 // epilogue, and return the split count here; a fused consumer kernel reduces them
+    int* plan_out = nullptr;                    // if set: int[4] = {kernel (GEMM_K_*), output tiles, K splits, blocks launched}
 };
+// which kernel the dispatcher chose (mmd_op_gemm_last_plan; parity tests assert the production kernel really ran)
+enum { GEMM_K_TILE64 = 0, GEMM_K_TILE128 = 1, GEMM_K_SKINNY = 2, GEMM_K_GEMV16 = 3, GEMM_K_BIG64 = 4, GEMM_K_BIG128 = 5, GEMM_K_RING256 = 6 };
 bool gemm_can_slab(int dtype, const GemmArgs& a);
 
 // launchers (dtype = mmd_dtype).  All return hipError_t of the launch.

@@ -468,6 +468,10 @@ __global__ __launch_bounds__(256) void gemm_gemv16_kernel(GemmP p, int KT) {
     }
 }
 
+static inline void set_plan(const GemmArgs& a, int kernel, int tiles, int splits, int blocks) {
+    if (a.plan_out) { a.plan_out[0] = kernel; a.plan_out[1] = tiles; a.plan_out[2] = splits; a.plan_out[3] = blocks; }
+}
+
 static void launch_gemv16(const GemmP& p, const GemmArgs& a, hipStream_t st) {
     const int KT = a.K >> 5, ntiles = a.N >> 4;
     int ksplit = 1;
@@ -476,6 +480,7 @@ static void launch_gemv16(const GemmP& p, const GemmArgs& a, hipStream_t st) {
         while (ksplit > 1 && (size_t)ksplit * a.M * a.N * sizeof(float) > a.splitk_ws_bytes) --ksplit;
     }
     if (a.slabs_out) *a.slabs_out = ksplit;
+    set_plan(a, GEMM_K_GEMV16, ntiles, ksplit, (a.epi == EPI_SWIGLU || (ntiles % 2 == 0 && ntiles >= 2048) ? ntiles / 2 : ntiles) * ksplit);
     if (a.epi == EPI_SWIGLU || (ntiles % 2 == 0 && ntiles >= 2048)) hipLaunchKernelGGL((gemm_gemv16_kernel<2, 8>), dim3(ntiles / 2, ksplit), dim3(256), 0, st, p, KT);
     else hipLaunchKernelGGL((gemm_gemv16_kernel<1, 8>), dim3(ntiles, ksplit), dim3(256), 0, st, p, KT);
 }
@@ -496,6 +501,7 @@ static void launch_skinny_mt(const GemmP& p, const GemmArgs& a, hipStream_t st) 
     int ktper = (int)round_up(cdiv(KT, splits), 4);
     splits = cdiv(KT, ktper);
     dim3 grid(nblocks, splits);
+    set_plan(a, GEMM_K_SKINNY, ntiles, splits, nblocks * splits);
     if (NT == 2) hipLaunchKernelGGL((gemm_skinny_kernel<MT, 2>), grid, dim3(256), 0, st, p, KT, ktper);
     else hipLaunchKernelGGL((gemm_skinny_kernel<MT, 1>), grid, dim3(256), 0, st, p, KT, ktper);
     if (a.slabs_out) { *a.slabs_out = splits; return; }
@@ -702,6 +708,7 @@ static void launch_big(const GemmP& p, const GemmArgs& a, hipStream_t st) {
         while (splits > 1 && (size_t)splits * a.M * a.N * sizeof(float) > a.splitk_ws_bytes) --splits;
     }
     dim3 grid(a.N / BN, cdiv(a.M, 128), splits);
+    set_plan(a, BN == 128 ? GEMM_K_BIG128 : GEMM_K_BIG64, tiles, splits, tiles * splits);
     const int KT = a.K >> 5;
     switch (a.epi) {
         case EPI_GELU_TANH: hipLaunchKernelGGL((gemm_big_kernel<BN, EPI_GELU_TANH>), grid, dim3(256), 0, st, p, KT); break;
@@ -915,6 +922,7 @@ static hipError_t launch_ring256(const GemmP& p, const GemmArgs& a, hipStream_t 
     const int tiles = cdiv(a.N, 256) * cdiv(a.M, 256);
     // one block per CU, looping over its tiles (split-K launches keep one tile per block: their blocks already fill the machine once)
     dim3 grid(splits > 1 || tiles <= 256 ? tiles : 256, 1, splits);
+    set_plan(a, GEMM_K_RING256, tiles, splits, (int)grid.x * splits);
     const int KT = a.K >> 5;
     const size_t smem = 3 * (256 * 32 + 256 * 32) * sizeof(bf16_t);          // 96 KB
     static bool attr_set = false;
@@ -1030,9 +1038,11 @@ static hipError_t launch_t(const GemmArgs& a, hipStream_t st, int* kind_out) {
     p.kper = kper;
     if (large) {
         dim3 grid(cdiv(a.N, 128), cdiv(a.M, 128), 1);
+        set_plan(a, GEMM_K_TILE128, (int)(grid.x * grid.y), 1, (int)(grid.x * grid.y));
         hipLaunchKernelGGL((gemm_tile_kernel<T, 128, 128>), grid, dim3(256), 0, st, p);
     } else {
         dim3 grid(cdiv(a.N, 64), cdiv(a.M, 64), splits);
+        set_plan(a, GEMM_K_TILE64, (int)(grid.x * grid.y), splits, (int)(grid.x * grid.y) * splits);
         hipLaunchKernelGGL((gemm_tile_kernel<T, 64, 64>), grid, dim3(256), 0, st, p);
         if (splits > 1) {
             long long work = (long long)a.M * ((a.N + 3) / 4);

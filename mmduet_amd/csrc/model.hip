@@ -7,6 +7,7 @@
 //       mmd_video_heads + mmd_lm_head
 //   fast_greedy_generate (models/modeling_live.py:51-77) -> mmd_greedy_generate
 #include "common.h"
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
@@ -58,6 +59,8 @@ struct mmd_ctx {
     void *l_h = 0, *l_xn = 0, *l_qkv = 0, *l_q = 0, *l_attn = 0, *l_act = 0, *l_hid = 0;
     float* splitk_ws = 0; size_t splitk_bytes = 0;
     float* attn_ws = 0; size_t attn_bytes = 0;
+    float* v_splitk_ws = 0; size_t v_splitk_bytes = 0;   // the tower runs on a side stream next to LLM steps: its own split-K / split-KV scratch
+    float* v_attn_ws = 0; size_t v_attn_bytes = 0;
     float* logits_ws = 0;              // [V] fp32 for generation
     float* heads_dev = 0;              // [max_step_tokens,4]
     int32_t* rows_dev = 0;
@@ -75,6 +78,7 @@ struct mmd_ctx {
     StepState* step_dev = nullptr; StepState* step_host = nullptr;
     hipGraphExec_t dec_graph = nullptr; hipGraph_t dec_graph_src = nullptr;
     float dec_pen = 0.f; int64_t dec_eos = 0; bool no_graph = false;
+    int last_plan[4] = {-1, 0, 0, 0};   // kernel / tiles / splits / blocks of the most recent gemm() (mmd_op_gemm_last_plan)
     bool no_fuse = false;              // MMDUET_NO_FUSE=1: keep the unfused launch schedule (A/B and parity cross-check)
     Prof prof;
 };
@@ -136,11 +140,12 @@ static void prof_drain(mmd_ctx* c) {
 
 // ---- GEMM wrapper --------------------------------------------------------------------------------------------------
 static int gemm(mmd_ctx* c, const void* X, int64_t ldx, const void* W, int64_t ldw, const void* bias, const void* R, int64_t ldr, void* Y,
-                int64_t ldy, int M, int N, int K, int epi, int out_f32 = 0, int variant = GEMM_AUTO, const void* Wp = nullptr) {
+                int64_t ldy, int M, int N, int K, int epi, int out_f32 = 0, int variant = GEMM_AUTO, const void* Wp = nullptr, bool tower = false) {
     GemmArgs a;
     a.X = X; a.ldx = ldx; a.W = W; a.ldw = ldw; a.Wp = Wp; a.bias = bias; a.R = R; a.ldr = ldr; a.Y = Y; a.ldy = ldy;
     a.M = M; a.N = N; a.K = K; a.epi = epi; a.out_f32 = out_f32; a.variant = variant;
-    a.splitk_ws = c->splitk_ws; a.splitk_ws_bytes = c->splitk_bytes;
+    a.splitk_ws = tower ? c->v_splitk_ws : c->splitk_ws; a.splitk_ws_bytes = tower ? c->v_splitk_bytes : c->splitk_bytes;
+    a.plan_out = c->last_plan;
     int kind = (variant == GEMM_SKINNY || (variant != GEMM_BIG && variant != GEMM_RING256 && variant != GEMM_RING256_SPLIT && variant != GEMM_LARGE && variant != GEMM_GENERIC && M <= 64)) ? MMD_K_GEMM_SKINNY : MMD_K_GEMM_TILE;
     double e = (double)es(c);
     double bytes = ((double)M * K + (double)N * K) * e + (double)M * (epi == EPI_SWIGLU ? N / 2 : N) * (out_f32 ? 4.0 : e);
@@ -439,6 +444,8 @@ static int alloc_workspaces(mmd_ctx* c) {
     WS(c->l_act, (size_t)S * g.intermediate_size * e); WS(c->l_hid, (size_t)S * H * e);
     c->splitk_bytes = (size_t)64 << 20; WS(c->splitk_ws, c->splitk_bytes);
     c->attn_bytes = (size_t)128 << 20; WS(c->attn_ws, c->attn_bytes);
+    c->v_splitk_bytes = (size_t)32 << 20; WS(c->v_splitk_ws, c->v_splitk_bytes);
+    c->v_attn_bytes = (size_t)32 << 20; WS(c->v_attn_ws, c->v_attn_bytes);
     WS(c->logits_ws, (size_t)g.vocab_size * sizeof(float));
     WS(c->heads_dev, (size_t)S * 4 * sizeof(float)); WS(c->rows_dev, (size_t)S * sizeof(int32_t));
     WS(c->tok_dev, 64); WS(c->argmax_scratch, 1024); c->prev_cap = 16384; WS(c->prev_dev, (size_t)c->prev_cap * sizeof(int64_t));
@@ -462,30 +469,30 @@ extern "C" int mmd_vit_encode(mmd_ctx* c, const void* px, int B, void* out) {
     if (B > g.max_vit_batch) FAIL(c, MMD_ERANGE, "vit batch %d exceeds max_vit_batch %d", B, g.max_vit_batch);
     const int C = g.vit_hidden, H = g.hidden_size, T = c->vit_tokens, M = B * T, hd = C / g.vit_heads;
     { ProfScope ps(c, MMD_K_OTHER, 0, 0); HIPCHK(c, launch_im2col(dt, px, B, g.vit_image, g.vit_patch, c->vit_grid, c->vit_kpad, c->v_col, st)); }
-    int rc = gemm(c, c->v_col, c->vit_kpad, c->patch_w, c->vit_kpad, c->patch_b, nullptr, 0, c->v_h, C, M, C, c->vit_kpad, EPI_NONE, 0, GEMM_AUTO, c->patch_w_p); if (rc) return rc;
+    int rc = gemm(c, c->v_col, c->vit_kpad, c->patch_w, c->vit_kpad, c->patch_b, nullptr, 0, c->v_h, C, M, C, c->vit_kpad, EPI_NONE, 0, GEMM_AUTO, c->patch_w_p, true); if (rc) return rc;
     { ProfScope ps(c, MMD_K_OTHER, 0, 0); HIPCHK(c, launch_add_rows(dt, c->v_h, c->pos_emb, M, C, T, st)); }
     for (int i = 0; i < g.vit_layers; ++i) {
         VitLayer& L = c->VL[i];
         { ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * M * C * es(c), 0); HIPCHK(c, launch_layernorm(dt, c->v_h, L.ln1w, L.ln1b, c->v_xn, M, C, g.vit_ln_eps, st)); }
-        rc = gemm(c, c->v_xn, C, L.wqkv, C, L.bqkv, nullptr, 0, c->v_qkv, 3 * C, M, 3 * C, C, EPI_NONE, 0, GEMM_AUTO, L.wqkv_p); if (rc) return rc;
+        rc = gemm(c, c->v_xn, C, L.wqkv, C, L.bqkv, nullptr, 0, c->v_qkv, 3 * C, M, 3 * C, C, EPI_NONE, 0, GEMM_AUTO, L.wqkv_p, true); if (rc) return rc;
         {
             AttnArgs a; memset(&a, 0, sizeof(a));
             a.q = c->v_qkv; a.ldq = 3 * C; a.K = (char*)c->v_qkv + (size_t)C * es(c); a.V = (char*)c->v_qkv + (size_t)2 * C * es(c);
             a.k_hs = hd; a.k_ts = 3 * C; a.v_hs = hd; a.v_ts = 3 * C; a.out = c->v_attn; a.ldo = C;
             a.S = T; a.nh = g.vit_heads; a.nkv = g.vit_heads; a.d = hd; a.n_ctx = 0; a.causal = 0;
             a.batch = B; a.q_bstride = (int64_t)T * 3 * C; a.kv_bstride = (int64_t)T * 3 * C; a.o_bstride = (int64_t)T * C;
-            a.ws = c->attn_ws; a.ws_bytes = c->attn_bytes; a.variant = 0;
+            a.ws = c->v_attn_ws; a.ws_bytes = c->v_attn_bytes; a.variant = 0;
             ProfScope ps(c, MMD_K_ATTN_VIT, 4.0 * M * C * es(c), 4.0 * B * (double)T * T * C);
             HIPCHK(c, launch_attention(dt, a, st));
         }
-        rc = gemm(c, c->v_attn, C, L.wo, C, L.bo, c->v_h, C, c->v_h, C, M, C, C, EPI_RESID, 0, GEMM_AUTO, L.wo_p); if (rc) return rc;
+        rc = gemm(c, c->v_attn, C, L.wo, C, L.bo, c->v_h, C, c->v_h, C, M, C, C, EPI_RESID, 0, GEMM_AUTO, L.wo_p, true); if (rc) return rc;
         { ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * M * C * es(c), 0); HIPCHK(c, launch_layernorm(dt, c->v_h, L.ln2w, L.ln2b, c->v_xn, M, C, g.vit_ln_eps, st)); }
-        rc = gemm(c, c->v_xn, C, L.w1, C, L.b1, nullptr, 0, c->v_mlp, c->vit_ipad, M, c->vit_ipad, C, EPI_GELU_TANH, 0, GEMM_AUTO, L.w1_p); if (rc) return rc;
-        rc = gemm(c, c->v_mlp, c->vit_ipad, L.w2, c->vit_ipad, L.b2, c->v_h, C, c->v_h, C, M, C, c->vit_ipad, EPI_RESID, 0, GEMM_AUTO, L.w2_p); if (rc) return rc;
+        rc = gemm(c, c->v_xn, C, L.w1, C, L.b1, nullptr, 0, c->v_mlp, c->vit_ipad, M, c->vit_ipad, C, EPI_GELU_TANH, 0, GEMM_AUTO, L.w1_p, true); if (rc) return rc;
+        rc = gemm(c, c->v_mlp, c->vit_ipad, L.w2, c->vit_ipad, L.b2, c->v_h, C, c->v_h, C, M, C, c->vit_ipad, EPI_RESID, 0, GEMM_AUTO, L.w2_p, true); if (rc) return rc;
     }
     if (g.vit_post_layernorm) { HIPCHK(c, launch_layernorm(dt, c->v_h, c->post_w, c->post_b, c->v_h, M, C, g.vit_ln_eps, st)); }
-    rc = gemm(c, c->v_h, C, c->p0w, C, c->p0b, nullptr, 0, c->v_p1, H, M, H, C, EPI_GELU_ERF, 0, GEMM_AUTO, c->p0w_p); if (rc) return rc;
-    rc = gemm(c, c->v_p1, H, c->p2w, H, c->p2b, nullptr, 0, c->v_p2, H, M, H, H, EPI_NONE, 0, GEMM_AUTO, c->p2w_p); if (rc) return rc;
+    rc = gemm(c, c->v_h, C, c->p0w, C, c->p0b, nullptr, 0, c->v_p1, H, M, H, C, EPI_GELU_ERF, 0, GEMM_AUTO, c->p0w_p, true); if (rc) return rc;
+    rc = gemm(c, c->v_p1, H, c->p2w, H, c->p2b, nullptr, 0, c->v_p2, H, M, H, H, EPI_NONE, 0, GEMM_AUTO, c->p2w_p, true); if (rc) return rc;
     { ProfScope ps(c, MMD_K_OTHER, 0, 0); HIPCHK(c, launch_pool(dt, c->v_p2, out, B, c->vit_grid, H, g.pool_mode, g.pool_stride, st)); }
     c->last_vit_B = B;
     return MMD_OK;
@@ -661,6 +668,8 @@ extern "C" int mmd_kv_truncate(mmd_stream* s, int64_t n) {
     s->len = n;
     return MMD_OK;
 }
+
+extern "C" int mmd_stream_reset(mmd_stream* s) { if (!s) return MMD_EINVAL; s->len = 0; return MMD_OK; }
 
 static int kv_reserve(mmd_ctx* c, mmd_stream* s, int64_t need);
 // measurement aid (tools/kv_growth_sweep.py): declare the first n slots of the arena live without computing them, to time a
@@ -909,7 +918,7 @@ static int decode_step_enqueue(mmd_ctx* c, mmd_stream* s, bool pen, float rep_pe
     HIPCHK(c, launch_embed(g.dtype, c->embed, c->tok_dev, 1, H, g.vocab_size, c->gen_embed, st));
     int rc = llm_step_impl(c, s, c->gen_embed, 1, nullptr, dyn); if (rc) return rc;
     rc = gemm(c, c->l_hid, H, c->lm_head, H, nullptr, nullptr, 0, c->logits_ws, g.vocab_size, 1, g.vocab_size, H, EPI_NONE, 1, GEMM_AUTO, c->lm_head_p); if (rc) return rc;
-    HIPCHK(c, launch_argmax_penalty(c->logits_ws, g.vocab_size, c->prev_dev, pen ? np : 0, pen ? rep_penalty : 1.f, c->tok_dev, st, dyn, c->argmax_scratch));
+    HIPCHK(c, launch_argmax_penalty(c->logits_ws, g.vocab_size, c->prev_dev, pen ? (np < c->prev_cap ? np : c->prev_cap) : 0, pen ? rep_penalty : 1.f, c->tok_dev, st, dyn, c->argmax_scratch));
     if (dyn) HIPCHK(c, launch_advance_state(c->step_dev, c->tok_dev, c->prev_dev, c->prev_cap, eos_id, pen ? 1 : 0, st));
     return MMD_OK;
 }
@@ -936,7 +945,7 @@ extern "C" int mmd_greedy_generate(mmd_ctx* c, mmd_stream* s, const void* prompt
         const void* last = (const char*)c->l_hid + (size_t)(S - 1) * H * e;
         rc = gemm(c, last, H, c->lm_head, H, nullptr, nullptr, 0, c->logits_ws, g.vocab_size, 1, g.vocab_size, H, EPI_NONE, 1, GEMM_AUTO, c->lm_head_p); if (rc) return rc;
         ProfScope ps(c, MMD_K_OTHER, 0, 0);
-        HIPCHK(c, launch_argmax_penalty(c->logits_ws, g.vocab_size, c->prev_dev, pen ? np : 0, pen ? rep_penalty : 1.f, c->tok_dev, st, nullptr, c->argmax_scratch));
+        HIPCHK(c, launch_argmax_penalty(c->logits_ws, g.vocab_size, c->prev_dev, pen ? (np < c->prev_cap ? np : c->prev_cap) : 0, pen ? rep_penalty : 1.f, c->tok_dev, st, nullptr, c->argmax_scratch));
     }
     int64_t tok = 0;
     rc = read_token(&tok); if (rc) return rc;
@@ -1020,13 +1029,19 @@ extern "C" int mmd_op_gemm(mmd_ctx* c, const void* X, const void* W, const void*
     if (!c->splitk_ws) { c->splitk_bytes = (size_t)64 << 20; int rc = dev_alloc(c, (void**)&c->splitk_ws, c->splitk_bytes); if (rc) return rc; }
     int NO = epi == EPI_SWIGLU ? N / 2 : N;
     void* Wp = nullptr;
-    if (variant == GEMM_SKINNY || variant == GEMM_BIG || variant == GEMM_RING256 || variant == GEMM_RING256_SPLIT) { int rc = make_packed(c, W, N, K, &Wp); if (rc) return rc; }
+    // the model holds every matrix in both layouts (or packed only): give the dispatcher the same choice, variant 0 included
+    if (variant == GEMM_AUTO || variant == GEMM_SKINNY || variant == GEMM_BIG || variant == GEMM_RING256 || variant == GEMM_RING256_SPLIT) { int rc = make_packed(c, W, N, K, &Wp); if (rc) return rc; }
     int rc = gemm(c, X, K, W, K, bias, R, NO, Y, NO, M, N, K, epi, out_f32, variant, Wp);
     if (Wp) { hipStreamSynchronize(c->stream); dev_free(c, Wp); }
     return rc;
 }
+extern "C" int mmd_op_gemm_last_plan(mmd_ctx* c, int* out4) {
+    if (!c || !out4) return MMD_EINVAL;
+    for (int i = 0; i < 4; ++i) out4[i] = c->last_plan[i];
+    return MMD_OK;
+}
 // times one GEMM shape on the context's stream with HIP events (weights packed once, outside the timed region)
-extern "C" int mmd_op_gemm_bench(mmd_ctx* c, int M, int N, int K, int epi, int variant, int iters, float* avg_ms_out) {
+extern "C" int mmd_op_gemm_bench(mmd_ctx* c, int M, int N, int K, int epi, int variant, int iters, float* avg_ms_out, const void* Xin, const void* Win) {
     if (!c || !avg_ms_out || iters <= 0) return MMD_EINVAL;
     hipSetDevice(c->device);
     if (!c->splitk_ws) { c->splitk_bytes = (size_t)64 << 20; int rc = dev_alloc(c, (void**)&c->splitk_ws, c->splitk_bytes); if (rc) return rc; }
@@ -1036,9 +1051,11 @@ extern "C" int mmd_op_gemm_bench(mmd_ctx* c, int M, int N, int K, int epi, int v
     int rc;
     if ((rc = dev_alloc(c, &X, (size_t)M * K * e)) || (rc = dev_alloc(c, &W, (size_t)N * K * e)) || (rc = dev_alloc(c, &Y, (size_t)M * NO * e)) ||
         (rc = dev_alloc(c, &R, (size_t)M * NO * e))) return rc;
-    // non-trivial operand bits (zero operands inflate clocks, MI355X guide rule 25): fill with a byte pattern
-    HIPCHK(c, hipMemsetAsync(X, 0x3c, (size_t)M * K * e, c->stream));
-    HIPCHK(c, hipMemsetAsync(W, 0x3b, (size_t)N * K * e, c->stream));
+    // operand values set the clock (zero / constant operands run 15-20 % faster than random ones, MI355X guide rule 25): the caller
+    // passes random X [M,K] / W [N,K]; the byte-pattern fill is only the fallback
+    if (Xin) HIPCHK(c, hipMemcpyAsync(X, Xin, (size_t)M * K * e, hipMemcpyDeviceToDevice, c->stream)); else HIPCHK(c, hipMemsetAsync(X, 0x3c, (size_t)M * K * e, c->stream));
+    if (Win) HIPCHK(c, hipMemcpyAsync(W, Win, (size_t)N * K * e, hipMemcpyDeviceToDevice, c->stream)); else HIPCHK(c, hipMemsetAsync(W, 0x3b, (size_t)N * K * e, c->stream));
+    if (Xin) HIPCHK(c, hipMemcpyAsync(R, Xin, std::min((size_t)M * K, (size_t)M * NO) * e, hipMemcpyDeviceToDevice, c->stream));
     if (variant != GEMM_GENERIC && variant != GEMM_LARGE) { rc = make_packed(c, W, N, K, &Wp); if (rc) return rc; }
     if (variant == 5 && !Wp) FAIL(c, MMD_EINVAL, "slab mode needs a packable shape");
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);

@@ -5,7 +5,13 @@ test/inference.py:337) for N manually launched processes.  Here one process per 
 'nccl' = RCCL over xGMI) takes streams `i % world == rank`; the only collective on the path is ONE all-gather of the
 per-frame head scores ([T,2] fp32 per stream, KB-scale, latency-bound -- no ring tuning applies).  Each video stream is
 an independent recurrence over its own KV arena, so there is no other exchange step.
+
+Two equivalent transports:
+  * `gather_scores`       torch.distributed (`all_gather_into_tensor`), any backend (gloo on CPU for the tests);
+  * `NativeScoreGather`   the C-ABI entry `mmd_gather_scores` (include/mmduet.h): one ncclAllGather issued by libmmduet_hip
+                          itself on the model's stream, the communicator's id handed around through the launcher's store.
 """
+import ctypes as C
 import os
 import torch
 import torch.distributed as dist
@@ -43,33 +49,98 @@ def shard_indices(n_items, rank, world, lengths=None):
     return sorted(mine)
 
 
-def gather_scores(local_scores, t_max=None):
-    """All-gather per-stream score arrays.
+def shard_shape(n_items, world, lengths=None):
+    """(n_max, t_max) of the padded score block, computed WITHOUT communication: the assignment is deterministic, so every rank
+    knows how many streams the busiest rank holds and (with `lengths`) the longest stream."""
+    n_max = max((len(shard_indices(n_items, r, world, lengths)) for r in range(world)), default=0)
+    t_max = max(lengths, default=0) if lengths is not None else None
+    return n_max, t_max
+
+
+def gather_scores(local_scores, t_max=None, n_max=None):
+    """All-gather per-stream score arrays in ONE collective.
 
     local_scores: list of float tensors [T_i, 2] (informative, relevance) for the streams of this rank (any device).
     Returns (scores [world, n_max, t_max, 2] fp32 padded with NaN, lengths [world, n_max] int32) on every rank; with
-    world == 1 no collective is issued."""
+    world == 1 no collective is issued.
+
+    The block every rank contributes is [n_max, t_max + 1, 2]: row 0 of a stream carries (T_i, 0) -- the length travels inside
+    the score block, so lengths need no collective of their own.  `n_max` / `t_max` are known to every rank without
+    communication when the dataset is (`shard_shape`); only if they are not given does a second, 16-byte all-gather of the
+    local shape precede the score gather."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     dev = torch.device('cuda', torch.cuda.current_device()) if (dist.is_initialized() and dist.get_backend() == 'nccl') else torch.device('cpu')
     n_local = len(local_scores)
     t_local = max([int(s.shape[0]) for s in local_scores], default=0)
-    meta = torch.tensor([n_local, t_local if t_max is None else t_max], dtype=torch.int64, device=dev)
-    if world > 1:
-        metas = [torch.zeros_like(meta) for _ in range(world)]
-        dist.all_gather(metas, meta)
-        n_max = max(int(m[0]) for m in metas)
-        t_max = max(int(m[1]) for m in metas)
-    else:
-        n_max, t_max = n_local, int(meta[1])
-    buf = torch.full((n_max, t_max, 2), float('nan'), dtype=torch.float32, device=dev)
-    lens = torch.zeros(n_max, dtype=torch.int32, device=dev)
+    if world > 1 and (t_max is None or n_max is None):
+        meta = torch.tensor([n_local, t_local], dtype=torch.int64, device=dev)
+        metas = torch.empty(world * 2, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(metas, meta)
+        metas = metas.view(world, 2).cpu()
+        n_max = int(metas[:, 0].max()) if n_max is None else n_max
+        t_max = int(metas[:, 1].max()) if t_max is None else t_max
+    n_max = n_local if n_max is None else int(n_max)
+    t_max = t_local if t_max is None else int(t_max)
+    if n_local > n_max or t_local > t_max:
+        raise ValueError(f'local block [{n_local},{t_local}] exceeds the agreed [{n_max},{t_max}]')
+    buf = torch.full((n_max, t_max + 1, 2), float('nan'), dtype=torch.float32)
+    buf[:, 0] = 0.0
     for i, s in enumerate(local_scores):
-        buf[i, :s.shape[0]] = s.to(device=dev, dtype=torch.float32)
-        lens[i] = s.shape[0]
+        buf[i, 0, 0] = float(s.shape[0])
+        buf[i, 1:1 + s.shape[0]] = s.detach().to(device='cpu', dtype=torch.float32)
+    buf = buf.to(dev)
     if world == 1:
-        return buf[None], lens[None]
-    out = torch.empty((world * n_max, t_max, 2), dtype=torch.float32, device=dev)
-    out_l = torch.empty((world * n_max,), dtype=torch.int32, device=dev)
-    dist.all_gather_into_tensor(out, buf)          # one RCCL all-gather of the padded score block (concatenated along dim 0)
-    dist.all_gather_into_tensor(out_l, lens)
-    return out.view(world, n_max, t_max, 2), out_l.view(world, n_max)
+        out = buf[None]
+    else:
+        out = torch.empty((world, n_max, t_max + 1, 2), dtype=torch.float32, device=dev)
+        dist.all_gather_into_tensor(out.view(world * n_max, t_max + 1, 2), buf)          # the ONE collective
+    return out[:, :, 1:], out[:, :, 0, 0].to(torch.int32)
+
+
+class NativeScoreGather:
+    """`mmd_gather_scores` (include/mmduet.h): the all-gather issued by libmmduet_hip itself (RCCL bound at run time) on the
+    model's stream.  The 128-byte communicator id is drawn on rank 0 and handed to the other ranks through a torch.distributed
+    broadcast (construction only); the data path never touches torch.distributed."""
+
+    def __init__(self, device, rank=None, world=None, stream=None):
+        from ._lib import lib, MmduetError
+        self._lib, self._err = lib(), MmduetError
+        self.rank = dist.get_rank() if rank is None and dist.is_initialized() else (rank or 0)
+        self.world = dist.get_world_size() if world is None and dist.is_initialized() else (world or 1)
+        self.device = torch.device(device)
+        ident = torch.zeros(128, dtype=torch.uint8)
+        if self.rank == 0:
+            rc = self._lib.mmd_comm_unique_id(C.c_void_p(ident.data_ptr()))
+            if rc:
+                raise MmduetError(f'mmd_comm_unique_id failed ({rc}): {self._lib.mmd_comm_last_error(None).decode()}')
+        if self.world > 1:
+            on = ident.to(self.device) if dist.get_backend() == 'nccl' else ident
+            dist.broadcast(on, src=0)
+            ident = on.cpu()
+        self._id = ident
+        h = C.c_void_p()
+        st = stream if stream is not None else torch.cuda.current_stream(self.device).cuda_stream
+        rc = self._lib.mmd_comm_create(C.c_void_p(ident.data_ptr()), self.rank, self.world, self.device.index or 0, C.c_void_p(st), C.byref(h))
+        if rc:
+            raise MmduetError(f'mmd_comm_create failed ({rc}): {self._lib.mmd_comm_last_error(None).decode()}')
+        self._h = h
+
+    def gather(self, scores, t_max):
+        """scores [T,2] fp32 on the device -> (all [world, t_max, 2] fp32 NaN-padded, lengths [world] int32), device tensors."""
+        s = scores.to(device=self.device, dtype=torch.float32).contiguous()
+        out = torch.empty(self.world, t_max + 1, 2, dtype=torch.float32, device=self.device)
+        rc = self._lib.mmd_gather_scores(self._h, C.c_void_p(s.data_ptr()), int(s.shape[0]), int(t_max), C.c_void_p(out.data_ptr()))
+        if rc:
+            raise self._err(f'mmd_gather_scores failed ({rc}): {self._lib.mmd_comm_last_error(self._h).decode()}')
+        return out[:, 1:], out[:, 0, 0].to(torch.int32)
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._lib.mmd_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -301,9 +301,14 @@ class LiveInferForBenchmark:
         if cap:                                  # leave room for the text prefix of the step (system prompt / stream header)
             k = max(1, min(k, (cap - 128) // self.frame_num_tokens))
         if self.query_queue:
+            # replay the clock exactly as the loop advances it (video_time += 1/fps per frame, test/inference.py:311): j/fps and
+            # j additions of 1/fps differ in the last ulp for any fps that is not a power of two, which would move the query
+            # by one frame against the one-frame-per-forward schedule
             q_time = self.query_queue[0][0]
+            t = self.video_time
             for j in range(1, k):
-                if self.video_time + j / self.frame_fps >= q_time:
+                t += 1 / self.frame_fps
+                if t >= q_time:
                     return j
         return k
 

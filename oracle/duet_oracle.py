@@ -340,7 +340,7 @@ def rope_tables(cfg: OracleConfig, positions, dtype):
     in fp32; emb = cat(freqs, freqs); cos/sin cast to the activation dtype."""
     d = cfg.head_dim
     inv = 1.0 / (cfg.rope_theta ** (torch.arange(0, d, 2, dtype=torch.float32) / d))
-    fr = positions.float()[:, None] * inv[None, :]
+    fr = positions.float()[:, None] * inv.to(positions.device)[None, :]
     emb = torch.cat([fr, fr], -1)
     return emb.cos().to(dtype), emb.sin().to(dtype)
 
@@ -374,8 +374,8 @@ def llm_layer(w, cfg: OracleConfig, i, h, cos, sin, past_k, past_v):
     kk = k[:, None].expand(nkv, rep, n_tot, d).reshape(nh, n_tot, d)
     vv = v[:, None].expand(nkv, rep, n_tot, d).reshape(nh, n_tot, d)
     s = torch.matmul(q, kk.transpose(1, 2)) * (d ** -0.5)
-    qpos = torch.arange(S)[:, None] + n
-    mask = torch.arange(n_tot)[None, :] > qpos
+    qpos = torch.arange(S, device=h.device)[:, None] + n
+    mask = torch.arange(n_tot, device=h.device)[None, :] > qpos
     s = s.masked_fill(mask[None], float('-inf'))
     a = torch.softmax(s, dim=-1, dtype=torch.float32).to(q.dtype)
     o = torch.matmul(a, vv).transpose(0, 1).reshape(S, nh * d)
@@ -394,7 +394,7 @@ def llm_forward(w, cfg: OracleConfig, inputs_embeds, past: Optional[KVHandle]):
     h = inputs_embeds
     S = h.shape[0]
     n = len(past) if past else 0
-    cos, sin = rope_tables(cfg, torch.arange(n, n + S), h.dtype)
+    cos, sin = rope_tables(cfg, torch.arange(n, n + S, device=h.device), h.dtype)
     ks, vs = [], []
     for i in range(cfg.num_hidden_layers):
         pk = past.k[i] if n else None
@@ -497,7 +497,7 @@ class OracleModel:
 
 def repetition_penalty_(scores, prev_ids, penalty):
     """RepetitionPenaltyLogitsProcessor.__call__ [3P]: score = score/p if score > 0 else score*p on seen ids."""
-    ids = torch.as_tensor(prev_ids, dtype=torch.long)
+    ids = torch.as_tensor(prev_ids, dtype=torch.long, device=scores.device)
     s = scores.clone()
     g = s[ids]
     s[ids] = torch.where(g < 0, g * penalty, g / penalty)
@@ -523,5 +523,5 @@ def fast_greedy_generate(*, model, inputs_embeds, past_key_values, eos_token_id,
         inplace_output_ids[:, i] = tok
         if tok == eos_token_id:
             break
-        inputs_embeds = model.get_input_embeddings()(torch.tensor([[tok]]))
+        inputs_embeds = model.get_input_embeddings()(torch.tensor([[tok]], device=inputs_embeds.device))
     return inplace_output_ids[:, :i + 1], past_key_values, generated_token_ids

@@ -5,17 +5,24 @@ from conftest import ROOT
 WORKER = r'''
 import os, sys, json, torch
 sys.path.insert(0, os.environ["MMD_ROOT"])
-from mmduet_amd.distributed import init_distributed, shard_indices, gather_scores
+from mmduet_amd.distributed import init_distributed, shard_indices, shard_shape, gather_scores
+import torch.distributed as dist
 rank, world, local = init_distributed(backend="gloo")
+calls = []
+_ag = dist.all_gather_into_tensor
+dist.all_gather_into_tensor = lambda out, inp, *a, **k: (calls.append(tuple(inp.shape)), _ag(out, inp, *a, **k))[1]
 lengths = [5, 9, 3, 7, 4]
 mine = shard_indices(len(lengths), rank, world)
 local_scores = [torch.full((lengths[i], 2), float(i)) + torch.arange(lengths[i])[:, None] * 0.01 for i in mine]
-scores, lens = gather_scores(local_scores)
+n_max, t_max = shard_shape(len(lengths), world, lengths)
+scores, lens = gather_scores(local_scores, t_max=t_max, n_max=n_max)      # shape known from the dataset: ONE collective
+assert calls == [(n_max, t_max + 1, 2)], calls
+s2, l2 = gather_scores(local_scores)                                      # shape unknown: + one 16-byte shape exchange
+assert len(calls) == 3 and torch.equal(l2, lens) and torch.equal(torch.nan_to_num(s2), torch.nan_to_num(scores))
 out = {"rank": rank, "mine": mine, "shape": list(scores.shape), "lens": lens.tolist(),
        "first": [[float(scores[r, j, 0, 0]) for j in range(scores.shape[1])] for r in range(world)],
        "balanced": [shard_indices(len(lengths), r, world, lengths) for r in range(world)]}
 print("RESULT " + json.dumps(out), flush=True)
-import torch.distributed as dist
 dist.barrier(); dist.destroy_process_group()
 '''
 
@@ -53,3 +60,4 @@ def test_single_process_gather_is_local():
     s, l = gather_scores([torch.ones(4, 2), torch.zeros(2, 2)])
     assert s.shape == (1, 2, 4, 2) and l.tolist() == [[4, 2]]
     assert shard_indices(5, 0, 1) == [0, 1, 2, 3, 4]
+    assert torch.isnan(s[0, 1, 2:]).all() and s[0, 0].eq(1).all() and s[0, 1, :2].eq(0).all()

@@ -157,3 +157,31 @@ def test_multistream_scheduler_propagates_errors():
     ms = MultiStreamInfer(a, model=model, tokenizer=tokenizer_for(base.config), n_slots=2)
     with pytest.raises(RuntimeError, match='device fault'):
         ms.run([dict(frames=stream_frames('grounding_q0'), conversation=case['conversation'])] * 2)
+
+
+@pytest.mark.parametrize('fps,k,q_times', [(3.0, 4, (10.0, 17.0)), (10.0, 5, (1.3, 2.0)), (3.0, 7, (0.0, 3.0 + 1e-9)), (7.0, 3, (1.0, 2.0, 3.0))])
+def test_mid_stream_query_lands_on_the_same_frame_for_every_chunk_size(fps, k, q_times):
+    """A user query due at time t is encoded before the first frame whose ACCUMULATED clock (video_time += 1/fps,
+    test/inference.py:281,311) reaches t.  j/fps and j additions of 1/fps differ in the last ulp for fps 3, 7, 10: the chunked
+    schedule must replay the accumulation, or the query slips by one frame against the one-frame-per-forward schedule."""
+    from helpers import stream_frames
+    model, _, _ = oracle_model('A')
+    tok = tokenizer_for(model.config)
+    frames = torch.cat([stream_frames('grounding_q0')] * 6)[:56]           # 56 frames
+    conv = [{'role': 'user', 'content': f'what happens at {t}?', 'time': t} for t in q_times]
+
+    def run(kk):
+        d = LiveInferForBenchmark(make_args(frame_fps=fps, system_prompt=META['system_prompt'], stream_end_prob_threshold=2.0, frames_per_forward=kk),
+                                  model=model, tokenizer=tok)
+        query_frames = []
+        enc = d._encode_query
+        d._encode_query = lambda: (query_frames.append(d.frame_idx), enc())[1]
+        d.input_video_stream(frames)
+        d.input_query_stream(conv)
+        d.inference()
+        return query_frames, [x['informative_score'] for x in d.debug_data_list], len(d.past_key_values)
+
+    q1, s1, n1 = run(1)
+    qk, sk, nk = run(k)
+    assert qk == q1 and nk == n1
+    assert sk == pytest.approx(s1, abs=2e-5)

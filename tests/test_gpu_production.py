@@ -1,0 +1,350 @@
+"""Parity in the regimes the benchmark actually runs (VERDICT r01 "next round" item 1).
+
+Every case goes through the C ABI and is compared with plain fp32 torch math / the oracle (oracle/duet_oracle.py is device-agnostic
+torch code; here it runs on the GPU through torch's own fp32 kernels -- an independent implementation -- on the SAME bf16-rounded
+weights and inputs).  Covered: the persistent 256-row ring GEMM with > 256 tiles (35-frame tower batch, M = 25 515), the 1274-row LLM
+chunk incl. the automatic split-K over grid.z, chunk attention at S = 1274 over 0 / 15 k / 30 k keys (cost-model split-KV), the 35-frame
+tower batch end to end, a 26-frame chunk against 26 per-frame steps, fp32 mode at the true widths, and one FULL-DEPTH (26 + 28 layers)
+stream prefix with measured head-logit deltas.  Measured deltas are written to gpurun_out/parity_r02.json (copied to profiles/).
+
+Tolerances (stated per test): bf16 kernels vs fp32 math on the same bf16 inputs -- output rounding (2^-9 relative) plus accumulation
+order; fp32 mode -- 1e-3 on head logits (the north-star figure)."""
+import json, math, os
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+from oracle import duet_oracle as O
+from conftest import ROOT
+
+RESULTS = {}
+
+
+def _record(key, **vals):
+    RESULTS[key] = {k: (float(v) if isinstance(v, (int, float)) else v) for k, v in vals.items()}
+    try:
+        d = os.path.join(ROOT, 'gpurun_out')
+        os.makedirs(d, exist_ok=True)
+        path = os.path.join(d, 'parity_r02.json')
+        cur = json.load(open(path)) if os.path.exists(path) else {}
+        cur[key] = RESULTS[key]
+        json.dump(cur, open(path, 'w'), indent=1, sort_keys=True)
+    except Exception:
+        pass
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from rawops import RawOps
+    return RawOps(torch.bfloat16)
+
+
+def _plan(ops):
+    import ctypes as C
+    from mmduet_amd._lib import lib
+    p = (C.c_int * 4)()
+    lib().mmd_op_gemm_last_plan(ops.ctx, p)
+    return dict(kernel=p[0], tiles=p[1], splits=p[2], blocks=p[3])
+
+
+RING = (6, 7)       # GEMM_K_RING256 / the 4-wave 256x128 ring
+
+
+def _rel_err(got, ref):
+    return (got.float() - ref.float()).abs().max().item() / max(1.0, ref.float().abs().max().item())
+
+
+# ---- (a) production GEMM shapes through the dispatcher ---------------------------------------------------------------------------
+PROD_GEMMS = [  # name, M, N, K, epilogue, bias, expects
+    ('vit_qkv', 25515, 3456, 1152, 'none', True, dict(min_tiles=257)),
+    ('vit_fc1', 25515, 4352, 1152, 'gelu_tanh', True, dict(min_tiles=257)),
+    ('vit_fc2', 25515, 1152, 4352, 'resid', True, dict(min_tiles=257)),
+    ('vit_o', 25515, 1152, 1152, 'resid', True, dict(min_tiles=257)),
+    ('proj0', 25515, 3584, 1152, 'gelu_erf', True, dict(min_tiles=257)),
+    ('llm_gate_up', 1274, 37888, 3584, 'swiglu', False, dict(min_tiles=257)),
+    ('llm_down', 1274, 3584, 18944, 'resid', False, dict(min_splits=2)),
+    ('llm_qkv', 1274, 4608, 3584, 'none', True, dict()),
+    ('llm_o', 1274, 3584, 3584, 'resid', False, dict()),
+    ('llm_gate_up_tail', 1303, 37888, 3584, 'swiglu', False, dict(min_tiles=257)),      # chunk + text prefix: M % 256 != 0 and M % 16 != 0
+]
+
+
+@pytest.mark.parametrize('name,M,N,K,epi,has_bias,expect', PROD_GEMMS, ids=[p[0] for p in PROD_GEMMS])
+def test_production_gemm_shapes_take_the_production_kernel_and_match_fp32(ops, name, M, N, K, epi, has_bias, expect):
+    """tolerance: 1.2e-2 x max(1, |ref|max) (bf16 output rounding 2^-9 rel. + accumulation order), as tests/test_gpu_ops.py"""
+    dev = ops.dev
+    g = torch.Generator(device=dev).manual_seed(M * 31 + N)
+    X = (torch.randn(M, K, generator=g, device=dev) * 0.7).to(torch.bfloat16)
+    W = (torch.randn(N, K, generator=g, device=dev) / math.sqrt(K)).to(torch.bfloat16)
+    b = (0.1 * torch.randn(N, generator=g, device=dev)).to(torch.bfloat16) if has_bias else None
+    NO = N // 2 if epi == 'swiglu' else N
+    R = torch.randn(M, NO, generator=g, device=dev).to(torch.bfloat16) if epi == 'resid' else None
+    Xf, Wf = X.float(), W.float()
+    if epi == 'swiglu':
+        gate, up = W[:N // 2], W[N // 2:]
+        Wi = torch.stack([gate.view(-1, 16, K), up.view(-1, 16, K)], 1).reshape(N, K).contiguous()      # the interleave mmd_finalize_weights builds
+        Y = ops.gemm(X, Wi, None, epi=epi, variant=0)
+        gg = (Xf @ gate.float().T).to(torch.bfloat16).float(); uu = (Xf @ up.float().T).to(torch.bfloat16).float()
+        ref = F.silu(gg).to(torch.bfloat16).float() * uu
+    else:
+        Y = ops.gemm(X, W, b, R=R, epi=epi, variant=0)
+        lin = F.linear(Xf, Wf, b.float() if b is not None else None)
+        if epi == 'resid':
+            ref = lin.to(torch.bfloat16).float() + R.float()
+        elif epi == 'gelu_tanh':
+            ref = O.gelu_tanh(lin.to(torch.bfloat16).float())
+        elif epi == 'gelu_erf':
+            ref = O.gelu_erf(lin.to(torch.bfloat16).float())
+        else:
+            ref = lin
+    plan = _plan(ops)
+    err = _rel_err(Y, ref)
+    _record(f'gemm_{name}', M=M, N=N, K=K, epi=epi, rel_err=err, **plan)
+    assert torch.isfinite(Y.float()).all()
+    assert err <= 1.2e-2 * (2.0 if epi != 'none' else 1.0), (name, err, plan)
+    if 'min_tiles' in expect:
+        assert plan['kernel'] in RING and plan['tiles'] >= expect['min_tiles'] and plan['blocks'] < plan['tiles'], plan      # persistent multi-tile loop ran
+    if 'min_splits' in expect:
+        assert plan['kernel'] in RING and plan['splits'] >= expect['min_splits'], plan                                        # automatic split-K over grid.z
+
+
+def test_ring_gemm_is_deterministic_and_tile_order_independent(ops):
+    """Same operands twice -> identical bits (no atomics, fixed reduction order); forced single-tile-per-block launch (variant 6 at a shape
+    with <= 256 tiles) vs the persistent loop on a sub-problem -> identical bits for the shared rows."""
+    dev = ops.dev
+    g = torch.Generator(device=dev).manual_seed(5)
+    X = torch.randn(25515, 1152, generator=g, device=dev).to(torch.bfloat16)
+    W = (torch.randn(3456, 1152, generator=g, device=dev) / 34).to(torch.bfloat16)
+    Y1 = ops.gemm(X, W, variant=0); p1 = _plan(ops)
+    Y2 = ops.gemm(X, W, variant=0)
+    assert torch.equal(Y1, Y2)
+    Ys = ops.gemm(X[:2048], W, variant=6); p2 = _plan(ops)          # 8 x 14 = 112 tiles: one tile per block, no persistence
+    assert p1['blocks'] < p1['tiles'] and p2['blocks'] == p2['tiles'] * p2['splits']
+    assert torch.equal(Ys, Y1[:2048])
+
+
+# ---- (b) chunk attention at the production sizes -----------------------------------------------------------------------------------
+def _ref_attention_gpu(q, K, V, nh, nkv, d, n_ctx):
+    """fp32 torch attention on the device, one kv group at a time.  q [S, nh*d]; K/V [nkv, cap, d]."""
+    S = q.shape[0]; n_tot = n_ctx + S; rep = nh // nkv
+    qh = q.float().view(S, nh, d).transpose(0, 1)
+    out = torch.empty(nh, S, d, device=q.device)
+    mask = torch.arange(n_tot, device=q.device)[None, :] > (torch.arange(S, device=q.device)[:, None] + n_ctx)
+    for h in range(nkv):
+        kk, vv = K[h, :n_tot].float(), V[h, :n_tot].float()
+        s = qh[h * rep:(h + 1) * rep] @ kk.T * d ** -0.5
+        s = s.masked_fill(mask[None], float('-inf'))
+        out[h * rep:(h + 1) * rep] = torch.softmax(s, -1) @ vv
+    return out.transpose(0, 1).reshape(S, nh * d)
+
+
+@pytest.mark.parametrize('S,n_ctx', [(1274, 0), (1274, 15000), (1274, 30000), (1323, 8000), (49, 30000), (131, 15000)])
+def test_chunk_attention_at_production_sizes(ops, S, n_ctx):
+    """attn_gqa128_kernel (variant 3: the arena layout with V transposed in 64-token blocks) incl. the cost-model split-KV + merge.
+    tolerance: 1.8e-2 x max(1, |ref|max): bf16 P and bf16 output rounding."""
+    nh, nkv, d = 28, 4, 128
+    dev = ops.dev
+    g = torch.Generator(device=dev).manual_seed(S + n_ctx)
+    cap = (n_ctx + S + 100 + 63) // 64 * 64
+    q = torch.randn(S, nh * d, generator=g, device=dev).to(torch.bfloat16)
+    K = torch.randn(nkv, cap, d, generator=g, device=dev).to(torch.bfloat16)
+    V = torch.randn(nkv, cap, d, generator=g, device=dev).to(torch.bfloat16)
+    K[:, n_ctx + S:] = 1e4; V[:, n_ctx + S:] = 1e4            # beyond the valid range: must never reach the result
+    o = ops.attention(q, K, V, nh, nkv, d, n_ctx, True, 3)
+    ref = _ref_attention_gpu(q, K, V, nh, nkv, d, n_ctx)
+    err = _rel_err(o, ref)
+    _record(f'attn_S{S}_n{n_ctx}', rel_err=err)
+    assert torch.isfinite(o.float()).all() and err <= 1.8e-2, err
+
+
+# ---- true-width models ---------------------------------------------------------------------------------------------------------------
+def _build(llm_layers, vit_layers, dtype, vocab=2048, max_vit_batch=35, max_step_tokens=1536, seed=3):
+    """(HIP model, oracle weights dict on the device in `dtype`-rounded fp32, oracle config)."""
+    from mmduet_amd.configuration_live import VideoHeadLiveLlavaQwenConfig
+    from mmduet_amd.modeling_live import VideoHeadLiveLlavaQwenForCausalLM
+    from mmduet_amd.weights import synthetic_weights
+    pcfg = VideoHeadLiveLlavaQwenConfig(vocab_size=vocab, num_hidden_layers=llm_layers, vit_num_hidden_layers=vit_layers + 1, vit_layers_removed=1,
+                                        frame_num_tokens=49, frame_resolution=384, v_placeholder='<image>')
+    ocfg = O.OracleConfig(vocab_size=vocab, num_hidden_layers=llm_layers, vit_layers=vit_layers)
+    m = VideoHeadLiveLlavaQwenForCausalLM(pcfg, torch_dtype=dtype, max_vit_batch=max_vit_batch, max_step_tokens=max_step_tokens, kv_initial_tokens=4096)
+    w = {}
+    for name, t in synthetic_weights(pcfg, seed=seed, device=m.device, dtype=dtype, scale='unit'):
+        m.load_tensor(name, t)
+        w[name] = t
+    m.finalize()
+    return m, w, ocfg
+
+
+def _oracle(w, ocfg, dtype):
+    return O.OracleModel(ocfg, {k: v.to(dtype) for k, v in w.items()})
+
+
+@pytest.fixture(scope='module')
+def width2():
+    """true widths, 2 tower layers + 2 decoder layers, bf16"""
+    m, w, ocfg = _build(2, 2, torch.bfloat16)
+    yield m, _oracle(w, ocfg, torch.float32), _oracle(w, ocfg, torch.bfloat16)
+    del m, w
+    torch.cuda.empty_cache()
+
+
+def maxerr(a, b):
+    return (a.float() - b.float().to(a.device)).abs().max().item()
+
+
+def test_tower_batch_of_35_frames_true_width(width2):
+    """(c) mmd_vit_encode on the production batch (M = 25 515 rows: persistent ring GEMMs, batch-35 ViT attention, projector, pooling) vs the
+    oracle in fp32 and in bf16.  tolerance: |ours - fp32 oracle| <= 3 x |bf16 oracle - fp32 oracle| + 2e-2 x scale."""
+    m, o32, o16 = width2
+    g = torch.Generator(device=m.device).manual_seed(0)
+    px = torch.randn(35, 3, 384, 384, generator=g, device=m.device).to(torch.bfloat16)
+    ve = m.visual_embed(px)
+    r32 = o32.visual_embed(px.float())
+    r16 = o16.visual_embed(px)
+    scale = r32.abs().max().item()
+    e_ours, e_ref = maxerr(ve, r32), maxerr(r16, r32)
+    _record('tower_35_frames_2_layers', ours_vs_fp32=e_ours, bf16_oracle_vs_fp32=e_ref, scale=scale)
+    assert ve.shape == (35 * 49, 3584)
+    assert e_ours <= 3 * e_ref + 2e-2 * max(1.0, scale), (e_ours, e_ref, scale)
+
+
+def test_chunk_of_26_frames_equals_26_frame_steps_true_width(width2):
+    """(d) k = 26 (M = 1274 + prefix: ring GEMMs, gqa128 chunk attention) vs 26 one-frame steps (weight-streaming kernels) vs the fp32 oracle.
+    tolerance on head logits: 6e-2 (bf16, 2 layers), and chunk == per-frame within the same bound."""
+    m, o32, o16 = width2
+    g = torch.Generator(device=m.device).manual_seed(2)
+    frames = [(torch.randn(49, 3584, generator=g, device=m.device) * 0.5).to(torch.bfloat16) for _ in range(26)]
+    prompt = (torch.randn(1, 29, 3584, generator=g, device=m.device) * 0.5).to(torch.bfloat16)
+    base = m(inputs_embeds=prompt).past_key_values
+    per, cache = [], base
+    for f in frames:
+        sc, cache = m.frame_step(f[None], cache, [48]); per.append(sc[0])
+    per = torch.stack(per)
+    rows = [49 * (j + 1) - 1 for j in range(26)]
+    chunk, cache2 = m.frame_step(torch.cat(frames)[None], m.cache_prefix(base, len(base)), rows)
+    assert len(cache2) == len(cache) == 29 + 26 * 49
+    oc = o32(inputs_embeds=prompt.float()).past_key_values
+    ref = o32(inputs_embeds=torch.cat(frames)[None].float(), past_key_values=oc)
+    want = torch.cat([ref.informative_logits[0, rows], ref.relevance_logits[0, rows]], -1).cpu()
+    ref16 = o16(inputs_embeds=torch.cat(frames)[None], past_key_values=o16(inputs_embeds=prompt).past_key_values)
+    want16 = torch.cat([ref16.informative_logits[0, rows], ref16.relevance_logits[0, rows]], -1).cpu()
+    _record('chunk26_2_layers', chunk_vs_fp32=maxerr(chunk, want), per_frame_vs_fp32=maxerr(per, want), chunk_vs_per_frame=maxerr(chunk, per),
+            bf16_oracle_vs_fp32=maxerr(want16, want))
+    assert maxerr(chunk, want) < 6e-2 and maxerr(per, want) < 6e-2 and maxerr(chunk, per) < 6e-2
+
+
+def test_fp32_mode_true_width_meets_1e3():
+    """(f) fp32 build at the true widths (2 + 2 layers): head logits within 1e-3 of the fp32 oracle (the north-star tolerance), frame chunk and decode rows."""
+    m, w, ocfg = _build(2, 2, torch.float32, max_vit_batch=2, max_step_tokens=512)
+    o32 = _oracle(w, ocfg, torch.float32)
+    g = torch.Generator(device=m.device).manual_seed(4)
+    px = torch.randn(2, 3, 384, 384, generator=g, device=m.device)
+    ve = m.visual_embed(px)
+    rv = o32.visual_embed(px)
+    e_ve = maxerr(ve, rv)
+    cache = ocache = None
+    worst = 0.0
+    steps = [torch.randn(1, 31, 3584, generator=g, device=m.device) * 0.5, ve[:49][None], ve[49:][None], torch.randn(1, 1, 3584, generator=g, device=m.device) * 0.5]
+    for x in steps:
+        out = m(inputs_embeds=x, past_key_values=cache); cache = out.past_key_values
+        ref = o32(inputs_embeds=x, past_key_values=ocache); ocache = ref.past_key_values
+        worst = max(worst, maxerr(out.informative_logits[0, -1], ref.informative_logits[0, -1]), maxerr(out.relevance_logits[0, -1], ref.relevance_logits[0, -1]))
+    _record('fp32_mode_true_width', visual_embed_err=e_ve, visual_embed_scale=rv.abs().max().item(), head_logit_err=worst)
+    assert worst <= 1e-3, worst
+    assert e_ve <= 1e-3 * max(1.0, rv.abs().max().item()), e_ve
+    del m, w
+    torch.cuda.empty_cache()
+
+
+def test_full_depth_stream_prefix_measured_deltas():
+    """(e) the FULL model (26 tower layers + projector + 28 decoder layers, vocab 152 064) in bf16 against the oracle on the same weights in fp32
+    and in bf16: system prompt, 3 frame steps (one frame, then a 2-frame chunk), a query, 8 greedy tokens.  Records max |delta head logit| of this
+    build and of the bf16 oracle, both against the fp32 oracle -- the measurement DESIGN.md section 2 quotes.
+    tolerance: ours <= 2 x (bf16 oracle's own distance to fp32) + 3e-2; token ids equal the bf16 or the fp32 oracle's, or the fp32 top-2 margin at the
+    first differing step is below 4 x the logit error (tie-fragile greedy on random weights, SURVEY.md section 7 hard part 5)."""
+    m, w, ocfg = _build(28, 26, torch.bfloat16, vocab=152064, max_vit_batch=4, max_step_tokens=512)
+    o32, o16 = _oracle(w, ocfg, torch.float32), _oracle(w, ocfg, torch.bfloat16)
+    dev = m.device
+    g = torch.Generator(device=dev).manual_seed(11)
+    px = torch.randn(3, 3, 384, 384, generator=g, device=dev).to(torch.bfloat16)
+    ve = m.visual_embed(px)
+    v32, v16 = o32.visual_embed(px.float()), o16.visual_embed(px)
+    res = dict(visual_embed=dict(ours_vs_fp32=maxerr(ve, v32), bf16_oracle_vs_fp32=maxerr(v16, v32), scale=v32.abs().max().item()))
+    ids = torch.randint(0, 152064, (1, 40), generator=g, device=dev)
+    emb = m.get_input_embeddings()
+    steps = [('prompt+frame0', 'cat0'), ('frames1-2', 'cat12'), ('query', 'ids'), ]
+    qids = torch.randint(0, 152064, (1, 24), generator=g, device=dev)
+
+    def run(model, frames, dt):
+        e = lambda i: model.get_input_embeddings()(i).to(dt)
+        out, cache, logs = None, None, []
+        for x in (torch.cat([e(ids), frames[:49][None].to(dt)], 1), frames[49:][None].to(dt), e(qids)):
+            out = model(inputs_embeds=x, past_key_values=cache); cache = out.past_key_values
+            rows = [x.shape[1] - 1] if x.shape[1] != 98 else [48, 97]
+            logs.append(torch.cat([out.informative_logits[0, rows], out.relevance_logits[0, rows]], -1).float().cpu())
+        return out, cache, logs
+
+    out_h, cache_h, logs_h = run(m, ve, torch.bfloat16)
+    out_32, cache_32, logs_32 = run(o32, ve.float(), torch.float32)            # the fp32 oracle is fed THIS build's frame embeddings: isolates the LLM side
+    out_16, cache_16, logs_16 = run(o16, ve, torch.bfloat16)
+    d_ours = max(maxerr(a, b) for a, b in zip(logs_h, logs_32))
+    d_ref = max(maxerr(a, b) for a, b in zip(logs_16, logs_32))
+    res['head_logits'] = dict(ours_vs_fp32=d_ours, bf16_oracle_vs_fp32=d_ref, ours_vs_bf16_oracle=max(maxerr(a, b) for a, b in zip(logs_h, logs_16)),
+                              logit_scale=max(l.abs().max().item() for l in logs_32))
+    # end to end incl. the tower: oracle fp32 on ITS OWN frame embeddings
+    _, _, logs_e2e = run(o32, v32, torch.float32)
+    res['head_logits_end_to_end'] = dict(ours_vs_fp32=max(maxerr(a, b) for a, b in zip(logs_h, logs_e2e)))
+    # 8 greedy tokens from the generation prompt
+    gen = torch.randint(0, 152064, (1, 5), generator=g, device=dev)
+    from mmduet_amd.modeling_live import fast_greedy_generate
+    buf = torch.zeros(1, 8, dtype=torch.long, device=dev)
+    ids_h, _, _ = fast_greedy_generate(model=m, inputs_embeds=emb(gen), past_key_values=cache_h, eos_token_id=-1, inplace_output_ids=buf)
+    ids_h = ids_h[0].tolist()
+    toks = {}
+    for name, om, cache, dt in (('fp32', o32, cache_32, torch.float32), ('bf16', o16, cache_16, torch.bfloat16)):
+        b2 = torch.zeros(1, 8, dtype=torch.long, device=dev)
+        t, _, _ = O.fast_greedy_generate(model=om, inputs_embeds=om.get_input_embeddings()(gen).to(dt), past_key_values=cache, eos_token_id=-1, inplace_output_ids=b2)
+        toks[name] = t[0].tolist()
+    res['tokens'] = dict(ours=ids_h, fp32_oracle=toks['fp32'], bf16_oracle=toks['bf16'])
+    # lm_head logits of the first generated position and the fp32 top-2 margin
+    lo = m(inputs_embeds=emb(gen), past_key_values=cache_h).logits[0, -1].float()
+    l32 = o32(inputs_embeds=o32.get_input_embeddings()(gen), past_key_values=cache_32).logits[0, -1].float()
+    top2 = l32.topk(2).values
+    res['lm_logits'] = dict(ours_vs_fp32=maxerr(lo, l32), fp32_top2_margin=(top2[0] - top2[1]).item(), scale=l32.abs().max().item())
+    _record('full_depth_bf16', **res)
+    assert d_ours <= 2 * d_ref + 3e-2, res['head_logits']
+    same = ids_h == toks['bf16'] or ids_h == toks['fp32']
+    if not same:
+        first = next(i for i in range(8) if ids_h[i] != toks['fp32'][i])
+        assert first > 0 or res['lm_logits']['fp32_top2_margin'] < 4 * res['lm_logits']['ours_vs_fp32'], res
+    del m, w, o32, o16
+    torch.cuda.empty_cache()
+
+
+# ---- multi-GPU: collectives --------------------------------------------------------------------------------------------------------
+def test_native_score_gather_world1():
+    """mmd_gather_scores (RCCL bound at run time by libmmduet_hip) on a one-rank communicator: the all-gather degenerates to a copy of the padded block."""
+    from mmduet_amd.distributed import NativeScoreGather
+    dev = torch.device('cuda', 0)
+    ng = NativeScoreGather(dev, rank=0, world=1)
+    s = torch.rand(37, 2, device=dev)
+    allsc, lens = ng.gather(s, 50)
+    torch.cuda.synchronize()
+    assert lens.tolist() == [37] and torch.equal(allsc[0, :37], s) and torch.isnan(allsc[0, 37:]).all()
+    a2, l2 = ng.gather(s[:0], 50)
+    torch.cuda.synchronize()
+    assert l2.tolist() == [0] and torch.isnan(a2).all()
+    ng.close()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs >= 2 GPUs (the pool boxes have one; the 8-GPU driver run covers it)')
+def test_bench_launches_its_own_ranks_nccl():
+    """`python bench.py --gpus 2` with no torchrun environment spawns two ranks over RCCL and prints n_gpus = rccl_ranks = 2."""
+    import subprocess, sys
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--tiny', '--frames', '12', '--steps', '1', '--warmup', '1', '--multi-stream', '0',
+                        '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['rccl_ranks'] == 2 and line['config']['native_gather_check'] == 'ok'

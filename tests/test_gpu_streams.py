@@ -85,3 +85,95 @@ def test_cli_over_predecoded_and_raw_decoded_entries(tmp_path, monkeypatch):
         assert a['model_response_list'] == b['model_response_list'] and len(a['debug_data']) == len(b['debug_data'])
         for x, y in zip(a['debug_data'], b['debug_data']):
             assert x['video_time'] == y['video_time'] and abs(x['relevance_score'][1] - y['relevance_score'][1]) <= 1.5e-3
+
+
+def test_demo_driver_on_gpu_with_concurrent_query_thread(model_f32):
+    """LiveInferForDemo on the HIP model: `input_one_frame` from the generator thread while `encode_given_query` arrives from a second
+    thread (the Gradio handler, demo/app.py:84-85).  The reference shares past_key_values unlocked; here both go through one lock, so
+    whatever the interleaving, the run equals SOME serial order: scores before the query equal the no-query stream, the context length
+    accounts for every call exactly once, and nothing raises."""
+    import threading, time
+    from mmduet_amd.liveinfer import LiveInferForDemo
+    from helpers import make_args, stream_frames
+    name = 'prob_keep_pen'
+    case, opts = META['cases'][name], META['cases'][name]['opts']
+    tok = tokenizer_for(model_f32.config)
+    model_f32.config.eos_token_id = META['eos_token_id']
+
+    def driver():
+        a = make_args(frame_fps=case['fps'], system_prompt=META['system_prompt'], max_new_tokens=12, stream_end_prob_threshold=opts['stream_end_prob_threshold'],
+                      score_heads=opts['score_heads'], repetition_penalty=opts['repetition_penalty'])
+        d = LiveInferForDemo(a, model=model_f32, tokenizer=tok)
+        d.input_video_stream(stream_frames(name))
+        return d
+
+    # serial reference: query first (the fixture's query is due at t = 0), then every frame
+    d0 = driver()
+    d0.encode_given_query(case['conversation'][0]['content'])
+    outs0 = []
+    while d0.frame_embeds_queue:
+        outs0.append(d0.input_one_frame())
+    assert [o['informative_score'] for o in outs0] == pytest.approx([x['informative_score'] for x in case['debug_data']], abs=2e-4)
+    assert len(d0.past_key_values) == case['final_kv_len']
+
+    # two threads: frames step while a second user query lands somewhere in the middle
+    d1 = driver()
+    d1.encode_given_query(case['conversation'][0]['content'])
+    errors, landed = [], []
+
+    def handler():
+        try:
+            time.sleep(0.01)
+            n_before = d1.frame_idx
+            d1.encode_given_query('and what happens next?')
+            landed.append(n_before)
+        except Exception as e:          # pragma: no cover
+            errors.append(e)
+
+    t = threading.Thread(target=handler)
+    outs1 = []
+    t.start()
+    while d1.frame_embeds_queue:
+        outs1.append(d1.input_one_frame())
+    t.join()
+    assert not errors and len(landed) == 1 and len(outs1) == case['T']
+    # frames stepped before the second query saw exactly the serial run's context
+    j = next((i for i, o in enumerate(outs1) if o['frame_idx'] > landed[0]), len(outs1))
+    pre = min(j, next((i for i, o in enumerate(outs0) if o['response'] is not None), len(outs0)) + 1)
+    assert [o['informative_score'] for o in outs1[:pre]] == pytest.approx([o['informative_score'] for o in outs0[:pre]], abs=1e-6)
+    assert all(0.0 <= o['informative_score'] <= 1.0 for o in outs1)
+
+
+def test_live_arena_growth_across_reallocations_matches_presized_arena():
+    """A LIVE KV arena that starts at 512 tokens and grows past 100 k tokens (>= 8 reallocations, each moving the K rows and the 64-token V^T
+    blocks of every layer) must hold exactly the context of an arena that was sized for the whole stream up front: identical head logits
+    (bit for bit -- same kernels, same data) at every probe and at the end."""
+    from helpers import hip_model
+    m_grow = hip_model('A', torch.bfloat16)[0]
+    m_grow.kv_initial_tokens = 512
+    m_big = hip_model('A', torch.bfloat16)[0]
+    m_big.kv_initial_tokens = 110_000
+    H = m_grow.config.hidden_size
+    g = torch.Generator(device='cuda').manual_seed(0)
+    from mmduet_amd._lib import lib
+    cg = cb = None
+    caps = set()
+    total = 0
+    for step in range(212):
+        S = 509 if step % 2 == 0 else 448                   # not multiples of 64: appends straddle the V^T block boundary
+        x = (torch.randn(1, S, H, generator=g, device='cuda') * 0.5).to(torch.bfloat16)
+        og = m_grow(inputs_embeds=x, past_key_values=cg); cg = og.past_key_values
+        ob = m_big(inputs_embeds=x, past_key_values=cb); cb = ob.past_key_values
+        total += S
+        caps.add(int(lib().mmd_kv_capacity(cg.arena.h)))
+        if step % 20 == 0 or step == 211:
+            assert torch.equal(og.informative_logits[0, -1], ob.informative_logits[0, -1]), (step, total)
+            assert torch.equal(og.hidden_states[0, -1], ob.hidden_states[0, -1])
+    assert total > 100_000 and len(cg) == len(cb) == total
+    assert len(caps) >= 3 and max(caps) >= total and int(lib().mmd_kv_capacity(cb.arena.h)) >= 110_000       # the live arena really was reallocated >= 2 times
+    # rollback into the grown arena and replay: same result as the first time
+    mid = m_grow.cache_prefix(cg, total - 448)
+    x = (torch.randn(1, 448, H, generator=torch.Generator(device='cuda').manual_seed(99), device='cuda') * 0.5).to(torch.bfloat16)
+    a = m_grow(inputs_embeds=x, past_key_values=mid).informative_logits[0, -1].clone()
+    b = m_big(inputs_embeds=x, past_key_values=m_big.cache_prefix(cb, total - 448)).informative_logits[0, -1]
+    assert torch.equal(a, b)

@@ -1,22 +1,70 @@
 #!/usr/bin/env python
-"""Micro-benchmark the GEMM shapes of the path through mmd_op_gemm_bench (run on the GPU box)."""
-import ctypes as C, sys, os
+"""Micro-benchmark the GEMM shapes of the path through mmd_op_gemm_bench (run on the GPU box), RANDOM operands
+(operand bits set the chip's clock: zero / constant fills read 15-20 % high, MI355X guide rule 25).
+
+    python tools/bench_gemm.py prod [out.json]     the production shapes (35-frame tower batch, 1274-row LLM chunk), dispatcher's choice
+                                                   + every forced kernel: ms, TF/s, fraction of the 2.5 PF dense bf16 peak, kernel chosen
+    python tools/bench_gemm.py llm                 weight-streaming shapes (M <= 64): GB/s
+    python tools/bench_gemm.py big                 tile kernels over a range of M
+"""
+import ctypes as C, json, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
 import torch
 from mmduet_amd._lib import lib, check, EPI
 from rawops import RawOps
 
 LLM = [('qkv', 4608, 3584, 'none'), ('o', 3584, 3584, 'resid'), ('gate_up', 37888, 3584, 'swiglu'), ('down', 3584, 18944, 'resid'), ('lm_head', 152064, 3584, 'none')]
-VIT = [('vit_qkv', 3456, 1152, 'none'), ('vit_o', 1152, 1152, 'resid'), ('vit_fc1', 4352, 1152, 'gelu_tanh'), ('vit_fc2', 1152, 4352, 'resid'), ('proj0', 3584, 1152, 'gelu_erf'), ('proj2', 3584, 3584, 'none')]
+VIT = [('vit_patch', 1152, 640, 'none'), ('vit_qkv', 3456, 1152, 'none'), ('vit_o', 1152, 1152, 'resid'), ('vit_fc1', 4352, 1152, 'gelu_tanh'), ('vit_fc2', 1152, 4352, 'resid'),
+       ('proj0', 3584, 1152, 'gelu_erf'), ('proj2', 3584, 3584, 'none')]
+KERNELS = ('tile64', 'tile128', 'skinny', 'gemv16', 'big64', 'big128', 'ring256', 'ring128x2')
+_cache = {}
 
-def run(ops, M, N, K, epi, variant, iters=30):
+
+def operands(ops, M, N, K):
+    """Random bf16 operands at the magnitudes of the path (activations O(1), weights N(0, 0.02)), cached per shape."""
+    key = (M, K)
+    if key not in _cache:
+        _cache.clear()
+        _cache[key] = (torch.randn(M, K, device=ops.dev, dtype=torch.float32) * 0.5).to(torch.bfloat16)
+    X = _cache[key]
+    W = (torch.randn(N, K, device=ops.dev, dtype=torch.float32) * 0.02).to(torch.bfloat16)
+    return X, W
+
+
+def run(ops, M, N, K, epi, variant, iters=30, random=True):
     ms = C.c_float()
-    check(lib().mmd_op_gemm_bench(ops.ctx, M, N, K, EPI[epi], variant, iters, C.byref(ms)), ops.ctx)
+    X, W = operands(ops, M, N, K) if random else (None, None)
+    p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    check(lib().mmd_op_gemm_bench(ops.ctx, M, N, K, EPI[epi], variant, iters, C.byref(ms), p(X), p(W)), ops.ctx)
+    plan = (C.c_int * 4)()
+    lib().mmd_op_gemm_last_plan(ops.ctx, plan)
+    run.plan = dict(kernel=KERNELS[plan[0]] if 0 <= plan[0] < len(KERNELS) else str(plan[0]), tiles=plan[1], splits=plan[2], blocks=plan[3])
+    del W
     return ms.value
+
 
 if __name__ == '__main__':
     ops = RawOps(torch.bfloat16)
-    which = sys.argv[1] if len(sys.argv) > 1 else 'llm'
+    which = sys.argv[1] if len(sys.argv) > 1 else 'prod'
+    if which == 'prod':
+        rows = []
+        variants = [(0, 'auto'), (4, 'big'), (6, 'ring256'), (7, 'ring256-splitK'), (8, 'ring128x2'), (9, 'ring128x2-splitK')]
+        for M, shapes in ((25515, VIT), (1274, LLM[:4]), (1323, LLM[:4])):
+            for name, N, K, epi in shapes:
+                for variant, vn in variants:
+                    try:
+                        ms = run(ops, M, N, K, epi, variant, iters=10)
+                    except Exception as e:
+                        continue
+                    tf = 2 * M * N * K / ms / 1e9
+                    NO = N // 2 if epi == 'swiglu' else N
+                    alg = (M * K + N * K + M * NO + (M * NO if epi == 'resid' else 0)) * 2
+                    rows.append(dict(M=M, name=name, N=N, K=K, epi=epi, variant=vn, ms=round(ms, 4), tflops=round(tf, 1), frac_of_2500=round(tf / 2500, 3),
+                                     algorithmic_bytes=alg, **run.plan))
+                    print(f'M={M:6d} {name:9s} N={N:6d} K={K:6d} {vn:16s} {ms*1e3:9.1f} us  {tf:7.1f} TF  {tf/2500:5.3f}  {run.plan}', flush=True)
+        if len(sys.argv) > 2:
+            json.dump(dict(note='tools/bench_gemm.py prod: mmd_op_gemm_bench, random bf16 operands (X ~ 0.5 N(0,1), W ~ 0.02 N(0,1)), 10 iterations after 3 warm-ups, '
+                                'HIP events on the launch stream; frac = TF/s / 2500 (dense bf16 MFMA peak)', rows=rows), open(sys.argv[2], 'w'), indent=1)
     if which in ('llm', 'all'):
         for M in (1, 16, 49, 64):
             for name, N, K, epi in LLM:
