@@ -81,7 +81,8 @@ struct StepState { long long n_ctx; long long cap; void* K; void* V; int n_prev;
 
 // ---- epilogues of the GEMM family ------------------------------------------------------------------------------
 enum { EPI_NONE = 0, EPI_GELU_TANH = 1, EPI_GELU_ERF = 2, EPI_RESID = 3, EPI_SWIGLU = 4 };
-enum { GEMM_AUTO = 0, GEMM_GENERIC = 1, GEMM_SKINNY = 2, GEMM_LARGE = 3, GEMM_BIG = 4, GEMM_SLAB = 5, GEMM_RING256 = 6, GEMM_RING256_SPLIT = 7 };
+enum { GEMM_AUTO = 0, GEMM_GENERIC = 1, GEMM_SKINNY = 2, GEMM_LARGE = 3, GEMM_BIG = 4, GEMM_SLAB = 5, GEMM_RING256 = 6, GEMM_RING256_SPLIT = 7,
+       GEMM_RINGX = 16 /* + 1: 4-wave 256x128 blocks, + 2: 32x32x16 MFMA, + 4: split K */ };
 
 struct GemmArgs {
     const void* X; int64_t ldx;      // [M,K]
@@ -100,7 +101,7 @@ struct GemmArgs {
     int* plan_out = nullptr;                    // if set: int[4] = {kernel (GEMM_K_*), output tiles, K splits, blocks launched}
 };
 // which kernel the dispatcher chose (mmd_op_gemm_last_plan; parity tests assert the production kernel really ran)
-enum { GEMM_K_TILE64 = 0, GEMM_K_TILE128 = 1, GEMM_K_SKINNY = 2, GEMM_K_GEMV16 = 3, GEMM_K_BIG64 = 4, GEMM_K_BIG128 = 5, GEMM_K_RING256 = 6 };
+enum { GEMM_K_TILE64 = 0, GEMM_K_TILE128 = 1, GEMM_K_SKINNY = 2, GEMM_K_GEMV16 = 3, GEMM_K_BIG64 = 4, GEMM_K_BIG128 = 5, GEMM_K_RING256 = 6, GEMM_K_RING128X2 = 7 };
 bool gemm_can_slab(int dtype, const GemmArgs& a);
 
 // launchers (dtype = mmd_dtype).  All return hipError_t of the launch.

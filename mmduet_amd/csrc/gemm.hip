@@ -948,6 +948,379 @@ static hipError_t launch_ring256(const GemmP& p, const GemmArgs& a, hipStream_t 
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// gemm_ringx_kernel<EPI, WN, M32>: the ring GEMM generalised.
+//   WN  = waves along N (block tile 256 x 64*WN).  WN = 4 is the 8-wave 256 x 256 block of gemm_ring256_kernel (one per CU).
+//         WN = 2 is a 4-wave 256 x 128 block with a 72 KB ring: TWO blocks are resident per CU (one wave of each per SIMD) and run
+//         unsynchronised, so one block's tile seam -- drain, fp32 -> bf16 conversion, epilogue math, the store burst -- is covered by
+//         the other block's MFMAs (the 8-wave block leaves the matrix pipe idle there: 10-15 % of a K = 1152 tile), and the tile
+//         count doubles, which halves the tail quantisation over 256 CUs.
+//   M32 = v_mfma_f32_32x32x16_bf16 instead of 16x16x32: back-to-back issue at the full 32 cycles (16x16x32 measures ~17 for its
+//         nominal 16), half the MFMA instructions per slice.  Same LDS images: a 32-row operand = two neighbouring 16-row pieces,
+//         lane l reads row (l & 15) of piece (l >> 4) & 1, k chunk 2*kk + (l >> 5) -- conflict-free for both the fragment-major W
+//         pieces and the XOR-swizzled X pieces.
+// Wave tile 128 x 64 in every variant; BK = 32 slices through a 3-slot DMA ring; one counted s_waitcnt + raw s_barrier per slice.
+// Tile order: bijective XCD remap, then bands of up to 8 m-tiles swept m-fastest, so the blocks that run together on an XCD share a
+// few X panels and a few W panels (for N > M this is the W-panel-stationary order of the LLM chunk).
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x4_t quad_of(const f32x16_t& v, int q) { return f32x4_t{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]}; }
+// two neighbouring n-quads (4 bf16 each) held by the two half-waves -> 8 consecutive columns per lane (v_permlane32_swap):
+// lanes 0-31 end up with columns 0..7 of the 16-column group, lanes 32-63 with columns 8..15
+__device__ __forceinline__ s16x8_t halves_to_row8(const s16x4_t& q0, const s16x4_t& q1) {
+    const uint2 a = __builtin_bit_cast(uint2, q0), b = __builtin_bit_cast(uint2, q1);
+    const auto x = __builtin_amdgcn_permlane32_swap(a.x, b.x, false, false);
+    const auto y = __builtin_amdgcn_permlane32_swap(a.y, b.y, false, false);
+    const uint4 o = {x[0], y[0], x[1], y[1]};
+    return __builtin_bit_cast(s16x8_t, o);
+}
+
+template <int EPI, int WN, bool M32>
+__global__ __launch_bounds__(WN * 128, 2) void gemm_ringx_kernel(GemmP p, int KT) {
+    constexpr int BM = 256, BN = 64 * WN, BK = 32, NW = 2 * WN;
+    constexpr int XE = BM * BK, WE = BN * BK, SE = XE + WE;    // elements per ring slot (32 KB / 24 KB)
+    constexpr int XP = (BM / 16) / NW, WP = (BN / 16) / NW;    // X / W pieces (1 KB DMAs) per wave and slice: 2+2 (8 waves), 4+2 (4 waves)
+    constexpr int NDMA = XP + WP;
+    extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lq = lane >> 4, lh = lane >> 5;
+    const int wr = wave / WN, wc = wave % WN;
+    const int nbx = (p.N + BN - 1) / BN, nby = (p.M + BM - 1) / BM;
+    const int nblk = nbx * nby;
+    int m0 = 0, n0 = 0;
+    auto tile_origin = [&](int bid) {
+        const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        const int TB = nby < 8 ? nby : 8;                              // band height in m-tiles
+        const int band = bid / (TB * nbx), rem = bid - band * (TB * nbx);
+        const int tb = min(TB, nby - band * TB);                       // the last band may be shorter
+        const int nt = rem / tb, mt = band * TB + rem - nt * tb;
+        m0 = mt * BM; n0 = nt * BN;
+    };
+    const int ntiles = p.N >> 4;
+    const bf16_t* X = (const bf16_t*)p.X;
+    const bf16_t* Wp = (const bf16_t*)p.W;
+    const int nsteps_all = p.K / BK;
+    const int zsteps = (nsteps_all + gridDim.z - 1) / gridDim.z;
+    const int t0 = blockIdx.z * zsteps;
+    const int nsteps = min(nsteps_all, t0 + zsteps) - t0;
+
+    const int srow = lane >> 2, spos = lane & 3;
+    const int sswz = (0x1230 >> (((srow >> 2) & 3) * 4)) & 3;
+    int xo[XP], wo[WP];
+    auto tile_sources = [&]() {
+#pragma unroll
+        for (int j = 0; j < XP; ++j) {
+            const int pi = wave + NW * j;
+            int row = m0 + pi * 16 + srow; row = row < p.M ? row : p.M - 1;
+            xo[j] = row * (int)p.ldx + ((spos ^ sswz) * 8) + t0 * BK;
+        }
+#pragma unroll
+        for (int j = 0; j < WP; ++j) {
+            const int pi = wave + NW * j;
+            int ntile = n0 / 16 + pi; ntile = ntile < ntiles ? ntile : ntiles - 1;
+            wo[j] = (ntile * KT * 64 + lane) * 8 + t0 * 512;
+        }
+    };
+    auto dma_x = [&](int slot, int step, int j) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + (long long)xo[j] + step * BK),
+                                         (__attribute__((address_space(3))) void*)(lds + slot * SE + (wave + NW * j) * 512), 16, 0, 0);
+    };
+    auto dma_w = [&](int slot, int step, int j) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wp + (long long)wo[j] + (long long)step * 512),
+                                         (__attribute__((address_space(3))) void*)(lds + slot * SE + XE + (wave + NW * j) * 512), 16, 0, 0);
+    };
+    auto stage = [&](int slot, int step) {
+#pragma unroll
+        for (int j = 0; j < XP; ++j) dma_x(slot, step, j);
+#pragma unroll
+        for (int j = 0; j < WP; ++j) dma_w(slot, step, j);
+    };
+    // the k-th DMA of a slice, k in [0, NDMA): X pieces first
+    auto dma_k = [&](int slot, int step, int k) { if (k < XP) dma_x(slot, step, k); else dma_w(slot, step, k - XP); };
+
+    constexpr int VM_ONE = NDMA, VM_TWO = 2 * NDMA;       // vmcnt leaving one / two slices in flight
+#define RINGX_WAIT(n) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(n) : "memory")
+    const int G = gridDim.x;
+    const int rswz = (0x1230 >> (((lr >> 2) & 3) * 4)) & 3;
+
+    if constexpr (!M32) {
+        // ---------------- 16x16x32: 8 x 4 accumulator tiles, the schedule of gemm_ring256_kernel ----------------
+        f32x4_t acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0, 0, 0, 0};
+        const int aoff = (wr * 8) * 512 + lr * 32 + ((lq ^ rswz) * 8);
+        const int boff = XE + (wc * 4) * 512 + lane * 8;
+        bf16x8_t a[8], b0[4], b1[4];
+        auto step = [&](auto steady, int s, int slot, const bf16x8_t (&b)[4], bf16x8_t (&bn)[4]) {
+            constexpr bool STEADY = decltype(steady)::value;
+            if (STEADY || s + 2 < nsteps) RINGX_WAIT(VM_ONE); else RINGX_WAIT(0);
+            MMD_BAR();
+            const bool refill = STEADY || s + 3 < nsteps;
+            const bool more = STEADY || s + 1 < nsteps;
+            const bf16_t* nbase = lds + (slot == 2 ? 0 : slot + 1) * SE;
+            bf16x8_t a6n, a7n;
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) {
+                    if (i < 6) a[i] = *reinterpret_cast<const bf16x8_t*>(nbase + aoff + i * 512);
+                    if (i < 4) bn[i] = *reinterpret_cast<const bf16x8_t*>(nbase + boff + i * 512);
+                    if (i == 0) a6n = *reinterpret_cast<const bf16x8_t*>(nbase + aoff + 6 * 512);
+                    if (i == 1) a7n = *reinterpret_cast<const bf16x8_t*>(nbase + aoff + 7 * 512);
+                }
+                if (refill) {       // NDMA = 4: rows 4..7; NDMA = 6: rows 2..7
+                    if (i >= 8 - NDMA) dma_k(slot, s + 3, i - (8 - NDMA));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (more) { a[6] = a6n; a[7] = a7n; }
+            __builtin_amdgcn_s_setprio(0);
+        };
+        auto prologue = [&]() { stage(0, 0); if (nsteps > 1) stage(1, 1); if (nsteps > 2) stage(2, 2); };
+        int tile = blockIdx.x;
+        tile_origin(tile); tile_sources(); prologue();
+        for (; tile < nblk; tile += G) {
+            if (nsteps > 2) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(VM_TWO) : "memory");
+            else if (nsteps > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(VM_ONE) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            MMD_BAR();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(lds + aoff + i * 512);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b0[j] = *reinterpret_cast<const bf16x8_t*>(lds + boff + j * 512);
+            int slot = 0, s = 0;
+            for (; s + 4 < nsteps; s += 2) {
+                step(std::true_type{}, s, slot, b0, b1);
+                slot = slot == 2 ? 0 : slot + 1;
+                step(std::true_type{}, s + 1, slot, b1, b0);
+                slot = slot == 2 ? 0 : slot + 1;
+            }
+            for (; s < nsteps; s += 2) {
+                step(std::false_type{}, s, slot, b0, b1);
+                slot = slot == 2 ? 0 : slot + 1;
+                if (s + 1 < nsteps) {
+                    step(std::false_type{}, s + 1, slot, b1, b0);
+                    slot = slot == 2 ? 0 : slot + 1;
+                }
+            }
+            const int em0 = m0, en0 = n0;
+            if (tile + G < nblk) { tile_origin(tile + G); tile_sources(); prologue(); }
+            if (gridDim.z > 1) {
+                float* wsl = p.ws + (long long)blockIdx.z * p.M * p.N;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int m = em0 + wr * 128 + i * 16 + lr;
+                    if (m < p.M) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { const int nb = en0 + wc * 64 + j * 16; if (nb + 16 <= p.N) *reinterpret_cast<f32x4_t*>(wsl + (long long)m * p.N + nb + lq * 4) = acc[i][j]; }
+                    }
+                }
+                return;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int m = em0 + wr * 128 + i * 16 + lr;
+                const int mc = m < p.M ? m : p.M - 1;
+                if constexpr (EPI == EPI_SWIGLU) {
+                    const int nb = en0 + wc * 64;
+                    const int ob = (nb >> 5) * 16;
+                    const s16x8_t v = pair_to_row8(big_value_swiglu(acc[i][0], acc[i][1]), big_value_swiglu(acc[i][2], acc[i][3]));
+                    if (m < p.M && nb + 32 * (lq & 1) + 32 <= p.N) *reinterpret_cast<s16x8_t*>((bf16_t*)p.Y + (long long)m * p.ldy + ob + (lq & 1) * 16 + (lq >> 1) * 8) = v;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; j += 2) {
+                        const int nb = en0 + wc * 64 + j * 16;
+                        const int na = nb + 16 <= p.N ? nb : p.N - 16, nc = nb + 32 <= p.N ? nb + 16 : p.N - 16;
+                        const s16x8_t v = pair_to_row8(big_value<EPI>(p, mc, na + lq * 4, acc[i][j]), big_value<EPI>(p, mc, nc + lq * 4, acc[i][j + 1]));
+                        if (m < p.M && nb + 16 * (lq & 1) + 16 <= p.N) *reinterpret_cast<s16x8_t*>((bf16_t*)p.Y + (long long)m * p.ldy + nb + (lq & 1) * 16 + (lq >> 1) * 8) = v;
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0, 0, 0, 0};
+        }
+    } else {
+        // ---------------- 32x32x16: 4 (m) x 2 (n) accumulator tiles of 32 x 32 ----------------
+        f32x16_t acc[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        const int lt = (lane >> 4) & 1;                      // which 16-row piece of the 32-row operand this lane reads
+        // X operand of m-tile i, k-step kk:  piece (wr*8 + 2i + lt), row lr, chunk (2kk + lh) ^ swz(lr)
+        const int xoff0 = (wr * 8 + lt) * 512 + lr * 32 + (((0 + lh) ^ rswz) * 8);
+        const int xoff1 = (wr * 8 + lt) * 512 + lr * 32 + (((2 + lh) ^ rswz) * 8);
+        // W operand of n-tile j, k-step kk:  piece (wc*4 + 2j + lt), fragment slot (2kk + lh)*16 + lr
+        const int woff0 = XE + (wc * 4 + lt) * 512 + ((0 + lh) * 16 + lr) * 8;
+        const int woff1 = XE + (wc * 4 + lt) * 512 + ((2 + lh) * 16 + lr) * 8;
+        bf16x8_t xf[4][2], w0[2][2], w1[2][2];
+        auto ldx = [&](const bf16_t* base, int i, int kk) { return *reinterpret_cast<const bf16x8_t*>(base + (kk ? xoff1 : xoff0) + i * 1024); };
+        auto ldw = [&](const bf16_t* base, int j, int kk) { return *reinterpret_cast<const bf16x8_t*>(base + (kk ? woff1 : woff0) + j * 1024); };
+        auto step = [&](auto steady, int s, int slot, const bf16x8_t (&w)[2][2], bf16x8_t (&wn)[2][2]) {
+            constexpr bool STEADY = decltype(steady)::value;
+            if (STEADY || s + 2 < nsteps) RINGX_WAIT(VM_ONE); else RINGX_WAIT(0);
+            MMD_BAR();
+            const bool refill = STEADY || s + 3 < nsteps;
+            const bool more = STEADY || s + 1 < nsteps;
+            const bf16_t* nbase = lds + (slot == 2 ? 0 : slot + 1) * SE;
+            bf16x8_t x3n0, x3n1;                 // m-tile 3 of the next slice travels in spare registers (issued in rows 0/1)
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                // row i: 4 MFMAs (two accumulators alternate, so a dependent pair is 64 cycles apart), then this row's share of the
+                // traffic, fenced so the scheduler cannot hoist a load above the MFMAs
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[j][kk], xf[i][kk], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) {
+                    if (i < 3) { xf[i][0] = ldx(nbase, i, 0); xf[i][1] = ldx(nbase, i, 1); }
+                    if (i == 0) { x3n0 = ldx(nbase, 3, 0); wn[0][0] = ldw(nbase, 0, 0); }
+                    if (i == 1) { x3n1 = ldx(nbase, 3, 1); wn[0][1] = ldw(nbase, 0, 1); }
+                    if (i == 2) { wn[1][0] = ldw(nbase, 1, 0); wn[1][1] = ldw(nbase, 1, 1); }
+                }
+                if (refill) {       // NDMA = 4: rows 2, 3 two each; NDMA = 6: rows 1, 2, 3 two each
+                    constexpr int first = 4 - NDMA / 2;
+                    if (i >= first) { dma_k(slot, s + 3, 2 * (i - first)); dma_k(slot, s + 3, 2 * (i - first) + 1); }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (more) { xf[3][0] = x3n0; xf[3][1] = x3n1; }
+            __builtin_amdgcn_s_setprio(0);
+        };
+        auto prologue = [&]() { stage(0, 0); if (nsteps > 1) stage(1, 1); if (nsteps > 2) stage(2, 2); };
+        int tile = blockIdx.x;
+        tile_origin(tile); tile_sources(); prologue();
+        for (; tile < nblk; tile += G) {
+            if (nsteps > 2) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(VM_TWO) : "memory");
+            else if (nsteps > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(VM_ONE) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            MMD_BAR();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { xf[i][0] = ldx(lds, i, 0); xf[i][1] = ldx(lds, i, 1); }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { w0[j][0] = ldw(lds, j, 0); w0[j][1] = ldw(lds, j, 1); }
+            int slot = 0, s = 0;
+            for (; s + 4 < nsteps; s += 2) {
+                step(std::true_type{}, s, slot, w0, w1);
+                slot = slot == 2 ? 0 : slot + 1;
+                step(std::true_type{}, s + 1, slot, w1, w0);
+                slot = slot == 2 ? 0 : slot + 1;
+            }
+            for (; s < nsteps; s += 2) {
+                step(std::false_type{}, s, slot, w0, w1);
+                slot = slot == 2 ? 0 : slot + 1;
+                if (s + 1 < nsteps) {
+                    step(std::false_type{}, s + 1, slot, w1, w0);
+                    slot = slot == 2 ? 0 : slot + 1;
+                }
+            }
+            const int em0 = m0, en0 = n0;
+            if (tile + G < nblk) { tile_origin(tile + G); tile_sources(); prologue(); }
+            // lane holds, for m = .. + (lane & 31), the n-quads 8q + 4*lh (q = 0..3) of every 32-wide n-tile
+            if (gridDim.z > 1) {
+                float* wsl = p.ws + (long long)blockIdx.z * p.M * p.N;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int m = em0 + wr * 128 + i * 32 + (lane & 31);
+                    if (m < p.M) {
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const int nb = en0 + wc * 64 + j * 32;
+                            if (nb + 32 <= p.N) {
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4_t*>(wsl + (long long)m * p.N + nb + 8 * q + 4 * lh) = quad_of(acc[i][j], q);
+                            }
+                        }
+                    }
+                }
+                return;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = em0 + wr * 128 + i * 32 + (lane & 31);
+                const int mc = m < p.M ? m : p.M - 1;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int nb = en0 + wc * 64 + j * 32;
+                    const int nbc = nb + 32 <= p.N ? nb : p.N - 32;            // N tail: clamp the reads, mask the stores
+                    if constexpr (EPI == EPI_SWIGLU) {
+                        // rows 0..15 of the n-tile are gate, 16..31 up, of output columns (nb >> 5) * 16 ..+15
+                        const s16x8_t v = halves_to_row8(big_value_swiglu(quad_of(acc[i][j], 0), quad_of(acc[i][j], 2)),
+                                                         big_value_swiglu(quad_of(acc[i][j], 1), quad_of(acc[i][j], 3)));
+                        if (m < p.M && nb + 32 <= p.N) *reinterpret_cast<s16x8_t*>((bf16_t*)p.Y + (long long)m * p.ldy + (nb >> 5) * 16 + lh * 8) = v;
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; q += 2) {
+                            const s16x8_t v = halves_to_row8(big_value<EPI>(p, mc, nbc + 8 * q + 4 * lh, quad_of(acc[i][j], q)),
+                                                             big_value<EPI>(p, mc, nbc + 8 * (q + 1) + 4 * lh, quad_of(acc[i][j], q + 1)));
+                            if (m < p.M && nb + 32 <= p.N) *reinterpret_cast<s16x8_t*>((bf16_t*)p.Y + (long long)m * p.ldy + nb + 8 * q + lh * 8) = v;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        }
+    }
+#undef RINGX_WAIT
+}
+
+template <int WN, bool M32>
+static hipError_t launch_ringx_t(const GemmP& p, const GemmArgs& a, hipStream_t st, int splits) {
+    while (splits > 1 && (a.epi == EPI_SWIGLU || !a.splitk_ws || (size_t)splits * a.M * a.N * sizeof(float) > a.splitk_ws_bytes)) --splits;
+    constexpr int BN = 64 * WN;
+    const int tiles = cdiv(a.N, BN) * cdiv(a.M, 256);
+    const int slots = WN == 2 ? 512 : 256;                                   // resident blocks: two 4-wave blocks per CU, or one 8-wave block
+    dim3 grid(splits > 1 || tiles <= slots ? tiles : slots, 1, splits);
+    set_plan(a, WN == 2 ? GEMM_K_RING128X2 : GEMM_K_RING256, tiles, splits, (int)grid.x * splits);
+    const int KT = a.K >> 5;
+    const size_t smem = 3 * (256 * 32 + BN * 32) * sizeof(bf16_t);           // 96 KB / 72 KB
+    static bool attr_set = false;
+    if (!attr_set) {
+#define RX_ATTR(E) hipFuncSetAttribute((const void*)gemm_ringx_kernel<E, WN, M32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        RX_ATTR(EPI_NONE) RX_ATTR(EPI_GELU_TANH) RX_ATTR(EPI_GELU_ERF) RX_ATTR(EPI_RESID) RX_ATTR(EPI_SWIGLU)
+#undef RX_ATTR
+        attr_set = true;
+    }
+    const dim3 block(WN * 128);
+    switch (a.epi) {
+        case EPI_GELU_TANH: hipLaunchKernelGGL((gemm_ringx_kernel<EPI_GELU_TANH, WN, M32>), grid, block, smem, st, p, KT); break;
+        case EPI_GELU_ERF: hipLaunchKernelGGL((gemm_ringx_kernel<EPI_GELU_ERF, WN, M32>), grid, block, smem, st, p, KT); break;
+        case EPI_RESID: hipLaunchKernelGGL((gemm_ringx_kernel<EPI_RESID, WN, M32>), grid, block, smem, st, p, KT); break;
+        case EPI_SWIGLU: hipLaunchKernelGGL((gemm_ringx_kernel<EPI_SWIGLU, WN, M32>), grid, block, smem, st, p, KT); break;
+        default: hipLaunchKernelGGL((gemm_ringx_kernel<EPI_NONE, WN, M32>), grid, block, smem, st, p, KT); break;
+    }
+    if (splits > 1) {
+        long long work = (long long)a.M * ((a.N + 3) / 4);
+        hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), dim3(cdiv(work, 256)), dim3(256), 0, st, p, splits);
+    }
+    return hipGetLastError();
+}
+// flags: bit 0 = 4-wave 256x128 blocks (two per CU), bit 1 = 32x32x16 MFMA
+static hipError_t launch_ringx(int flags, const GemmP& p, const GemmArgs& a, hipStream_t st, int splits = 1) {
+    switch (flags & 3) {
+        case 0: return launch_ringx_t<4, false>(p, a, st, splits);
+        case 1: return launch_ringx_t<2, false>(p, a, st, splits);
+        case 2: return launch_ringx_t<4, true>(p, a, st, splits);
+        default: return launch_ringx_t<2, true>(p, a, st, splits);
+    }
+}
+
 static bool big_packed_ok(int dtype, const GemmArgs& a, int BN) {
     return dtype == MMD_BF16 && a.Wp != nullptr && a.M > 64 && (a.N % BN) == 0 && (a.K % 64) == 0 && (a.ldx % 8) == 0 &&
            ((uintptr_t)a.X % 16) == 0 && !a.out_f32 && (a.ldy % 4) == 0 && ((uintptr_t)a.Y % 8) == 0 &&
@@ -995,6 +1368,20 @@ static hipError_t launch_t(const GemmArgs& a, hipStream_t st, int* kind_out) {
                 if (kind_out) *kind_out = MMD_K_GEMM_TILE;
                 return launch_ring256(p, a, st, sp);
             }
+        }
+        if (variant >= GEMM_RINGX && variant < GEMM_RINGX + 8) {          // forced ring variants (A/B and parity of every instantiation)
+            if (!big_packed_ok(MMD_BF16, a, 16) || (a.N % 32) != 0) return hipErrorInvalidValue;
+            const int flags = variant - GEMM_RINGX;
+            int sp = 1;
+            if (flags & 4) {
+                const int slots = (flags & 1) ? 512 : 256, tl = cdiv(a.M, 256) * cdiv(a.N, (flags & 1) ? 128 : 256);
+                sp = slots / tl; if (sp < 1) sp = 1;
+                while (sp > 1 && a.K / sp < 1024) --sp;
+                if (sp < 2) sp = 2;
+            }
+            p.W = a.Wp;
+            if (kind_out) *kind_out = MMD_K_GEMM_TILE;
+            return launch_ringx(flags, p, a, st, sp);
         }
         const bool want_big = variant == GEMM_BIG || (variant == GEMM_AUTO && a.M > 64);
         if (want_big) {

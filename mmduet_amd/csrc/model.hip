@@ -146,7 +146,7 @@ static int gemm(mmd_ctx* c, const void* X, int64_t ldx, const void* W, int64_t l
     a.M = M; a.N = N; a.K = K; a.epi = epi; a.out_f32 = out_f32; a.variant = variant;
     a.splitk_ws = tower ? c->v_splitk_ws : c->splitk_ws; a.splitk_ws_bytes = tower ? c->v_splitk_bytes : c->splitk_bytes;
     a.plan_out = c->last_plan;
-    int kind = (variant == GEMM_SKINNY || (variant != GEMM_BIG && variant != GEMM_RING256 && variant != GEMM_RING256_SPLIT && variant != GEMM_LARGE && variant != GEMM_GENERIC && M <= 64)) ? MMD_K_GEMM_SKINNY : MMD_K_GEMM_TILE;
+    int kind = (variant == GEMM_SKINNY || (variant != GEMM_BIG && variant != GEMM_RING256 && variant != GEMM_RING256_SPLIT && variant < GEMM_RINGX && variant != GEMM_LARGE && variant != GEMM_GENERIC && M <= 64)) ? MMD_K_GEMM_SKINNY : MMD_K_GEMM_TILE;
     double e = (double)es(c);
     double bytes = ((double)M * K + (double)N * K) * e + (double)M * (epi == EPI_SWIGLU ? N / 2 : N) * (out_f32 ? 4.0 : e);
     ProfScope ps(c, kind, bytes, 2.0 * M * N * K);
@@ -1030,7 +1030,7 @@ extern "C" int mmd_op_gemm(mmd_ctx* c, const void* X, const void* W, const void*
     int NO = epi == EPI_SWIGLU ? N / 2 : N;
     void* Wp = nullptr;
     // the model holds every matrix in both layouts (or packed only): give the dispatcher the same choice, variant 0 included
-    if (variant == GEMM_AUTO || variant == GEMM_SKINNY || variant == GEMM_BIG || variant == GEMM_RING256 || variant == GEMM_RING256_SPLIT) { int rc = make_packed(c, W, N, K, &Wp); if (rc) return rc; }
+    if (variant == GEMM_AUTO || variant == GEMM_SKINNY || variant == GEMM_BIG || variant == GEMM_RING256 || variant == GEMM_RING256_SPLIT || variant >= GEMM_RINGX) { int rc = make_packed(c, W, N, K, &Wp); if (rc) return rc; }
     int rc = gemm(c, X, K, W, K, bias, R, NO, Y, NO, M, N, K, epi, out_f32, variant, Wp);
     if (Wp) { hipStreamSynchronize(c->stream); dev_free(c, Wp); }
     return rc;

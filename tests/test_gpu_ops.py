@@ -38,12 +38,12 @@ GEMM_SHAPES = [(49, 64, 64), (7, 130, 72), (200, 96, 588), (64, 256, 512), (300,
 def _variant_ok(ops, variant, M, N, K):
     if variant == 4 and (ops.dtype != torch.bfloat16 or M <= 64 or N % 64 or K % 64):
         pytest.skip('big-tile kernel: bf16, M > 64, N % 64 == 0, K % 64 == 0')
-    if variant in (6, 7) and (ops.dtype != torch.bfloat16 or M <= 64 or N % 32 or K % 64):
+    if (variant in (6, 7) or variant >= 16) and (ops.dtype != torch.bfloat16 or M <= 64 or N % 32 or K % 64):
         pytest.skip('256x256 kernel: bf16, M > 64, N % 32 == 0, K % 64 == 0')
 
 
 @pytest.mark.parametrize('M,N,K', GEMM_SHAPES)
-@pytest.mark.parametrize('variant', [1, 2, 3, 4, 6, 7])
+@pytest.mark.parametrize('variant', [1, 2, 3, 4, 6, 7, 16, 17, 18, 19, 21, 23])
 def test_gemm_bias(ops, M, N, K, variant):
     _variant_ok(ops, variant, M, N, K)
     g = torch.Generator().manual_seed(M * 7 + N)
@@ -54,10 +54,10 @@ def test_gemm_bias(ops, M, N, K, variant):
 
 
 @pytest.mark.parametrize('epi', ['gelu_tanh', 'gelu_erf', 'resid', 'swiglu'])
-@pytest.mark.parametrize('variant', [1, 2, 3, 4, 6, 7])
+@pytest.mark.parametrize('variant', [1, 2, 3, 4, 6, 7, 16, 17, 18, 19, 21, 23])
 def test_gemm_epilogues(ops, epi, variant):
     g = torch.Generator().manual_seed(11)
-    M, N, K = (70, 192, 136) if variant not in (4, 6, 7) else (300, 320, 192)
+    M, N, K = (70, 192, 136) if variant not in (4, 6, 7) and variant < 16 else (300, 320, 192)
     _variant_ok(ops, variant, M, N, K)
     X = torch.randn(M, K, generator=g); W = torch.randn(N, K, generator=g) / math.sqrt(K); b = 0.1 * torch.randn(N, generator=g)
     R = torch.randn(M, N, generator=g)

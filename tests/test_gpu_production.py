@@ -109,6 +109,37 @@ def test_production_gemm_shapes_take_the_production_kernel_and_match_fp32(ops, n
         assert plan['kernel'] in RING and plan['splits'] >= expect['min_splits'], plan                                        # automatic split-K over grid.z
 
 
+@pytest.mark.parametrize('variant', [16, 17, 18, 19])
+@pytest.mark.parametrize('name,M,N,K,epi', [('vit_fc1', 25515, 4352, 1152, 'gelu_tanh'), ('vit_o', 25515, 1152, 1152, 'resid'), ('gate_up_tail', 1303, 37888, 3584, 'swiglu'),
+                                            ('ragged', 3000, 1184, 704, 'none')])
+def test_every_ring_instantiation_at_production_shapes(ops, variant, name, M, N, K, epi):
+    """gemm_ringx_kernel<EPI, WN, M32>: 8-wave 256x256 / 4-wave 256x128 blocks x 16x16x32 / 32x32x16 MFMA, persistent multi-tile loops, M and N tails.
+    All four must agree with fp32 math to the bf16 bound AND with each other to accumulation-order noise."""
+    dev = ops.dev
+    g = torch.Generator(device=dev).manual_seed(N + K)
+    X = (torch.randn(M, K, generator=g, device=dev) * 0.7).to(torch.bfloat16)
+    W = (torch.randn(N, K, generator=g, device=dev) / math.sqrt(K)).to(torch.bfloat16)
+    b = (0.1 * torch.randn(N, generator=g, device=dev)).to(torch.bfloat16)
+    Xf = X.float()
+    if epi == 'swiglu':
+        gate, up = W[:N // 2], W[N // 2:]
+        Wi = torch.stack([gate.view(-1, 16, K), up.view(-1, 16, K)], 1).reshape(N, K).contiguous()
+        Y = ops.gemm(X, Wi, None, epi=epi, variant=variant)
+        ref = F.silu((Xf @ gate.float().T).to(torch.bfloat16).float()).to(torch.bfloat16).float() * (Xf @ up.float().T).to(torch.bfloat16).float()
+    elif epi == 'resid':
+        R = torch.randn(M, N, generator=g, device=dev).to(torch.bfloat16)
+        Y = ops.gemm(X, W, b, R=R, epi=epi, variant=variant)
+        ref = F.linear(Xf, W.float(), b.float()).to(torch.bfloat16).float() + R.float()
+    else:
+        Y = ops.gemm(X, W, b, epi=epi, variant=variant)
+        lin = F.linear(Xf, W.float(), b.float())
+        ref = O.gelu_tanh(lin.to(torch.bfloat16).float()) if epi == 'gelu_tanh' else lin
+    plan = _plan(ops)
+    err = _rel_err(Y, ref)
+    assert torch.isfinite(Y.float()).all() and err <= 2.4e-2, (variant, name, err, plan)
+    assert plan['kernel'] == (7 if variant & 1 else 6), plan
+
+
 def test_ring_gemm_is_deterministic_and_tile_order_independent(ops):
     """Same operands twice -> identical bits (no atomics, fixed reduction order); forced single-tile-per-block launch (variant 6 at a shape
     with <= 256 tiles) vs the persistent loop on a sub-problem -> identical bits for the shared rows."""

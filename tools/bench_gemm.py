@@ -48,10 +48,13 @@ if __name__ == '__main__':
     which = sys.argv[1] if len(sys.argv) > 1 else 'prod'
     if which == 'prod':
         rows = []
-        variants = [(0, 'auto'), (4, 'big'), (6, 'ring256'), (7, 'ring256-splitK'), (8, 'ring128x2'), (9, 'ring128x2-splitK')]
+        variants = [(0, 'auto'), (4, 'big'), (6, 'ring256'), (16, 'rx-8w-m16'), (17, 'rx-4w-m16'), (18, 'rx-8w-m32'), (19, 'rx-4w-m32'), (7, 'ring256-splitK'), (21, 'rx-4w-m16-splitK'), (23, 'rx-4w-m32-splitK')]
+        if len(sys.argv) > 3: variants = [v for v in variants if v[1] in sys.argv[3].split(',')]
         for M, shapes in ((25515, VIT), (1274, LLM[:4]), (1323, LLM[:4])):
             for name, N, K, epi in shapes:
                 for variant, vn in variants:
+                    if 'splitK' in vn and (K < 8192 or epi == 'swiglu'):
+                        continue
                     try:
                         ms = run(ops, M, N, K, epi, variant, iters=10)
                     except Exception as e:
