@@ -724,244 +724,35 @@ static void launch_big(const GemmP& p, const GemmArgs& a, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// gemm_ring256_kernel: 256 x 256 block tile, 8 waves (2 x 4, wave tile 128 x 64: 25 % fewer LDS fragment bytes per MFMA
-// and half the DMA instructions of the 128^2 kernel).  Every wave is software-pipelined against itself and the block
-// meets at ONE barrier per BK = 32 slice.  (Its predecessor ran four barrier-separated phases per 64-wide K tile with
-// the two wave groups of a SIMD half a phase apart: 1.1-1.2 PF steady state; this loop: 1.4-1.55 PF.)  K advances through a 3-slot DMA ring (32 KB per slot): in iteration s a wave issues the 32 MFMAs of slice s
-// from registers while (a) the fragments of slice s+1 arrive -- B into the other register set, A in place (row i of A is
-// dead once its 4 MFMAs are issued) -- and (b) its 4 global_load_lds of slice s+3 refill the slot slice s just vacated;
-// the streams are interleaved explicitly with sched_group_barrier.  One s_waitcnt vmcnt(4) lgkmcnt(0) + raw s_barrier
-// per slice makes slice s+1 visible.  X pieces are 16 rows x 64 B with the 16-byte chunk index XOR-ed by g[(row>>2)&3],
-// g = {0,3,2,1} (conflict-free b128 fragment reads), W pieces are the packed MFMA fragment tiles.
-// (A 4-wave variant with 128 x 128 wave tiles -- a third fewer LDS bytes per MFMA -- needs all 256 AGPRs for its
-// accumulators and the compiler spills inside the loop; not kept.)
-// ------------------------------------------------------------------------------------------------------------------
-template <int EPI>
-__global__ __launch_bounds__(512) void gemm_ring256_kernel(GemmP p, int KT) {
-    constexpr int BM = 256, BN = 256, BK = 32;
-    constexpr int XE = BM * BK, WE = BN * BK, SE = XE + WE;    // 16384 elements = 32 KB per slot
-    extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lr = lane & 15, lq = lane >> 4;
-    const int wr = wave >> 2, wc = wave & 3;
-    // persistent over tiles: block b takes the logical tiles b, b + G, b + 2G, ... (G = gridDim.x, a multiple of 8 or the tile count,
-    // so a block stays on its XCD's share of the bijective XCD remap); while it converts and stores tile i, the first three
-    // slices of tile i+1 are already in flight
-    const int nbx = (p.N + BN - 1) / BN, nby = (p.M + BM - 1) / BM;
-    const int nblk = nbx * nby;
-    int m0 = 0, n0 = 0;
-    auto tile_origin = [&](int bid) {
-        const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-        int mt, nt;
-        if (p.N > p.M) { nt = bid / nby; mt = bid % nby; } else { mt = bid / nbx; nt = bid % nbx; }
-        m0 = mt * BM; n0 = nt * BN;
-    };
-    const int ntiles = p.N >> 4;
-    const bf16_t* X = (const bf16_t*)p.X;
-    const bf16_t* Wp = (const bf16_t*)p.W;
-    // split-K: block z covers slices [t0, t0 + nsteps) and leaves an fp32 slab for splitk_reduce_kernel
-    const int nsteps_all = p.K / BK;
-    const int zsteps = (nsteps_all + gridDim.z - 1) / gridDim.z;
-    const int t0 = blockIdx.z * zsteps;
-    const int nsteps = min(nsteps_all, t0 + zsteps) - t0;
-
-    const int srow = lane >> 2, spos = lane & 3;
-    const int sswz = (0x1230 >> (((srow >> 2) & 3) * 4)) & 3;
-    // per-wave DMA sources of slice 0 (2 X pieces + 2 W pieces) as 32-bit element offsets; a slice advances X by 32
-    // elements and W by one k-tile (512 elements)
-    int xo[2], wo[2];
-    auto tile_sources = [&]() {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int pi = wave + 8 * j;
-            int row = m0 + pi * 16 + srow; row = row < p.M ? row : p.M - 1;
-            xo[j] = row * (int)p.ldx + ((spos ^ sswz) * 8) + t0 * BK;
-            int ntile = n0 / 16 + pi; ntile = ntile < ntiles ? ntile : ntiles - 1;
-            wo[j] = (ntile * KT * 64 + lane) * 8 + t0 * 512;
-        }
-    };
-    auto stage = [&](int slot, int step) {
-        bf16_t* xs = lds + slot * SE;
-        bf16_t* ws = xs + XE;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int pi = wave + 8 * j;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + (long long)xo[j] + step * BK),
-                                             (__attribute__((address_space(3))) void*)(xs + pi * 512), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wp + (long long)wo[j] + (long long)step * 512),
-                                             (__attribute__((address_space(3))) void*)(ws + pi * 512), 16, 0, 0);
-        }
-    };
-
-    f32x4_t acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0, 0, 0, 0};
-
-    const int rswz = (0x1230 >> (((lr >> 2) & 3) * 4)) & 3;
-    const int aoff = (wr * 8) * 512 + lr * 32 + ((lq ^ rswz) * 8);
-    const int boff = XE + (wc * 4) * 512 + lane * 8;
-    bf16x8_t a[8], b0[4], b1[4];
-    // STEADY = every condition is known true (s + 3 < nsteps): the body is ONE basic block, so the scheduler can interleave.
-    auto step = [&](auto steady, int s, int slot, const bf16x8_t (&b)[4], bf16x8_t (&bn)[4]) {
-        constexpr bool STEADY = decltype(steady)::value;
-        if (STEADY || s + 2 < nsteps) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        MMD_BAR();
-        const bool refill = STEADY || s + 3 < nsteps;
-        const bool more = STEADY || s + 1 < nsteps;
-        const bf16_t* nbase = lds + (slot == 2 ? 0 : slot + 1) * SE;
-        bf16_t* xs = lds + slot * SE;
-        bf16x8_t a6n, a7n;                 // rows 6 and 7 of the next slice travel in spare registers (issued early, see below)
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            // row i: its 4 MFMAs first (everything they read was waited for at the top), then -- fenced, so the scheduler cannot
-            // hoist a load above MFMAs and make the waitcnt pass drain it -- this row's share of the traffic: rows 0-5 refresh
-            // their own A row in place, rows 0-3 fetch one B fragment, rows 0-1 fetch A rows 6/7 early so the last LDS read is
-            // two rows old at the next barrier, rows 4-7 issue one DMA of slice s+3 each.
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (more) {
-                if (i < 6) a[i] = *reinterpret_cast<const bf16x8_t*>(nbase + aoff + i * 512);
-                if (i < 4) bn[i] = *reinterpret_cast<const bf16x8_t*>(nbase + boff + i * 512);
-                if (i == 0) a6n = *reinterpret_cast<const bf16x8_t*>(nbase + aoff + 6 * 512);
-                if (i == 1) a7n = *reinterpret_cast<const bf16x8_t*>(nbase + aoff + 7 * 512);
-            }
-            if (refill && i >= 4) {
-                const int j = (i - 4) >> 1, pi = wave + 8 * j;
-                if ((i & 1) == 0)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + (long long)xo[j] + (s + 3) * BK),
-                                                     (__attribute__((address_space(3))) void*)(xs + pi * 512), 16, 0, 0);
-                else
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wp + (long long)wo[j] + (long long)(s + 3) * 512),
-                                                     (__attribute__((address_space(3))) void*)(xs + XE + pi * 512), 16, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (more) { a[6] = a6n; a[7] = a7n; }
-        __builtin_amdgcn_s_setprio(0);
-    };
-
-    auto prologue = [&]() { stage(0, 0); if (nsteps > 1) stage(1, 1); if (nsteps > 2) stage(2, 2); };
-    const int G = gridDim.x;
-    int tile = blockIdx.x;
-    tile_origin(tile); tile_sources(); prologue();
-    for (; tile < nblk; tile += G) {
-        if (nsteps > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (nsteps > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        MMD_BAR();
-    #pragma unroll
-        for (int i = 0; i < 8; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(lds + aoff + i * 512);
-    #pragma unroll
-        for (int j = 0; j < 4; ++j) b0[j] = *reinterpret_cast<const bf16x8_t*>(lds + boff + j * 512);
-        int slot = 0, s = 0;
-        for (; s + 4 < nsteps; s += 2) {               // steady state: both slices have s + 3 < nsteps
-            step(std::true_type{}, s, slot, b0, b1);
-            slot = slot == 2 ? 0 : slot + 1;
-            step(std::true_type{}, s + 1, slot, b1, b0);
-            slot = slot == 2 ? 0 : slot + 1;
-        }
-        for (; s < nsteps; s += 2) {                   // the last slices: conditions evaluated
-            step(std::false_type{}, s, slot, b0, b1);
-            slot = slot == 2 ? 0 : slot + 1;
-            if (s + 1 < nsteps) {
-                step(std::false_type{}, s + 1, slot, b1, b0);
-                slot = slot == 2 ? 0 : slot + 1;
-            }
-        }
-
-        // tile done: every fragment read was waited for before the last barrier, so the ring is free -- start the next tile's
-        // first slices NOW and let them fly while this tile's accumulators are converted and stored
-        const int em0 = m0, en0 = n0;
-        if (tile + G < nblk) { tile_origin(tile + G); tile_sources(); prologue(); }
-        if (gridDim.z > 1) {
-            float* wsl = p.ws + (long long)blockIdx.z * p.M * p.N;
-    #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int m = em0 + wr * 128 + i * 16 + lr;
-                if (m < p.M) {
-    #pragma unroll
-                    for (int j = 0; j < 4; ++j) { const int nb = en0 + wc * 64 + j * 16; if (nb + 16 <= p.N) *reinterpret_cast<f32x4_t*>(wsl + (long long)m * p.N + nb + lq * 4) = acc[i][j]; }
-                }
-            }
-            return;
-        }
-    #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int m = em0 + wr * 128 + i * 16 + lr;
-            const int mc = m < p.M ? m : p.M - 1;                                   // rows past M compute on a valid row and are not stored
-            if constexpr (EPI == EPI_SWIGLU) {
-                const int nb = en0 + wc * 64;                                       // gate/up pairs (0,1) and (2,3) -> two neighbouring output tiles
-                const int ob = (nb >> 5) * 16;
-                const s16x8_t v = pair_to_row8(big_value_swiglu(acc[i][0], acc[i][1]), big_value_swiglu(acc[i][2], acc[i][3]));
-                if (m < p.M && nb + 32 * (lq & 1) + 32 <= p.N) *reinterpret_cast<s16x8_t*>((bf16_t*)p.Y + (long long)m * p.ldy + ob + (lq & 1) * 16 + (lq >> 1) * 8) = v;
-            } else {
-    #pragma unroll
-                for (int j = 0; j < 4; j += 2) {
-                    const int nb = en0 + wc * 64 + j * 16;
-                    const int na = nb + 16 <= p.N ? nb : p.N - 16, nc = nb + 32 <= p.N ? nb + 16 : p.N - 16;      // N tail: clamp the reads
-                    const s16x8_t v = pair_to_row8(big_value<EPI>(p, mc, na + lq * 4, acc[i][j]), big_value<EPI>(p, mc, nc + lq * 4, acc[i][j + 1]));
-                    if (m < p.M && nb + 16 * (lq & 1) + 16 <= p.N) *reinterpret_cast<s16x8_t*>((bf16_t*)p.Y + (long long)m * p.ldy + nb + (lq & 1) * 16 + (lq >> 1) * 8) = v;
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0, 0, 0, 0};
-    }
-}
-
-static hipError_t launch_ring256(const GemmP& p, const GemmArgs& a, hipStream_t st, int splits = 1) {
-    while (splits > 1 && (a.epi == EPI_SWIGLU || !a.splitk_ws || (size_t)splits * a.M * a.N * sizeof(float) > a.splitk_ws_bytes)) --splits;
-    const int tiles = cdiv(a.N, 256) * cdiv(a.M, 256);
-    // one block per CU, looping over its tiles (split-K launches keep one tile per block: their blocks already fill the machine once)
-    dim3 grid(splits > 1 || tiles <= 256 ? tiles : 256, 1, splits);
-    set_plan(a, GEMM_K_RING256, tiles, splits, (int)grid.x * splits);
-    const int KT = a.K >> 5;
-    const size_t smem = 3 * (256 * 32 + 256 * 32) * sizeof(bf16_t);          // 96 KB
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void*)gemm_ring256_kernel<EPI_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipFuncSetAttribute((const void*)gemm_ring256_kernel<EPI_GELU_TANH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipFuncSetAttribute((const void*)gemm_ring256_kernel<EPI_GELU_ERF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipFuncSetAttribute((const void*)gemm_ring256_kernel<EPI_RESID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipFuncSetAttribute((const void*)gemm_ring256_kernel<EPI_SWIGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_set = true;
-    }
-    switch (a.epi) {
-        case EPI_GELU_TANH: hipLaunchKernelGGL((gemm_ring256_kernel<EPI_GELU_TANH>), grid, dim3(512), smem, st, p, KT); break;
-        case EPI_GELU_ERF: hipLaunchKernelGGL((gemm_ring256_kernel<EPI_GELU_ERF>), grid, dim3(512), smem, st, p, KT); break;
-        case EPI_RESID: hipLaunchKernelGGL((gemm_ring256_kernel<EPI_RESID>), grid, dim3(512), smem, st, p, KT); break;
-        case EPI_SWIGLU: hipLaunchKernelGGL((gemm_ring256_kernel<EPI_SWIGLU>), grid, dim3(512), smem, st, p, KT); break;
-        default: hipLaunchKernelGGL((gemm_ring256_kernel<EPI_NONE>), grid, dim3(512), smem, st, p, KT); break;
-    }
-    if (splits > 1) {
-        long long work = (long long)a.M * ((a.N + 3) / 4);
-        hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), dim3(cdiv(work, 256)), dim3(256), 0, st, p, splits);
-    }
-    return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// gemm_ringx_kernel<EPI, WN, M32>: the ring GEMM generalised.
-//   WN  = waves along N (block tile 256 x 64*WN).  WN = 4 is the 8-wave 256 x 256 block of gemm_ring256_kernel (one per CU).
-//         WN = 2 is a 4-wave 256 x 128 block with a 72 KB ring: TWO blocks are resident per CU (one wave of each per SIMD) and run
-//         unsynchronised, so one block's tile seam -- drain, fp32 -> bf16 conversion, epilogue math, the store burst -- is covered by
-//         the other block's MFMAs (the 8-wave block leaves the matrix pipe idle there: 10-15 % of a K = 1152 tile), and the tile
-//         count doubles, which halves the tail quantisation over 256 CUs.
-//   M32 = v_mfma_f32_32x32x16_bf16 instead of 16x16x32: back-to-back issue at the full 32 cycles (16x16x32 measures ~17 for its
-//         nominal 16), half the MFMA instructions per slice.  Same LDS images: a 32-row operand = two neighbouring 16-row pieces,
-//         lane l reads row (l & 15) of piece (l >> 4) & 1, k chunk 2*kk + (l >> 5) -- conflict-free for both the fragment-major W
-//         pieces and the XOR-swizzled X pieces.
-// Wave tile 128 x 64 in every variant; BK = 32 slices through a 3-slot DMA ring; one counted s_waitcnt + raw s_barrier per slice.
-// Tile order: bijective XCD remap, then bands of up to 8 m-tiles swept m-fastest, so the blocks that run together on an XCD share a
-// few X panels and a few W panels (for N > M this is the W-panel-stationary order of the LLM chunk).
+// gemm_ringx_kernel<EPI, WN, M32, NS, EARLY>: the ring GEMM -- the MFMA-bound kernel of the path (every tower / projector GEMM of a
+// 35-frame batch, gate_up and, with split-K over grid.z, down_proj of a >= 600-row LLM chunk).
+//
+// Block tile 256 x 64*WN, wave tile 128 x 64, K in BK = 32 slices through an NS-slot ring filled by direct-to-LDS DMA
+// (global_load_lds, 1 KB per wave instruction).  Every wave is software-pipelined against itself: in step s it issues the MFMAs of
+// slice s from registers while (a) the fragments of slice s+1 arrive from LDS -- B into the other register set, A in place (row i of
+// A is dead once its MFMAs are issued; the last rows travel in spare registers so the last LDS read is two rows old at the barrier)
+// -- and (b) its DMAs of slice s+NS refill the slot slice s just vacated.  Rows are fenced with sched_barrier so the compiler cannot
+// hoist a load above MFMAs (its waitcnt pass would drain it).  ONE counted `s_waitcnt vmcnt((NS-2)*NDMA) lgkmcnt(0)` + raw s_barrier
+// per slice.  X pieces are 16 rows x 64 B with the 16-byte chunk index XOR-ed by g[(row>>2)&3], g = {0,3,2,1} (conflict-free b128
+// fragment reads, SQ_LDS_BANK_CONFLICT = 0), W pieces are the packed MFMA fragment tiles.  The kernel is persistent (one block per
+// resident slot looping over its tiles: the next tile's first slices are in flight while the current tile is converted and stored) and
+// the epilogue exchanges neighbouring column groups across lanes (v_permlane16/32_swap) so every lane stores 16 contiguous bytes.
+// Tile order: bijective XCD remap, then bands of up to 8 m-tiles swept m-fastest (for N > M this is the W-panel-stationary order).
+//
+// Shipped instantiation: WN = 4 (8 waves, 256 x 256), 16x16x32 MFMA, NS = 3, EARLY (the refill DMAs in the FIRST rows of a step).
+// What the template parameters were built to test, on random operands, within one process (profiles/r02_gemm_shapes.json):
+//   EARLY  refill DMAs issued right after the barrier instead of in the last rows: +3-5 % (1.20 -> 1.25 PF on gate_up at M = 1274).
+//   NS = 4 one more slice of DMA lookahead (128 KB ring): +-0 -- DMA latency is covered at NS = 3.
+//   M32    v_mfma_f32_32x32x16_bf16 (half the MFMA instructions, same LDS images: a 32-row operand = two neighbouring 16-row pieces):
+//          5-10 % SLOWER on every shape although its loop is as clean in the ISA; not shipped.
+//   WN = 2 4-wave 256 x 128 blocks, two unsynchronised blocks per CU (72 KB rings), optionally started half a tile apart so that one
+//          block's tile seam is covered by the other's MFMAs: loses 10-15 % on long-K shapes (1.5 x the DMA bytes per flop), +-0 on the
+//          K = 1152 tower shapes with or without the stagger; it wins only where 256 x 256 tiles cannot fill the chip.
+//   DBG    timing-only modes (wrong results): with NO DMA at all the same loop runs 1.15-1.46 PF, with the real DMA 0.9-1.25 PF: the
+//          ceiling of this structure is the wave-level issue stream (32 MFMA + 12 ds_read_b128 + 4 LDS-DMA per wave and slice, two
+//          waves per SIMD), not HBM / L2 (FETCH_SIZE 0.6 GB per gate_up launch = 2 TB/s) and not LDS conflicts (0).
+//          rocprofv3 PMC on gate_up: SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x GRBM cycles) = 56-60 %; per wave 23 % issuing, 47 % waiting
+//          for the matrix pipe, 30 % parked at the slice barrier (profiles/r02_pmc_gemm.txt).
 // ------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ f32x4_t quad_of(const f32x16_t& v, int q) { return f32x4_t{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]}; }
 // two neighbouring n-quads (4 bf16 each) held by the two half-waves -> 8 consecutive columns per lane (v_permlane32_swap):
@@ -974,12 +765,13 @@ __device__ __forceinline__ s16x8_t halves_to_row8(const s16x4_t& q0, const s16x4
     return __builtin_bit_cast(s16x8_t, o);
 }
 
-template <int EPI, int WN, bool M32>
+// DBG != 0: timing experiments only (results are WRONG): 1 = X pieces fetched as contiguous 1 KB runs, 2 = no X DMA, 3 = no DMA at all
+template <int EPI, int WN, bool M32, int NS, bool EARLY, int DBG = 0>
 __global__ __launch_bounds__(WN * 128, 2) void gemm_ringx_kernel(GemmP p, int KT) {
     constexpr int BM = 256, BN = 64 * WN, BK = 32, NW = 2 * WN;
     constexpr int XE = BM * BK, WE = BN * BK, SE = XE + WE;    // elements per ring slot (32 KB / 24 KB)
     constexpr int XP = (BM / 16) / NW, WP = (BN / 16) / NW;    // X / W pieces (1 KB DMAs) per wave and slice: 2+2 (8 waves), 4+2 (4 waves)
-    constexpr int NDMA = XP + WP;
+    constexpr int NDMA = DBG == 3 ? 0 : (DBG == 2 ? WP : XP + WP);     // DMAs really issued per wave and slice (what vmcnt counts)
     extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4, lh = lane >> 5;
@@ -1022,10 +814,17 @@ __global__ __launch_bounds__(WN * 128, 2) void gemm_ringx_kernel(GemmP p, int KT
         }
     };
     auto dma_x = [&](int slot, int step, int j) {
+        if constexpr (DBG >= 2) return;
+        if constexpr (DBG == 1) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + (long long)min(m0 + (wave + NW * j) * 16, p.M - 16) * p.ldx + (long long)step * 512 + lane * 8),
+                                             (__attribute__((address_space(3))) void*)(lds + slot * SE + (wave + NW * j) * 512), 16, 0, 0);
+            return;
+        }
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + (long long)xo[j] + step * BK),
                                          (__attribute__((address_space(3))) void*)(lds + slot * SE + (wave + NW * j) * 512), 16, 0, 0);
     };
     auto dma_w = [&](int slot, int step, int j) {
+        if constexpr (DBG == 3) return;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wp + (long long)wo[j] + (long long)step * 512),
                                          (__attribute__((address_space(3))) void*)(lds + slot * SE + XE + (wave + NW * j) * 512), 16, 0, 0);
     };
@@ -1036,12 +835,20 @@ __global__ __launch_bounds__(WN * 128, 2) void gemm_ringx_kernel(GemmP p, int KT
         for (int j = 0; j < WP; ++j) dma_w(slot, step, j);
     };
     // the k-th DMA of a slice, k in [0, NDMA): X pieces first
-    auto dma_k = [&](int slot, int step, int k) { if (k < XP) dma_x(slot, step, k); else dma_w(slot, step, k - XP); };
+    auto dma_k = [&](int slot, int step, int k) { if (k < XP) dma_x(slot, step, k); else if (k < XP + WP) dma_w(slot, step, k - XP); };
 
     constexpr int VM_ONE = NDMA, VM_TWO = 2 * NDMA;       // vmcnt leaving one / two slices in flight
 #define RINGX_WAIT(n) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(n) : "memory")
     const int G = gridDim.x;
     const int rswz = (0x1230 >> (((lr >> 2) & 3) * 4)) & 3;
+    if constexpr (WN == 2 && NS == 3) {
+        // Two blocks share a CU and would run in lockstep (same start, same tile length): both in their tile seam at the same time.  The
+        // blocks dispatched into the second slot (ids >= 256, observed placement -- speed only) start ~half a tile late, so that one
+        // block's seam (drain, epilogue math, store burst) is covered by the other's MFMAs for the rest of the launch.
+        if (G > 256 && (int)blockIdx.x >= 256 && p.kper > 0) {
+            for (int i = 0; i < p.kper; ++i) __builtin_amdgcn_s_sleep(127);          // 127 x 64 cycles ~ 4 us each
+        }
+    }
 
     if constexpr (!M32) {
         // ---------------- 16x16x32: 8 x 4 accumulator tiles, the schedule of gemm_ring256_kernel ----------------
@@ -1055,11 +862,13 @@ __global__ __launch_bounds__(WN * 128, 2) void gemm_ringx_kernel(GemmP p, int KT
         bf16x8_t a[8], b0[4], b1[4];
         auto step = [&](auto steady, int s, int slot, const bf16x8_t (&b)[4], bf16x8_t (&bn)[4]) {
             constexpr bool STEADY = decltype(steady)::value;
-            if (STEADY || s + 2 < nsteps) RINGX_WAIT(VM_ONE); else RINGX_WAIT(0);
+            if (STEADY || s + NS - 1 < nsteps) RINGX_WAIT((NS - 2) * NDMA);
+            else if (NS == 4 && s + 2 < nsteps) RINGX_WAIT(NDMA);
+            else RINGX_WAIT(0);
             MMD_BAR();
-            const bool refill = STEADY || s + 3 < nsteps;
+            const bool refill = STEADY || s + NS < nsteps;
             const bool more = STEADY || s + 1 < nsteps;
-            const bf16_t* nbase = lds + (slot == 2 ? 0 : slot + 1) * SE;
+            const bf16_t* nbase = lds + (slot == NS - 1 ? 0 : slot + 1) * SE;
             bf16x8_t a6n, a7n;
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -1074,18 +883,19 @@ __global__ __launch_bounds__(WN * 128, 2) void gemm_ringx_kernel(GemmP p, int KT
                     if (i == 1) a7n = *reinterpret_cast<const bf16x8_t*>(nbase + aoff + 7 * 512);
                 }
                 if (refill) {       // NDMA = 4: rows 4..7; NDMA = 6: rows 2..7
-                    if (i >= 8 - NDMA) dma_k(slot, s + 3, i - (8 - NDMA));
+                    if (EARLY ? i < XP + WP : i >= 8 - (XP + WP)) dma_k(slot, s + NS, i - (EARLY ? 0 : 8 - (XP + WP)));
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (more) { a[6] = a6n; a[7] = a7n; }
             __builtin_amdgcn_s_setprio(0);
         };
-        auto prologue = [&]() { stage(0, 0); if (nsteps > 1) stage(1, 1); if (nsteps > 2) stage(2, 2); };
+        auto prologue = [&]() { stage(0, 0); if (nsteps > 1) stage(1, 1); if (nsteps > 2) stage(2, 2); if (NS > 3 && nsteps > 3) stage(3, 3); };
         int tile = blockIdx.x;
         tile_origin(tile); tile_sources(); prologue();
         for (; tile < nblk; tile += G) {
-            if (nsteps > 2) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(VM_TWO) : "memory");
+            if (NS > 3 && nsteps > 3) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(3 * NDMA) : "memory");
+            else if (nsteps > 2) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(VM_TWO) : "memory");
             else if (nsteps > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(VM_ONE) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             MMD_BAR();
@@ -1094,18 +904,18 @@ __global__ __launch_bounds__(WN * 128, 2) void gemm_ringx_kernel(GemmP p, int KT
 #pragma unroll
             for (int j = 0; j < 4; ++j) b0[j] = *reinterpret_cast<const bf16x8_t*>(lds + boff + j * 512);
             int slot = 0, s = 0;
-            for (; s + 4 < nsteps; s += 2) {
+            for (; s + NS + 1 < nsteps; s += 2) {
                 step(std::true_type{}, s, slot, b0, b1);
-                slot = slot == 2 ? 0 : slot + 1;
+                slot = slot == NS - 1 ? 0 : slot + 1;
                 step(std::true_type{}, s + 1, slot, b1, b0);
-                slot = slot == 2 ? 0 : slot + 1;
+                slot = slot == NS - 1 ? 0 : slot + 1;
             }
             for (; s < nsteps; s += 2) {
                 step(std::false_type{}, s, slot, b0, b1);
-                slot = slot == 2 ? 0 : slot + 1;
+                slot = slot == NS - 1 ? 0 : slot + 1;
                 if (s + 1 < nsteps) {
                     step(std::false_type{}, s + 1, slot, b1, b0);
-                    slot = slot == 2 ? 0 : slot + 1;
+                    slot = slot == NS - 1 ? 0 : slot + 1;
                 }
             }
             const int em0 = m0, en0 = n0;
@@ -1167,11 +977,13 @@ __global__ __launch_bounds__(WN * 128, 2) void gemm_ringx_kernel(GemmP p, int KT
         auto ldw = [&](const bf16_t* base, int j, int kk) { return *reinterpret_cast<const bf16x8_t*>(base + (kk ? woff1 : woff0) + j * 1024); };
         auto step = [&](auto steady, int s, int slot, const bf16x8_t (&w)[2][2], bf16x8_t (&wn)[2][2]) {
             constexpr bool STEADY = decltype(steady)::value;
-            if (STEADY || s + 2 < nsteps) RINGX_WAIT(VM_ONE); else RINGX_WAIT(0);
+            if (STEADY || s + NS - 1 < nsteps) RINGX_WAIT((NS - 2) * NDMA);
+            else if (NS == 4 && s + 2 < nsteps) RINGX_WAIT(NDMA);
+            else RINGX_WAIT(0);
             MMD_BAR();
-            const bool refill = STEADY || s + 3 < nsteps;
+            const bool refill = STEADY || s + NS < nsteps;
             const bool more = STEADY || s + 1 < nsteps;
-            const bf16_t* nbase = lds + (slot == 2 ? 0 : slot + 1) * SE;
+            const bf16_t* nbase = lds + (slot == NS - 1 ? 0 : slot + 1) * SE;
             bf16x8_t x3n0, x3n1;                 // m-tile 3 of the next slice travels in spare registers (issued in rows 0/1)
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -1190,19 +1002,20 @@ __global__ __launch_bounds__(WN * 128, 2) void gemm_ringx_kernel(GemmP p, int KT
                     if (i == 2) { wn[1][0] = ldw(nbase, 1, 0); wn[1][1] = ldw(nbase, 1, 1); }
                 }
                 if (refill) {       // NDMA = 4: rows 2, 3 two each; NDMA = 6: rows 1, 2, 3 two each
-                    constexpr int first = 4 - NDMA / 2;
-                    if (i >= first) { dma_k(slot, s + 3, 2 * (i - first)); dma_k(slot, s + 3, 2 * (i - first) + 1); }
+                    constexpr int first = EARLY ? 0 : 4 - (XP + WP) / 2;
+                    if (i >= first && i < first + (XP + WP) / 2) { dma_k(slot, s + NS, 2 * (i - first)); dma_k(slot, s + NS, 2 * (i - first) + 1); }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (more) { xf[3][0] = x3n0; xf[3][1] = x3n1; }
             __builtin_amdgcn_s_setprio(0);
         };
-        auto prologue = [&]() { stage(0, 0); if (nsteps > 1) stage(1, 1); if (nsteps > 2) stage(2, 2); };
+        auto prologue = [&]() { stage(0, 0); if (nsteps > 1) stage(1, 1); if (nsteps > 2) stage(2, 2); if (NS > 3 && nsteps > 3) stage(3, 3); };
         int tile = blockIdx.x;
         tile_origin(tile); tile_sources(); prologue();
         for (; tile < nblk; tile += G) {
-            if (nsteps > 2) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(VM_TWO) : "memory");
+            if (NS > 3 && nsteps > 3) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(3 * NDMA) : "memory");
+            else if (nsteps > 2) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(VM_TWO) : "memory");
             else if (nsteps > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(VM_ONE) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             MMD_BAR();
@@ -1211,18 +1024,18 @@ __global__ __launch_bounds__(WN * 128, 2) void gemm_ringx_kernel(GemmP p, int KT
 #pragma unroll
             for (int j = 0; j < 2; ++j) { w0[j][0] = ldw(lds, j, 0); w0[j][1] = ldw(lds, j, 1); }
             int slot = 0, s = 0;
-            for (; s + 4 < nsteps; s += 2) {
+            for (; s + NS + 1 < nsteps; s += 2) {
                 step(std::true_type{}, s, slot, w0, w1);
-                slot = slot == 2 ? 0 : slot + 1;
+                slot = slot == NS - 1 ? 0 : slot + 1;
                 step(std::true_type{}, s + 1, slot, w1, w0);
-                slot = slot == 2 ? 0 : slot + 1;
+                slot = slot == NS - 1 ? 0 : slot + 1;
             }
             for (; s < nsteps; s += 2) {
                 step(std::false_type{}, s, slot, w0, w1);
-                slot = slot == 2 ? 0 : slot + 1;
+                slot = slot == NS - 1 ? 0 : slot + 1;
                 if (s + 1 < nsteps) {
                     step(std::false_type{}, s + 1, slot, w1, w0);
-                    slot = slot == 2 ? 0 : slot + 1;
+                    slot = slot == NS - 1 ? 0 : slot + 1;
                 }
             }
             const int em0 = m0, en0 = n0;
@@ -1280,30 +1093,33 @@ __global__ __launch_bounds__(WN * 128, 2) void gemm_ringx_kernel(GemmP p, int KT
 #undef RINGX_WAIT
 }
 
-template <int WN, bool M32>
-static hipError_t launch_ringx_t(const GemmP& p, const GemmArgs& a, hipStream_t st, int splits) {
+template <int WN, bool M32, int NS, bool EARLY>
+static hipError_t launch_ringx_t(const GemmP& p, const GemmArgs& a, hipStream_t st, int splits, bool stagger = true) {
     while (splits > 1 && (a.epi == EPI_SWIGLU || !a.splitk_ws || (size_t)splits * a.M * a.N * sizeof(float) > a.splitk_ws_bytes)) --splits;
     constexpr int BN = 64 * WN;
     const int tiles = cdiv(a.N, BN) * cdiv(a.M, 256);
-    const int slots = WN == 2 ? 512 : 256;                                   // resident blocks: two 4-wave blocks per CU, or one 8-wave block
+    const int slots = (WN == 2 && NS == 3) ? 512 : 256;                      // resident blocks: two 4-wave blocks per CU (72 KB rings), else one
     dim3 grid(splits > 1 || tiles <= slots ? tiles : slots, 1, splits);
     set_plan(a, WN == 2 ? GEMM_K_RING128X2 : GEMM_K_RING256, tiles, splits, (int)grid.x * splits);
     const int KT = a.K >> 5;
-    const size_t smem = 3 * (256 * 32 + BN * 32) * sizeof(bf16_t);           // 96 KB / 72 KB
+    const size_t smem = NS * (256 * 32 + BN * 32) * sizeof(bf16_t);          // 96 KB / 72 KB (3 slots), 128 KB / 96 KB (4)
     static bool attr_set = false;
     if (!attr_set) {
-#define RX_ATTR(E) hipFuncSetAttribute((const void*)gemm_ringx_kernel<E, WN, M32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+#define RX_ATTR(E) hipFuncSetAttribute((const void*)gemm_ringx_kernel<E, WN, M32, NS, EARLY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         RX_ATTR(EPI_NONE) RX_ATTR(EPI_GELU_TANH) RX_ATTR(EPI_GELU_ERF) RX_ATTR(EPI_RESID) RX_ATTR(EPI_SWIGLU)
 #undef RX_ATTR
         attr_set = true;
     }
     const dim3 block(WN * 128);
+    GemmP q = p;
+    // start-up stagger of the second-slot blocks in ~4 us units: about half a tile (K/32 steps of ~0.75 us) -- see the kernel
+    q.kper = (!stagger || splits > 1) ? 0 : ((a.K / 32) * 10) / 100 + 1;
     switch (a.epi) {
-        case EPI_GELU_TANH: hipLaunchKernelGGL((gemm_ringx_kernel<EPI_GELU_TANH, WN, M32>), grid, block, smem, st, p, KT); break;
-        case EPI_GELU_ERF: hipLaunchKernelGGL((gemm_ringx_kernel<EPI_GELU_ERF, WN, M32>), grid, block, smem, st, p, KT); break;
-        case EPI_RESID: hipLaunchKernelGGL((gemm_ringx_kernel<EPI_RESID, WN, M32>), grid, block, smem, st, p, KT); break;
-        case EPI_SWIGLU: hipLaunchKernelGGL((gemm_ringx_kernel<EPI_SWIGLU, WN, M32>), grid, block, smem, st, p, KT); break;
-        default: hipLaunchKernelGGL((gemm_ringx_kernel<EPI_NONE, WN, M32>), grid, block, smem, st, p, KT); break;
+        case EPI_GELU_TANH: hipLaunchKernelGGL((gemm_ringx_kernel<EPI_GELU_TANH, WN, M32, NS, EARLY>), grid, block, smem, st, q, KT); break;
+        case EPI_GELU_ERF: hipLaunchKernelGGL((gemm_ringx_kernel<EPI_GELU_ERF, WN, M32, NS, EARLY>), grid, block, smem, st, q, KT); break;
+        case EPI_RESID: hipLaunchKernelGGL((gemm_ringx_kernel<EPI_RESID, WN, M32, NS, EARLY>), grid, block, smem, st, q, KT); break;
+        case EPI_SWIGLU: hipLaunchKernelGGL((gemm_ringx_kernel<EPI_SWIGLU, WN, M32, NS, EARLY>), grid, block, smem, st, q, KT); break;
+        default: hipLaunchKernelGGL((gemm_ringx_kernel<EPI_NONE, WN, M32, NS, EARLY>), grid, block, smem, st, q, KT); break;
     }
     if (splits > 1) {
         long long work = (long long)a.M * ((a.N + 3) / 4);
@@ -1311,13 +1127,32 @@ static hipError_t launch_ringx_t(const GemmP& p, const GemmArgs& a, hipStream_t 
     }
     return hipGetLastError();
 }
-// flags: bit 0 = 4-wave 256x128 blocks (two per CU), bit 1 = 32x32x16 MFMA
+template <int DBG>
+static hipError_t launch_ringx_dbg(const GemmP& p, const GemmArgs& a, hipStream_t st) {
+    const int tiles = cdiv(a.N, 256) * cdiv(a.M, 256);
+    dim3 grid(tiles <= 256 ? tiles : 256, 1, 1);
+    set_plan(a, GEMM_K_RING256, tiles, 1, (int)grid.x);
+    const size_t smem = 3 * (256 * 32 + 256 * 32) * sizeof(bf16_t);
+    hipFuncSetAttribute((const void*)gemm_ringx_kernel<EPI_NONE, 4, false, 3, true, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL((gemm_ringx_kernel<EPI_NONE, 4, false, 3, true, DBG>), grid, dim3(512), smem, st, p, a.K >> 5);
+    return hipGetLastError();
+}
+// flags: bit 0 = 4-wave 256x128 blocks (two per CU), bit 1 = 32x32x16 MFMA, bit 3 = 4-slot ring, bit 4 = refill DMAs in the first rows of a step
 static hipError_t launch_ringx(int flags, const GemmP& p, const GemmArgs& a, hipStream_t st, int splits = 1) {
-    switch (flags & 3) {
-        case 0: return launch_ringx_t<4, false>(p, a, st, splits);
-        case 1: return launch_ringx_t<2, false>(p, a, st, splits);
-        case 2: return launch_ringx_t<4, true>(p, a, st, splits);
-        default: return launch_ringx_t<2, true>(p, a, st, splits);
+    const int f = flags & 27;
+    if ((flags & 32) && f == 1) return launch_ringx_t<2, false, 3, false>(p, a, st, splits, false);
+    if ((flags & 32) && f == 17) return launch_ringx_t<2, false, 3, true>(p, a, st, splits, false);
+    switch (f) {
+        case 0: return launch_ringx_t<4, false, 3, false>(p, a, st, splits);
+        case 1: return launch_ringx_t<2, false, 3, false>(p, a, st, splits);
+        case 2: return launch_ringx_t<4, true, 3, false>(p, a, st, splits);
+        case 3: return launch_ringx_t<2, true, 3, false>(p, a, st, splits);
+        case 8: return launch_ringx_t<4, false, 4, false>(p, a, st, splits);
+        case 16: return launch_ringx_t<4, false, 3, true>(p, a, st, splits);
+        case 17: return launch_ringx_t<2, false, 3, true>(p, a, st, splits);
+        case 24: return launch_ringx_t<4, false, 4, true>(p, a, st, splits);
+        case 26: return launch_ringx_t<4, true, 4, true>(p, a, st, splits);
+        default: return hipErrorInvalidValue;
     }
 }
 
@@ -1352,7 +1187,7 @@ static hipError_t launch_t(const GemmArgs& a, hipStream_t st, int* kind_out) {
             if (!big_packed_ok(MMD_BF16, a, 16) || (a.N % 32) != 0) return hipErrorInvalidValue;
             p.W = a.Wp;
             if (kind_out) *kind_out = MMD_K_GEMM_TILE;
-            return launch_ring256(p, a, st);
+            return launch_ringx(16, p, a, st);
         }
         // long K with under one block wave of 256^2 tiles (down_proj of a chunk): split K across grid.z so ~one block per CU runs a
         // long steady state (1.05 PF at M = 1274 against 0.84 PF for the 128-row kernel's 3-way split); K = 3584 shapes lose to it
@@ -1366,10 +1201,15 @@ static hipError_t launch_t(const GemmArgs& a, hipStream_t st, int* kind_out) {
             if (variant == GEMM_RING256_SPLIT || sp >= 2) {
                 p.W = a.Wp;
                 if (kind_out) *kind_out = MMD_K_GEMM_TILE;
-                return launch_ring256(p, a, st, sp);
+                return launch_ringx(16, p, a, st, sp);
             }
         }
-        if (variant >= GEMM_RINGX && variant < GEMM_RINGX + 8) {          // forced ring variants (A/B and parity of every instantiation)
+        if (variant >= 96 && variant <= 98) {                               // timing experiments (WRONG results): see gemm_ringx_kernel DBG
+            if (!big_packed_ok(MMD_BF16, a, 16) || (a.N % 32) != 0) return hipErrorInvalidValue;
+            p.W = a.Wp;
+            return variant == 96 ? launch_ringx_dbg<1>(p, a, st) : (variant == 97 ? launch_ringx_dbg<2>(p, a, st) : launch_ringx_dbg<3>(p, a, st));
+        }
+        if (variant >= GEMM_RINGX && variant < GEMM_RINGX + 64) {          // forced ring variants (A/B and parity of every instantiation)
             if (!big_packed_ok(MMD_BF16, a, 16) || (a.N % 32) != 0) return hipErrorInvalidValue;
             const int flags = variant - GEMM_RINGX;
             int sp = 1;

@@ -32,7 +32,7 @@ def assert_close(got, ref, dtype, scale=1.0, what=''):
     assert err <= tol * max(1.0, den), f'{what}: max abs err {err:.3e} (ref max {den:.3e}, tol {tol:.1e})'
 
 
-GEMM_SHAPES = [(49, 64, 64), (7, 130, 72), (200, 96, 588), (64, 256, 512), (300, 384, 256), (1, 512, 64), (129, 160, 4352), (392, 512, 1152), (729, 256, 640), (1000, 1152, 1152), (520, 96, 128)]
+GEMM_SHAPES = [(49, 64, 64), (7, 130, 72), (200, 96, 588), (64, 256, 512), (300, 384, 256), (1, 512, 64), (129, 160, 4352), (392, 512, 1152), (729, 256, 640), (1000, 1152, 1152), (520, 96, 128), (200, 64, 64), (130, 128, 192), (257, 160, 320), (300, 96, 448)]
 
 
 def _variant_ok(ops, variant, M, N, K):
@@ -43,7 +43,7 @@ def _variant_ok(ops, variant, M, N, K):
 
 
 @pytest.mark.parametrize('M,N,K', GEMM_SHAPES)
-@pytest.mark.parametrize('variant', [1, 2, 3, 4, 6, 7, 16, 17, 18, 19, 21, 23])
+@pytest.mark.parametrize('variant', [1, 2, 3, 4, 6, 7, 16, 17, 18, 19, 21, 23, 24, 32, 33, 40, 42, 44])
 def test_gemm_bias(ops, M, N, K, variant):
     _variant_ok(ops, variant, M, N, K)
     g = torch.Generator().manual_seed(M * 7 + N)
@@ -54,7 +54,7 @@ def test_gemm_bias(ops, M, N, K, variant):
 
 
 @pytest.mark.parametrize('epi', ['gelu_tanh', 'gelu_erf', 'resid', 'swiglu'])
-@pytest.mark.parametrize('variant', [1, 2, 3, 4, 6, 7, 16, 17, 18, 19, 21, 23])
+@pytest.mark.parametrize('variant', [1, 2, 3, 4, 6, 7, 16, 17, 18, 19, 21, 23, 24, 32, 33, 40, 42, 44])
 def test_gemm_epilogues(ops, epi, variant):
     g = torch.Generator().manual_seed(11)
     M, N, K = (70, 192, 136) if variant not in (4, 6, 7) and variant < 16 else (300, 320, 192)

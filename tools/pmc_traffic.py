@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""profiles/r01_pmc_traffic.json from two tools/pmc_summary.py outputs (FETCH_SIZE pass, WRITE_SIZE pass) of the same workload.
+"""profiles/rNN_pmc_traffic.json from two tools/pmc_summary.py outputs (FETCH_SIZE pass, WRITE_SIZE pass) of the same workload.
 
     python tools/pmc_traffic.py profiles/r01_final_pmc_FETCH_SIZE.txt profiles/r01_final_pmc_WRITE_SIZE.txt > profiles/r01_pmc_traffic.json
 
@@ -9,7 +9,7 @@ A class launch = one main kernel; helper kernels of the class (split-K reduce, a
 import json, re, sys
 
 CLASSES = {     # class -> (main kernel prefixes, helper kernel prefixes)
-    'gemm_tile': (('void gemm_ring256_kernel', 'void gemm_big_kernel', 'void gemm_tile_kernel'), ('void splitk_reduce_kernel',)),
+    'gemm_tile': (('void gemm_ringx_kernel', 'void gemm_ring256_kernel', 'void gemm_big_kernel', 'void gemm_tile_kernel'), ('void splitk_reduce_kernel',)),
     'gemm_skinny': (('void gemm_gemv16_kernel', 'void gemm_skinny_kernel'), ()),
     'attn_llm': (('void attn_gqa128_kernel', 'void attn_mfma_kernel'), ('attn_combine128_kernel', 'attn_combine_kernel')),
     'attn_vit': (('void attn_rowmajor_kernel',), ()),
