@@ -31,6 +31,9 @@ extern "C" {
 #define MMD_EHIP (-5)
 
 typedef enum { MMD_F32 = 0, MMD_BF16 = 1 } mmd_dtype;
+/* storage of the decoder's linear-layer weights (q/k/v/o/gate/up/down): MMD_W_FP8_E4M3 = OCP e4m3fn with one fp32 scale per output
+ * channel (BASELINE configs[4], scripts/inference/youcook2.sh:12-14 workload), activations and accumulation unchanged (bf16 / fp32) */
+typedef enum { MMD_W_DTYPE = 0, MMD_W_FP8_E4M3 = 1 } mmd_weight_dtype;
 /* ADAPTIVE_AVG = adaptive_avg_pool2d to pool_stride x pool_stride tokens (the secondary encoder path, models/vision_live.py:17-24) */
 typedef enum { MMD_POOL_BILINEAR = 0, MMD_POOL_AVERAGE = 1, MMD_POOL_MAX = 2, MMD_POOL_ADAPTIVE_AVG = 3 } mmd_pool_mode;
 
@@ -51,6 +54,7 @@ typedef struct mmd_config {
     /* workspace sizing */
     int32_t max_vit_batch;        /* frames per mmd_vit_encode call (reference: 32, test/inference.py:208) */
     int32_t max_step_tokens;      /* max rows of one mmd_llm_step call */
+    int32_t weight_dtype;         /* mmd_weight_dtype (bf16 contexts only) */
 } mmd_config;
 
 typedef struct mmd_ctx mmd_ctx;
@@ -184,6 +188,12 @@ int mmd_op_gemm(mmd_ctx* ctx, const void* X, const void* W, const void* bias, co
 /* what the dispatcher chose for the most recent GEMM of this context: out4 = {kernel (0 tile64, 1 tile128, 2 skinny, 3 gemv16, 4 big64,
  * 5 big128, 6 ring256), output tiles, K splits, blocks launched} */
 int mmd_op_gemm_last_plan(mmd_ctx* ctx, int* out4);
+/* fp8 weight path, raw form: mmd_op_quantize_fp8 replaces W [N,K] (bf16, row-major, device) by bf16(q), q = rne_e4m3(W / scale[n]),
+ * scale[n] = amax_n / 448, and writes the fp8 bytes q8 [N,K] and scale [N] (fp32).  mmd_op_gemm_w8 = mmd_op_gemm on such a matrix:
+ * Y = epilogue((X . q^T) * scale + bias); M <= 64 streams the fp8 copy, larger M the bf16(q) copy (bit-identical values). */
+int mmd_op_quantize_fp8(mmd_ctx* ctx, void* W, int N, int K, uint8_t* q8_out, float* scale_out);
+int mmd_op_gemm_w8(mmd_ctx* ctx, const void* X, const void* Wq, const uint8_t* q8, const float* scale, const void* bias, const void* R, void* Y,
+                   int M, int N, int K, int epi, int out_f32, int variant);
 /* micro-benchmark of one GEMM shape (HIP events on the context's stream); avg ms per call incl. any split-K reduce.  X [M,K] / W [N,K]
  * (device, ctx dtype) supply the operand VALUES (random data: operand bits set the chip's clock); NULL = a constant fill */
 int mmd_op_gemm_bench(mmd_ctx* ctx, int M, int N, int K, int epi, int variant, int iters, float* avg_ms_out, const void* X, const void* W);

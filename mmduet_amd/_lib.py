@@ -23,7 +23,7 @@ class MmdConfig(C.Structure):
                 ('vit_hidden', C.c_int32), ('vit_intermediate', C.c_int32), ('vit_layers', C.c_int32), ('vit_heads', C.c_int32),
                 ('vit_image', C.c_int32), ('vit_patch', C.c_int32), ('vit_ln_eps', C.c_float), ('vit_post_layernorm', C.c_int32),
                 ('pool_mode', C.c_int32), ('pool_stride', C.c_int32), ('frame_num_tokens', C.c_int32),
-                ('max_vit_batch', C.c_int32), ('max_step_tokens', C.c_int32)]
+                ('max_vit_batch', C.c_int32), ('max_step_tokens', C.c_int32), ('weight_dtype', C.c_int32)]
 
 
 class MmduetError(RuntimeError):
@@ -78,6 +78,8 @@ _SIGS = {
     'mmd_op_gemm': (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _I]),
     'mmd_op_gemm_bench': (_I, [_VP, _I, _I, _I, _I, _I, _I, C.POINTER(_F), _VP, _VP]),
     'mmd_op_gemm_last_plan': (_I, [_VP, C.POINTER(_I)]),
+    'mmd_op_quantize_fp8': (_I, [_VP, _VP, _I, _I, _VP, _VP]),
+    'mmd_op_gemm_w8': (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _I]),
     'mmd_op_rmsnorm': (_I, [_VP, _VP, _VP, _VP, _I, _I, _F]),
     'mmd_op_layernorm': (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _F]),
     'mmd_op_rope_append': (_I, [_VP, _VP, _I, _I, _I, _I, _F, _I64, _VP, _VP, _VP, _I64]),

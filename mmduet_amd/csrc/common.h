@@ -14,6 +14,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(2))) short s16x2_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 
 #define WAVE 64
 
@@ -88,6 +89,9 @@ struct GemmArgs {
     const void* X; int64_t ldx;      // [M,K]
     const void* W; int64_t ldw;      // [N,K]  (nn.Linear layout); may be null when only Wp exists
     const void* Wp = nullptr;        // same matrix, MFMA-fragment-major (launch_pack_w); enables the weight-streaming skinny kernel
+    const void* Wp8 = nullptr;       // fp8 e4m3 copy of the (unscaled) weights, fragment-major in 64-k pairs (launch_pack_w8): the weight-streaming
+                                     // kernels (M <= 64) read this one -- half the bytes; W / Wp then hold bf16(q), bit-identical values
+    const float* wscale = nullptr;   // per-output-channel scale of a quantised matrix: Y = (X . q^T) * wscale[n] (+ bias ...)
     const void* bias;                // [N] or null (ctx dtype)
     const void* R; int64_t ldr;      // residual [M,N] (EPI_RESID)
     void* Y; int64_t ldy;            // [M,N] (or [M,N/2] for SWIGLU); ctx dtype, or fp32 if out_f32
@@ -107,6 +111,10 @@ bool gemm_can_slab(int dtype, const GemmArgs& a);
 // launchers (dtype = mmd_dtype).  All return hipError_t of the launch.
 hipError_t launch_gemm(int dtype, const GemmArgs& a, hipStream_t st, int* kind_out);
 hipError_t launch_pack_w(const void* W, int64_t ldw, int N, int K, void* out, hipStream_t st);   // bf16 only, N%16==0, K%32==0
+// fp8 e4m3 (OCP) weights, one scale per output channel: W [N,K] bf16 row-major is REPLACED by bf16(q) (q = rne_fp8(W / scale), scale = amax / 448),
+// q8_rowmajor [N,K] bytes and scale [N] fp32 are written;  launch_pack_w8 lays q8 out fragment-major for the streaming kernels (N%16==0, K%64==0)
+hipError_t launch_quantize_fp8_rows(void* W_bf16, int N, int K, uint8_t* q8_rowmajor, float* scale, hipStream_t st);
+hipError_t launch_pack_w8(const uint8_t* q8_rowmajor, int N, int K, void* out, hipStream_t st);
 hipError_t launch_rmsnorm(int dtype, const void* x, const void* w, void* y, int M, int H, float eps, hipStream_t st);
 hipError_t launch_layernorm(int dtype, const void* x, const void* w, const void* b, void* y, int M, int H, float eps, hipStream_t st);
 // fused consumers of skinny-GEMM slabs (ops.hip)

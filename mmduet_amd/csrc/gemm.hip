@@ -17,6 +17,7 @@
 
 struct GemmP {
     const void* X; const void* W; const void* bias; const void* R; void* Y; float* ws;
+    const float* wscale;   // per-output-channel weight scale (fp8-quantised matrices) or null
     long long ldx, ldw, ldr, ldy;
     int M, N, K, epi, out_f32, kper, vec;
     int slabs;         // skinny kernel: always leave fp32 slabs in ws (the consumer kernel reduces them)
@@ -74,6 +75,7 @@ __device__ __forceinline__ void store4(const GemmP& p, int m, int n, const float
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         float x = v[r];
+        if (n + r < p.N && p.wscale) x *= p.wscale[n + r];
         if (n + r < p.N && p.bias) x += to_f<T>(((const T*)p.bias)[n + r]);
         if (p.epi == EPI_GELU_TANH) x = gelu_tanh_t<T>(rnd<T>(x));
         else if (p.epi == EPI_GELU_ERF) x = gelu_erf_t<T>(rnd<T>(x));
@@ -109,7 +111,9 @@ __device__ __forceinline__ void store4_swiglu(const GemmP& p, int m, int n_gate,
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         if (oc + r < NO) {
-            float gg = rnd<T>(g[r]), uu = rnd<T>(u[r]);
+            float gs = g[r], us = u[r];
+            if (p.wscale) { gs *= p.wscale[n_gate + r]; us *= p.wscale[n_gate + 16 + r]; }
+            float gg = rnd<T>(gs), uu = rnd<T>(us);
             float s = rnd<T>(silu_t<T>(gg));
             y[r] = from_f<T>(s * uu);
         }
@@ -264,9 +268,71 @@ hipError_t launch_pack_w(const void* W, int64_t ldw, int N, int K, void* out, hi
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// fp8 e4m3 (OCP e4m3fn) weight path (BASELINE configs[4]: "fp8 MFMA weights"; SURVEY.md section 8d row 5: per-channel-scaled
+// weights, bf16 activations, fp32 accumulate).  gfx950's plain fp8 MFMA runs at the bf16 rate and would need fp8 ACTIVATIONS, so the
+// gain is bytes, not FLOPs: the weight-streaming kernels (M <= 64: decode GEMV, per-frame steps) read the 1-byte copy and widen it to
+// bf16 in registers (v_cvt_scalef32_pk_bf16_fp8, exact), the MFMA-bound tile kernels keep reading a bf16 copy of the SAME values q.
+// Every regime computes (sum_k x_k q_nk) * scale_n with exact products and fp32 accumulation, so the chunked and the per-frame schedule
+// still agree up to accumulation order.  scale_n = amax_n / 448, q = round-to-nearest-even(W / scale_n) (v_cvt_pk_fp8_f32).
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void quantize_fp8_rows_kernel(bf16_t* __restrict__ W, int K, uint8_t* __restrict__ q8, float* __restrict__ scale) {
+    __shared__ float red[4];
+    const long long row = blockIdx.x;
+    bf16_t* w = W + row * K;
+    float amax = 0.f;
+    for (int k = threadIdx.x; k < K; k += 256) amax = fmaxf(amax, fabsf(bf2f(w[k])));
+    amax = wave_max(amax);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
+    __syncthreads();
+    amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float sc = amax > 0.f ? amax / 448.0f : 1.0f;
+    if (threadIdx.x == 0) scale[row] = sc;
+    for (int k = threadIdx.x * 2; k < K; k += 512) {                // K is even
+        const float a = bf2f(w[k]) / sc, b = bf2f(w[k + 1]) / sc;   // true division: the host reference does W / scale
+        const int pk = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+        q8[row * K + k] = (uint8_t)(pk & 0xff); q8[row * K + k + 1] = (uint8_t)((pk >> 8) & 0xff);
+        const auto back = __builtin_amdgcn_cvt_pk_f32_fp8(pk, false);
+        w[k] = f2bf(back[0]); w[k + 1] = f2bf(back[1]);             // e4m3 has 3 mantissa bits: exact in bf16
+    }
+}
+hipError_t launch_quantize_fp8_rows(void* W, int N, int K, uint8_t* q8, float* scale, hipStream_t st) {
+    if (N <= 0 || (K & 1)) return N <= 0 ? hipSuccess : hipErrorInvalidValue;
+    hipLaunchKernelGGL(quantize_fp8_rows_kernel, dim3(N), dim3(256), 0, st, (bf16_t*)W, K, q8, scale);
+    return hipGetLastError();
+}
+// fragment-major fp8 layout: block (nt, kp) = 16 rows x 64 k = 1 KiB; lane l's 16 bytes = row (l & 15), k = kp*64 + (l >> 4)*8 + {0..7} (the
+// A operand of k-step 2kp) followed by k = kp*64 + 32 + (l >> 4)*8 + {0..7} (k-step 2kp + 1): one coalesced 1 KiB load feeds two MFMAs
+__global__ void pack_w8_kernel(const uint8_t* __restrict__ q8, int N, int K, uint8_t* __restrict__ out) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int KP = K >> 6;
+    const long long pieces = (long long)(N >> 4) * KP * 64;
+    if (i >= pieces) return;
+    const int lane = (int)(i & 63);
+    const long long blk = i >> 6;
+    const int kp = (int)(blk % KP);
+    const long long nt = blk / KP;
+    const uint8_t* src = q8 + (nt * 16 + (lane & 15)) * (long long)K + kp * 64 + (lane >> 4) * 8;
+    uint2 lo = *reinterpret_cast<const uint2*>(src), hi = *reinterpret_cast<const uint2*>(src + 32);
+    *reinterpret_cast<uint4*>(out + i * 16) = uint4{lo.x, lo.y, hi.x, hi.y};
+}
+hipError_t launch_pack_w8(const uint8_t* q8, int N, int K, void* out, hipStream_t st) {
+    const long long pieces = (long long)(N >> 4) * (K >> 6) * 64;
+    if (pieces <= 0) return hipSuccess;
+    hipLaunchKernelGGL(pack_w8_kernel, dim3(cdiv(pieces, 256)), dim3(256), 0, st, q8, N, K, (uint8_t*)out);
+    return hipGetLastError();
+}
+// 8 fp8 (two dwords) -> 8 bf16, exact
+__device__ __forceinline__ bf16x8_t fp8x8_to_bf16(unsigned lo, unsigned hi) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 b2;
+    const b2 a = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8((int)lo, 1.0f, false), b = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8((int)lo, 1.0f, true);
+    const b2 c = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8((int)hi, 1.0f, false), d = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8((int)hi, 1.0f, true);
+    return bf16x8_t{a[0], a[1], b[0], b[1], c[0], c[1], d[0], d[1]};
+}
+
 __device__ __forceinline__ int xs_slot(int ktl, int kq, int r) { return kq * 16 + (r ^ (kq + 4 * (ktl & 1))); }
 
-template <int MT, int NT>
+template <int MT, int NT, bool W8 = false>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmP p, int KT, int kt_per_split) {
     constexpr int KS = 4;                                   // k-tiles (of 32) per pipeline step
     __shared__ __attribute__((aligned(16))) bf16_t Xs[2][MT * KS * 64 * 8];
@@ -289,6 +355,20 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmP p, int KT, int k
     s16x8_t xr[MT];
 
     auto load_w = [&](bf16x8_t (&w)[NT][KS], int kt) {
+        if constexpr (W8) {
+            // fp8 copy: one 16-byte piece per lane = the operands of two k-steps (kt is a multiple of 4 here, K % 64 == 0)
+            const uint8_t* W8p = (const uint8_t*)p.W;
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int s = 0; s < KS; s += 2) {
+                    u32x4_t v = {0, 0, 0, 0};
+                    if (nt0 + j < ntiles && kt + s < kt_end)
+                        v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(W8p + (((long long)(nt0 + j) * (KT >> 1) + ((kt + s) >> 1)) * 64 + lane) * 16));
+                    w[j][s] = fp8x8_to_bf16(v[0], v[1]); w[j][s + 1] = fp8x8_to_bf16(v[2], v[3]);
+                }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -352,7 +432,11 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmP p, int KT, int k
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 int m = i * 16 + lr, n = (nt0 + j) * 16 + lq * 4;
-                if (m < p.M && nt0 + j < ntiles) *reinterpret_cast<f32x4_t*>(ws + (long long)m * p.N + n) = acc[i][j];
+                if (m < p.M && nt0 + j < ntiles) {
+                    f32x4_t v = acc[i][j];
+                    if (p.slabs && p.wscale) v *= *reinterpret_cast<const f32x4_t*>(p.wscale + n);      // the fused slab consumers know no scale (split-K reduce applies it itself)
+                    *reinterpret_cast<f32x4_t*>(ws + (long long)m * p.N + n) = v;
+                }
             }
         return;
     }
@@ -391,7 +475,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmP p, int KT, int k
 // operands directly.  The four partial accumulators meet in LDS once; wave 0 applies the epilogue (or leaves ONE fp32
 // slab for the fused consumer): no split-K slabs, no reduce launch.
 // ------------------------------------------------------------------------------------------------------------------
-template <int NT, int U>
+template <int NT, int U, bool W8 = false>
 __global__ __launch_bounds__(256) void gemm_gemv16_kernel(GemmP p, int KT) {
     __shared__ __attribute__((aligned(16))) float red[3][NT][64][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -410,6 +494,41 @@ __global__ __launch_bounds__(256) void gemm_gemv16_kernel(GemmP p, int KT) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[j] = f32x4_t{0, 0, 0, 0};
 
+    if constexpr (W8) {
+        // fp8 weights: K ranges are in 64-k pairs; a 1 KiB load feeds two MFMAs; U/2 loads per n-tile in flight
+        const uint8_t* W8p = (const uint8_t*)p.W;
+        const int KP = KT >> 1;
+        const int kpb = (KP + gridDim.y - 1) / gridDim.y;
+        const int pb_beg = blockIdx.y * kpb, pb_end = min(KP, pb_beg + kpb);
+        const int kpw = (pb_end - pb_beg + 3) >> 2;
+        const int kp_beg = pb_beg + wave * kpw, kp_end = min(pb_end, kp_beg + kpw);
+        constexpr int UP = U / 2;
+        for (int kp0 = kp_beg; kp0 < kp_end; kp0 += UP) {
+            u32x4_t wv[NT][UP]; bf16x8_t x[UP][2];
+#pragma unroll
+            for (int u = 0; u < UP; ++u) {
+                const int kp = kp0 + u;
+                s16x8_t x0 = {0, 0, 0, 0, 0, 0, 0, 0}, x1 = x0;
+                if (kp < kp_end) {
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        wv[j][u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(W8p + (((long long)(nt0 + j) * KP + kp) * 64 + lane) * 16));
+                    if (row_ok) { x0 = *reinterpret_cast<const s16x8_t*>(xrow + kp * 64); x1 = *reinterpret_cast<const s16x8_t*>(xrow + kp * 64 + 32); }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) wv[j][u] = u32x4_t{0, 0, 0, 0};
+                }
+                x[u][0] = __builtin_bit_cast(bf16x8_t, x0); x[u][1] = __builtin_bit_cast(bf16x8_t, x1);
+            }
+#pragma unroll
+            for (int u = 0; u < UP; ++u)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fp8x8_to_bf16(wv[j][u][0], wv[j][u][1]), x[u][0], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fp8x8_to_bf16(wv[j][u][2], wv[j][u][3]), x[u][1], acc[j], 0, 0, 0);
+                }
+        }
+    } else
     for (int kt0 = kt_beg; kt0 < kt_end; kt0 += U) {
         bf16x8_t w[NT][U], x[U];
 #pragma unroll
@@ -447,7 +566,11 @@ __global__ __launch_bounds__(256) void gemm_gemv16_kernel(GemmP p, int KT) {
     if (p.slabs) {
         float* ws = p.ws + (long long)blockIdx.y * p.M * p.N;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) *reinterpret_cast<f32x4_t*>(ws + (long long)m * p.N + (nt0 + j) * 16 + lq * 4) = acc[j];
+        for (int j = 0; j < NT; ++j) {
+            f32x4_t v = acc[j];
+            if (p.wscale) v *= *reinterpret_cast<const f32x4_t*>(p.wscale + (nt0 + j) * 16 + lq * 4);       // slabs feed the fused consumers, which know no scale
+            *reinterpret_cast<f32x4_t*>(ws + (long long)m * p.N + (nt0 + j) * 16 + lq * 4) = v;
+        }
         return;
     }
     if (p.epi == EPI_SWIGLU) {
@@ -481,7 +604,14 @@ static void launch_gemv16(const GemmP& p, const GemmArgs& a, hipStream_t st) {
     }
     if (a.slabs_out) *a.slabs_out = ksplit;
     set_plan(a, GEMM_K_GEMV16, ntiles, ksplit, (a.epi == EPI_SWIGLU || (ntiles % 2 == 0 && ntiles >= 2048) ? ntiles / 2 : ntiles) * ksplit);
-    if (a.epi == EPI_SWIGLU || (ntiles % 2 == 0 && ntiles >= 2048)) hipLaunchKernelGGL((gemm_gemv16_kernel<2, 8>), dim3(ntiles / 2, ksplit), dim3(256), 0, st, p, KT);
+    const bool two = a.epi == EPI_SWIGLU || (ntiles % 2 == 0 && ntiles >= 2048);
+    if (a.Wp8) {
+        GemmP q = p; q.W = a.Wp8;
+        if (two) hipLaunchKernelGGL((gemm_gemv16_kernel<2, 8, true>), dim3(ntiles / 2, ksplit), dim3(256), 0, st, q, KT);
+        else hipLaunchKernelGGL((gemm_gemv16_kernel<1, 8, true>), dim3(ntiles, ksplit), dim3(256), 0, st, q, KT);
+        return;
+    }
+    if (two) hipLaunchKernelGGL((gemm_gemv16_kernel<2, 8>), dim3(ntiles / 2, ksplit), dim3(256), 0, st, p, KT);
     else hipLaunchKernelGGL((gemm_gemv16_kernel<1, 8>), dim3(ntiles, ksplit), dim3(256), 0, st, p, KT);
 }
 
@@ -502,7 +632,11 @@ static void launch_skinny_mt(const GemmP& p, const GemmArgs& a, hipStream_t st) 
     splits = cdiv(KT, ktper);
     dim3 grid(nblocks, splits);
     set_plan(a, GEMM_K_SKINNY, ntiles, splits, nblocks * splits);
-    if (NT == 2) hipLaunchKernelGGL((gemm_skinny_kernel<MT, 2>), grid, dim3(256), 0, st, p, KT, ktper);
+    if (a.Wp8) {
+        GemmP q = p; q.W = a.Wp8;
+        if (NT == 2) hipLaunchKernelGGL((gemm_skinny_kernel<MT, 2, true>), grid, dim3(256), 0, st, q, KT, ktper);
+        else hipLaunchKernelGGL((gemm_skinny_kernel<MT, 1, true>), grid, dim3(256), 0, st, q, KT, ktper);
+    } else if (NT == 2) hipLaunchKernelGGL((gemm_skinny_kernel<MT, 2>), grid, dim3(256), 0, st, p, KT, ktper);
     else hipLaunchKernelGGL((gemm_skinny_kernel<MT, 1>), grid, dim3(256), 0, st, p, KT, ktper);
     if (a.slabs_out) { *a.slabs_out = splits; return; }
     if (splits > 1) {
@@ -527,6 +661,11 @@ static void launch_skinny_mt(const GemmP& p, const GemmArgs& a, hipStream_t st) 
 template <int EPI>
 __device__ __forceinline__ s16x4_t big_value(const GemmP& p, int m, int n, const f32x4_t& a) {      // m < p.M
     float v[4] = {a[0], a[1], a[2], a[3]};
+    if (p.wscale) {
+        const f32x4_t sc = *reinterpret_cast<const f32x4_t*>(p.wscale + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= sc[r];
+    }
     if (p.bias) {
         s16x4_t b = *reinterpret_cast<const s16x4_t*>((const bf16_t*)p.bias + n);
 #pragma unroll
@@ -550,7 +689,10 @@ __device__ __forceinline__ void big_store(const GemmP& p, int m, int n, const f3
     if (m >= p.M) return;
     *reinterpret_cast<s16x4_t*>((bf16_t*)p.Y + (long long)m * p.ldy + n) = big_value<EPI>(p, m, n, a);
 }
-__device__ __forceinline__ s16x4_t big_value_swiglu(const f32x4_t& g, const f32x4_t& u) {
+// n_gate = weight row of the gate quad (its up partner sits 16 rows further); ws = per-row weight scales or null
+__device__ __forceinline__ s16x4_t big_value_swiglu(const f32x4_t& g_in, const f32x4_t& u_in, const float* ws = nullptr, int n_gate = 0) {
+    f32x4_t g = g_in, u = u_in;
+    if (ws) { g *= *reinterpret_cast<const f32x4_t*>(ws + n_gate); u *= *reinterpret_cast<const f32x4_t*>(ws + n_gate + 16); }
     s16x4_t o;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -573,7 +715,7 @@ __device__ __forceinline__ s16x8_t pair_to_row8(const s16x4_t& ta, const s16x4_t
 __device__ __forceinline__ void big_store_swiglu(const GemmP& p, int m, int n_gate, const f32x4_t& g, const f32x4_t& u) {
     if (m >= p.M) return;
     const int oc = (n_gate >> 5) * 16 + (n_gate & 15);
-    *reinterpret_cast<s16x4_t*>((bf16_t*)p.Y + (long long)m * p.ldy + oc) = big_value_swiglu(g, u);
+    *reinterpret_cast<s16x4_t*>((bf16_t*)p.Y + (long long)m * p.ldy + oc) = big_value_swiglu(g, u, p.wscale, n_gate);
 }
 
 template <int BN, int EPI>
@@ -682,7 +824,7 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(GemmP p, int KT) {
         if constexpr (EPI == EPI_SWIGLU) {
             if constexpr (TN == 4) {                                                // two output tiles: row-contiguous 16-byte stores (pair_to_row8)
                 const int nb = n0 + wn, ob = (nb >> 5) * 16;
-                const s16x8_t v = pair_to_row8(big_value_swiglu(acc[i][0], acc[i][1]), big_value_swiglu(acc[i][2], acc[i][3]));
+                const s16x8_t v = pair_to_row8(big_value_swiglu(acc[i][0], acc[i][1], p.wscale, nb + lq * 4), big_value_swiglu(acc[i][2], acc[i][3], p.wscale, nb + 32 + lq * 4));
                 if (m < p.M) *reinterpret_cast<s16x8_t*>((bf16_t*)p.Y + (long long)m * p.ldy + ob + (lq & 1) * 16 + (lq >> 1) * 8) = v;
             } else {
 #pragma unroll
@@ -939,7 +1081,8 @@ __global__ __launch_bounds__(WN * 128, 2) void gemm_ringx_kernel(GemmP p, int KT
                 if constexpr (EPI == EPI_SWIGLU) {
                     const int nb = en0 + wc * 64;
                     const int ob = (nb >> 5) * 16;
-                    const s16x8_t v = pair_to_row8(big_value_swiglu(acc[i][0], acc[i][1]), big_value_swiglu(acc[i][2], acc[i][3]));
+                    const int ns0 = min(nb, p.N - 32) + lq * 4, ns1 = min(nb + 32, p.N - 32) + lq * 4;      // N tail: clamp the scale reads
+                    const s16x8_t v = pair_to_row8(big_value_swiglu(acc[i][0], acc[i][1], p.wscale, ns0), big_value_swiglu(acc[i][2], acc[i][3], p.wscale, ns1));
                     if (m < p.M && nb + 32 * (lq & 1) + 32 <= p.N) *reinterpret_cast<s16x8_t*>((bf16_t*)p.Y + (long long)m * p.ldy + ob + (lq & 1) * 16 + (lq >> 1) * 8) = v;
                 } else {
 #pragma unroll
@@ -1069,8 +1212,8 @@ __global__ __launch_bounds__(WN * 128, 2) void gemm_ringx_kernel(GemmP p, int KT
                     const int nbc = nb + 32 <= p.N ? nb : p.N - 32;            // N tail: clamp the reads, mask the stores
                     if constexpr (EPI == EPI_SWIGLU) {
                         // rows 0..15 of the n-tile are gate, 16..31 up, of output columns (nb >> 5) * 16 ..+15
-                        const s16x8_t v = halves_to_row8(big_value_swiglu(quad_of(acc[i][j], 0), quad_of(acc[i][j], 2)),
-                                                         big_value_swiglu(quad_of(acc[i][j], 1), quad_of(acc[i][j], 3)));
+                        const s16x8_t v = halves_to_row8(big_value_swiglu(quad_of(acc[i][j], 0), quad_of(acc[i][j], 2), p.wscale, nbc + 4 * lh),
+                                                         big_value_swiglu(quad_of(acc[i][j], 1), quad_of(acc[i][j], 3), p.wscale, nbc + 8 + 4 * lh));
                         if (m < p.M && nb + 32 <= p.N) *reinterpret_cast<s16x8_t*>((bf16_t*)p.Y + (long long)m * p.ldy + (nb >> 5) * 16 + lh * 8) = v;
                     } else {
 #pragma unroll
@@ -1171,7 +1314,7 @@ static bool skinny_packed_ok(int dtype, const GemmArgs& a) {
 template <typename T>
 static hipError_t launch_t(const GemmArgs& a, hipStream_t st, int* kind_out) {
     GemmP p;
-    p.X = a.X; p.W = a.W; p.bias = a.bias; p.R = a.R; p.Y = a.Y; p.ws = a.splitk_ws;
+    p.X = a.X; p.W = a.W; p.bias = a.bias; p.R = a.R; p.Y = a.Y; p.ws = a.splitk_ws; p.wscale = a.wscale;
     p.ldx = a.ldx; p.ldw = a.ldw; p.ldr = a.ldr; p.ldy = a.ldy;
     p.M = a.M; p.N = a.N; p.K = a.K; p.epi = a.epi; p.out_f32 = a.out_f32; p.slabs = a.slabs_out ? 1 : 0;
     p.vec = (sizeof(T) == 2 && (a.ldx % 8) == 0 && (a.ldw % 8) == 0 && ((uintptr_t)a.X % 16) == 0 && ((uintptr_t)a.W % 16) == 0) ? 1 : 0;

@@ -33,7 +33,9 @@ struct Prof {
 };
 
 struct LlmLayer { void *ln1 = 0, *ln2 = 0, *wqkv = 0, *bqkv = 0, *wo = 0, *wgu = 0, *wdown = 0;
-                  void *wqkv_p = 0, *wo_p = 0, *wgu_p = 0, *wdown_p = 0; };   // *_p: MFMA-fragment-major copies (skinny GEMM)
+                  void *wqkv_p = 0, *wo_p = 0, *wgu_p = 0, *wdown_p = 0;       // *_p: MFMA-fragment-major copies (skinny GEMM)
+                  void *wqkv_8 = 0, *wo_8 = 0, *wgu_8 = 0, *wdown_8 = 0;       // fp8 e4m3 fragment-major copies (weight_dtype = fp8: the streaming kernels read these)
+                  float *sqkv = 0, *so = 0, *sgu = 0, *sdown = 0; };          // per-output-channel scales of the quantised matrices
 struct VitLayer { void *ln1w = 0, *ln1b = 0, *wqkv = 0, *bqkv = 0, *wo = 0, *bo = 0, *ln2w = 0, *ln2b = 0, *w1 = 0, *b1 = 0, *w2 = 0, *b2 = 0;
                   void *wqkv_p = 0, *wo_p = 0, *w1_p = 0, *w2_p = 0; };
 
@@ -140,15 +142,16 @@ static void prof_drain(mmd_ctx* c) {
 
 // ---- GEMM wrapper --------------------------------------------------------------------------------------------------
 static int gemm(mmd_ctx* c, const void* X, int64_t ldx, const void* W, int64_t ldw, const void* bias, const void* R, int64_t ldr, void* Y,
-                int64_t ldy, int M, int N, int K, int epi, int out_f32 = 0, int variant = GEMM_AUTO, const void* Wp = nullptr, bool tower = false) {
+                int64_t ldy, int M, int N, int K, int epi, int out_f32 = 0, int variant = GEMM_AUTO, const void* Wp = nullptr, bool tower = false,
+                const void* Wp8 = nullptr, const float* wscale = nullptr) {
     GemmArgs a;
     a.X = X; a.ldx = ldx; a.W = W; a.ldw = ldw; a.Wp = Wp; a.bias = bias; a.R = R; a.ldr = ldr; a.Y = Y; a.ldy = ldy;
-    a.M = M; a.N = N; a.K = K; a.epi = epi; a.out_f32 = out_f32; a.variant = variant;
+    a.M = M; a.N = N; a.K = K; a.epi = epi; a.out_f32 = out_f32; a.variant = variant; a.Wp8 = Wp8; a.wscale = wscale;
     a.splitk_ws = tower ? c->v_splitk_ws : c->splitk_ws; a.splitk_ws_bytes = tower ? c->v_splitk_bytes : c->splitk_bytes;
     a.plan_out = c->last_plan;
     int kind = (variant == GEMM_SKINNY || (variant != GEMM_BIG && variant != GEMM_RING256 && variant != GEMM_RING256_SPLIT && variant < GEMM_RINGX && variant != GEMM_LARGE && variant != GEMM_GENERIC && M <= 64)) ? MMD_K_GEMM_SKINNY : MMD_K_GEMM_TILE;
     double e = (double)es(c);
-    double bytes = ((double)M * K + (double)N * K) * e + (double)M * (epi == EPI_SWIGLU ? N / 2 : N) * (out_f32 ? 4.0 : e);
+    double bytes = (double)M * K * e + (double)N * K * ((Wp8 && M <= 64) ? 1.0 : e) + (double)M * (epi == EPI_SWIGLU ? N / 2 : N) * (out_f32 ? 4.0 : e);
     ProfScope ps(c, kind, bytes, 2.0 * M * N * K);
     HIPCHK(c, launch_gemm(c->cfg.dtype, a, c->stream, nullptr));
     return MMD_OK;
@@ -159,6 +162,7 @@ extern "C" int mmd_create(const mmd_config* cfg, int device, mmd_ctx** out) {
     if (!cfg || !out) { g_create_error = "null argument"; return MMD_EINVAL; }
     if (cfg->struct_size != (int32_t)sizeof(mmd_config)) { g_create_error = "mmd_config size mismatch (ABI)"; return MMD_EINVAL; }
     if (cfg->dtype != MMD_F32 && cfg->dtype != MMD_BF16) { g_create_error = "unsupported dtype"; return MMD_EINVAL; }
+    if (cfg->weight_dtype != MMD_W_DTYPE && (cfg->weight_dtype != MMD_W_FP8_E4M3 || cfg->dtype != MMD_BF16)) { g_create_error = "weight_dtype fp8_e4m3 needs a bf16 context"; return MMD_EINVAL; }
     if (cfg->num_heads % cfg->num_kv_heads != 0 || cfg->head_dim % 2 != 0 || cfg->head_dim > 128) { g_create_error = "unsupported head configuration"; return MMD_EINVAL; }
     if (cfg->vit_hidden % cfg->vit_heads != 0 || cfg->vit_hidden / cfg->vit_heads > 128) { g_create_error = "unsupported ViT head configuration"; return MMD_EINVAL; }
     hipError_t e = hipSetDevice(device);
@@ -308,6 +312,22 @@ static int pack_and_release(mmd_ctx* c, void** W, int N, int K, void** out) {
     return MMD_OK;
 }
 
+// fp8 e4m3 copy of a row-major bf16 matrix (W is replaced by bf16(q)); out8 = fragment-major bytes for the streaming kernels, scale = [N] fp32
+static int quantize_fp8(mmd_ctx* c, void* W, int N, int K, void** out8, float** scale) {
+    *out8 = nullptr; *scale = nullptr;
+    if ((N % 16) != 0 || (K % 64) != 0) FAIL(c, MMD_EINVAL, "fp8 weights need N %% 16 == 0 and K %% 64 == 0 (got %d x %d)", N, K);
+    uint8_t* q8 = nullptr;
+    HIPCHK(c, hipMalloc((void**)&q8, (size_t)N * K));
+    int rc = dev_alloc(c, (void**)scale, (size_t)N * sizeof(float), false); if (rc) { hipFree(q8); return rc; }
+    rc = dev_alloc(c, out8, (size_t)N * K, false); if (rc) { hipFree(q8); return rc; }
+    hipError_t e = launch_quantize_fp8_rows(W, N, K, q8, *scale, c->stream);
+    if (e == hipSuccess) e = launch_pack_w8(q8, N, K, *out8, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(q8);
+    HIPCHK(c, e);
+    return MMD_OK;
+}
+
 extern "C" int mmd_finalize_weights(mmd_ctx* c) {
     if (!c) return MMD_EINVAL;
     if (c->finalized) return MMD_OK;
@@ -350,6 +370,10 @@ extern "C" int mmd_finalize_weights(mmd_ctx* c) {
         HIPCHK(c, launch_interleave16(dt, wg.p, wu.p, L.wgu, I, H, st));
         if (Ipad != I) FAIL(c, MMD_EINVAL, "intermediate_size must be a multiple of 16 (got %d)", I);
         { TAKE(t, p + "mlp.down_proj.weight", {H, I}); L.wdown = t.p; }
+        if (g.weight_dtype == MMD_W_FP8_E4M3) {      // quantise the fused matrices (one scale per output channel), then pack both copies
+            if ((rc = quantize_fp8(c, L.wqkv, c->qkv_w, H, &L.wqkv_8, &L.sqkv)) || (rc = quantize_fp8(c, L.wo, H, nh * d, &L.wo_8, &L.so)) ||
+                (rc = quantize_fp8(c, L.wgu, 2 * I, H, &L.wgu_8, &L.sgu)) || (rc = quantize_fp8(c, L.wdown, H, I, &L.wdown_8, &L.sdown))) return rc;
+        }
         rc = pack_and_release(c, &L.wqkv, c->qkv_w, H, &L.wqkv_p); if (rc) return rc;
         rc = pack_and_release(c, &L.wo, H, nh * d, &L.wo_p); if (rc) return rc;
         rc = pack_and_release(c, &L.wgu, 2 * I, H, &L.wgu_p); if (rc) return rc;
@@ -421,6 +445,7 @@ extern "C" int mmd_finalize_weights(mmd_ctx* c) {
     size_t wb = 0; { size_t fr = 0, tot = 0; (void)fr; (void)tot; }
     wb = ((size_t)2 * V * H + (size_t)g.num_layers * ((size_t)c->qkv_w * H + (size_t)H * nh * d + (size_t)3 * I * H) +
           (size_t)g.vit_layers * ((size_t)4 * C * C + (size_t)2 * c->vit_ipad * C) + (size_t)C * c->vit_kpad + (size_t)H * C + (size_t)H * H) * e;
+    if (g.weight_dtype == MMD_W_FP8_E4M3) wb += (size_t)g.num_layers * ((size_t)c->qkv_w * H + (size_t)H * nh * d + (size_t)3 * I * H);     // the 1-byte copies
     c->weight_bytes = (int64_t)wb;
     int rc = alloc_workspaces(c);
     if (rc) return rc;
@@ -755,11 +780,11 @@ static int llm_step_segs(mmd_ctx* c, const StepSeg* segs, int nseg, const void* 
         GemmArgs p3 = probe; p3.Wp = c->L[0].wo_p; p3.N = H; p3.K = nh * d; p3.ldx = nh * d; p3.X = c->l_attn;
         fused = gemm_can_slab(dt, probe) && gemm_can_slab(dt, p2) && gemm_can_slab(dt, p3);
     }
-    auto slab_gemm = [&](const void* X, int64_t ldx, const void* Wp, int N, int K, int* splits) -> int {
+    auto slab_gemm = [&](const void* X, int64_t ldx, const void* Wp, int N, int K, int* splits, const void* Wp8, const float* wscale) -> int {
         GemmArgs a; memset(&a, 0, sizeof(a));
-        a.X = X; a.ldx = ldx; a.Wp = Wp; a.M = S; a.N = N; a.K = K; a.epi = EPI_NONE; a.variant = GEMM_SKINNY;
+        a.X = X; a.ldx = ldx; a.Wp = Wp; a.Wp8 = Wp8; a.wscale = wscale; a.M = S; a.N = N; a.K = K; a.epi = EPI_NONE; a.variant = GEMM_SKINNY;
         a.splitk_ws = c->splitk_ws; a.splitk_ws_bytes = c->splitk_bytes; a.slabs_out = splits;
-        ProfScope ps(c, MMD_K_GEMM_SKINNY, ((double)S * K + (double)N * K) * e + (double)S * N * e, 2.0 * S * N * K);
+        ProfScope ps(c, MMD_K_GEMM_SKINNY, (double)S * K * e + (double)N * K * (Wp8 ? 1.0 : e) + (double)S * N * e, 2.0 * S * N * K);
         HIPCHK(c, launch_gemm(dt, a, st, nullptr));
         return MMD_OK;
     };
@@ -772,12 +797,12 @@ static int llm_step_segs(mmd_ctx* c, const StepSeg* segs, int nseg, const void* 
         void* Vl = (char*)s->V + (size_t)i * layer_elems * e;
         int splits = 1;
         if (fused) {
-            rc = slab_gemm(c->l_xn, H, L.wqkv_p, c->qkv_w, H, &splits); if (rc) return rc;
+            rc = slab_gemm(c->l_xn, H, L.wqkv_p, c->qkv_w, H, &splits, L.wqkv_8, L.sqkv); if (rc) return rc;
             ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * S * c->qkv_w * e, 0);
             HIPCHK(c, launch_slab_rope_append(c->splitk_ws, splits, L.bqkv, S, nh, nkv, d, c->inv_freq, n, c->l_q, Kl, Vl, s->cap, st, dyn, i));
         } else {
             { ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * S * H * e, 0); HIPCHK(c, launch_rmsnorm(dt, c->l_h, L.ln1, c->l_xn, S, H, g.rms_norm_eps, st)); }
-            rc = gemm(c, c->l_xn, H, L.wqkv, H, L.bqkv, nullptr, 0, c->l_qkv, c->qkv_w, S, c->qkv_w, H, EPI_NONE, 0, GEMM_AUTO, L.wqkv_p); if (rc) return rc;
+            rc = gemm(c, c->l_xn, H, L.wqkv, H, L.bqkv, nullptr, 0, c->l_qkv, c->qkv_w, S, c->qkv_w, H, EPI_NONE, 0, GEMM_AUTO, L.wqkv_p, false, L.wqkv_8, L.sqkv); if (rc) return rc;
             ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * S * c->qkv_w * e, 0);
             for (int j = 0; j < nseg; ++j) {
                 mmd_stream* sj = segs[j].s;
@@ -806,18 +831,18 @@ static int llm_step_segs(mmd_ctx* c, const StepSeg* segs, int nseg, const void* 
         const void* next_norm = (i + 1 < g.num_layers) ? c->L[i + 1].ln1 : c->fnorm;
         void* next_xn = (i + 1 < g.num_layers) ? c->l_xn : c->l_hid;
         if (fused) {
-            rc = slab_gemm(c->l_attn, (int64_t)nh * d, L.wo_p, H, nh * d, &splits); if (rc) return rc;
+            rc = slab_gemm(c->l_attn, (int64_t)nh * d, L.wo_p, H, nh * d, &splits, L.wo_8, L.so); if (rc) return rc;
             { ProfScope ps(c, MMD_K_NORM_ROPE, 4.0 * S * H * e, 0);
               HIPCHK(c, launch_slab_resid_rmsnorm(c->splitk_ws, splits, S, H, c->l_h, c->l_h, L.ln2, g.rms_norm_eps, c->l_xn, st)); }
-            rc = gemm(c, c->l_xn, H, L.wgu, H, nullptr, nullptr, 0, c->l_act, I, S, 2 * I, H, EPI_SWIGLU, 0, GEMM_AUTO, L.wgu_p); if (rc) return rc;
-            rc = slab_gemm(c->l_act, I, L.wdown_p, H, I, &splits); if (rc) return rc;
+            rc = gemm(c, c->l_xn, H, L.wgu, H, nullptr, nullptr, 0, c->l_act, I, S, 2 * I, H, EPI_SWIGLU, 0, GEMM_AUTO, L.wgu_p, false, L.wgu_8, L.sgu); if (rc) return rc;
+            rc = slab_gemm(c->l_act, I, L.wdown_p, H, I, &splits, L.wdown_8, L.sdown); if (rc) return rc;
             ProfScope ps(c, MMD_K_NORM_ROPE, 4.0 * S * H * e, 0);
             HIPCHK(c, launch_slab_resid_rmsnorm(c->splitk_ws, splits, S, H, c->l_h, c->l_h, next_norm, g.rms_norm_eps, next_xn, st));
         } else {
-            rc = gemm(c, c->l_attn, (int64_t)nh * d, L.wo, (int64_t)nh * d, nullptr, c->l_h, H, c->l_h, H, S, H, nh * d, EPI_RESID, 0, GEMM_AUTO, L.wo_p); if (rc) return rc;
+            rc = gemm(c, c->l_attn, (int64_t)nh * d, L.wo, (int64_t)nh * d, nullptr, c->l_h, H, c->l_h, H, S, H, nh * d, EPI_RESID, 0, GEMM_AUTO, L.wo_p, false, L.wo_8, L.so); if (rc) return rc;
             { ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * S * H * e, 0); HIPCHK(c, launch_rmsnorm(dt, c->l_h, L.ln2, c->l_xn, S, H, g.rms_norm_eps, st)); }
-            rc = gemm(c, c->l_xn, H, L.wgu, H, nullptr, nullptr, 0, c->l_act, I, S, 2 * I, H, EPI_SWIGLU, 0, GEMM_AUTO, L.wgu_p); if (rc) return rc;
-            rc = gemm(c, c->l_act, I, L.wdown, I, nullptr, c->l_h, H, c->l_h, H, S, H, I, EPI_RESID, 0, GEMM_AUTO, L.wdown_p); if (rc) return rc;
+            rc = gemm(c, c->l_xn, H, L.wgu, H, nullptr, nullptr, 0, c->l_act, I, S, 2 * I, H, EPI_SWIGLU, 0, GEMM_AUTO, L.wgu_p, false, L.wgu_8, L.sgu); if (rc) return rc;
+            rc = gemm(c, c->l_act, I, L.wdown, I, nullptr, c->l_h, H, c->l_h, H, S, H, I, EPI_RESID, 0, GEMM_AUTO, L.wdown_p, false, L.wdown_8, L.sdown); if (rc) return rc;
         }
     }
     if (!fused) { ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * S * H * e, 0); HIPCHK(c, launch_rmsnorm(dt, c->l_h, c->fnorm, c->l_hid, S, H, g.rms_norm_eps, st)); }
@@ -1035,6 +1060,29 @@ extern "C" int mmd_op_gemm(mmd_ctx* c, const void* X, const void* W, const void*
     if (Wp) { hipStreamSynchronize(c->stream); dev_free(c, Wp); }
     return rc;
 }
+extern "C" int mmd_op_quantize_fp8(mmd_ctx* c, void* W, int N, int K, uint8_t* q8_out, float* scale_out) {
+    if (!c || !W || !q8_out || !scale_out) return MMD_EINVAL;
+    if (c->cfg.dtype != MMD_BF16) FAIL(c, MMD_EINVAL, "fp8 weights need a bf16 context");
+    hipSetDevice(c->device);
+    HIPCHK(c, launch_quantize_fp8_rows(W, N, K, q8_out, scale_out, c->stream));
+    return MMD_OK;
+}
+extern "C" int mmd_op_gemm_w8(mmd_ctx* c, const void* X, const void* Wq, const uint8_t* q8, const float* scale, const void* bias, const void* R, void* Y,
+                              int M, int N, int K, int epi, int out_f32, int variant) {
+    if (!c || !X || !Wq || !q8 || !scale || !Y) return MMD_EINVAL;
+    if (c->cfg.dtype != MMD_BF16 || (N % 16) != 0 || (K % 64) != 0) FAIL(c, MMD_EINVAL, "mmd_op_gemm_w8: bf16 context, N %% 16 == 0, K %% 64 == 0");
+    hipSetDevice(c->device);
+    if (!c->splitk_ws) { c->splitk_bytes = (size_t)64 << 20; int rc = dev_alloc(c, (void**)&c->splitk_ws, c->splitk_bytes); if (rc) return rc; }
+    void *Wp = nullptr, *Wp8 = nullptr;
+    int rc = make_packed(c, Wq, N, K, &Wp); if (rc) return rc;
+    rc = dev_alloc(c, &Wp8, (size_t)N * K, false); if (rc) return rc;
+    HIPCHK(c, launch_pack_w8(q8, N, K, Wp8, c->stream));
+    const int NO = epi == EPI_SWIGLU ? N / 2 : N;
+    rc = gemm(c, X, K, Wq, K, bias, R, NO, Y, NO, M, N, K, epi, out_f32, variant, Wp, false, Wp8, scale);
+    hipStreamSynchronize(c->stream);
+    dev_free(c, Wp); dev_free(c, Wp8);
+    return rc;
+}
 extern "C" int mmd_op_gemm_last_plan(mmd_ctx* c, int* out4) {
     if (!c || !out4) return MMD_EINVAL;
     for (int i = 0; i < 4; ++i) out4[i] = c->last_plan[i];
@@ -1056,6 +1104,9 @@ extern "C" int mmd_op_gemm_bench(mmd_ctx* c, int M, int N, int K, int epi, int v
     if (Xin) HIPCHK(c, hipMemcpyAsync(X, Xin, (size_t)M * K * e, hipMemcpyDeviceToDevice, c->stream)); else HIPCHK(c, hipMemsetAsync(X, 0x3c, (size_t)M * K * e, c->stream));
     if (Win) HIPCHK(c, hipMemcpyAsync(W, Win, (size_t)N * K * e, hipMemcpyDeviceToDevice, c->stream)); else HIPCHK(c, hipMemsetAsync(W, 0x3b, (size_t)N * K * e, c->stream));
     if (Xin) HIPCHK(c, hipMemcpyAsync(R, Xin, std::min((size_t)M * K, (size_t)M * NO) * e, hipMemcpyDeviceToDevice, c->stream));
+    // variant + 1000: the matrix is quantised to fp8 e4m3 first (per-channel scales); the streaming kernels then read the 1-byte copy
+    void* Wp8 = nullptr; float* wsc = nullptr;
+    if (variant >= 1000) { variant -= 1000; rc = quantize_fp8(c, W, N, K, &Wp8, &wsc); if (rc) return rc; }
     if (variant != GEMM_GENERIC && variant != GEMM_LARGE) { rc = make_packed(c, W, N, K, &Wp); if (rc) return rc; }
     if (variant == 5 && !Wp) FAIL(c, MMD_EINVAL, "slab mode needs a packable shape");
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
@@ -1064,11 +1115,11 @@ extern "C" int mmd_op_gemm_bench(mmd_ctx* c, int M, int N, int K, int epi, int v
     auto run = [&]() -> int {
         if (variant == 5) {        // skinny path in slab mode (what the fused LLM schedule launches); the consumer kernel is not part of this timing
             GemmArgs g; memset(&g, 0, sizeof(g));
-            g.X = X; g.ldx = K; g.Wp = Wp; g.M = M; g.N = N; g.K = K; g.epi = EPI_NONE; g.variant = GEMM_SKINNY;
+            g.X = X; g.ldx = K; g.Wp = Wp; g.Wp8 = Wp8; g.wscale = wsc; g.M = M; g.N = N; g.K = K; g.epi = EPI_NONE; g.variant = GEMM_SKINNY;
             g.splitk_ws = c->splitk_ws; g.splitk_ws_bytes = c->splitk_bytes; g.slabs_out = &slabs;
             return launch_gemm(c->cfg.dtype, g, c->stream, nullptr) == hipSuccess ? MMD_OK : MMD_EHIP;
         }
-        return gemm(c, X, K, W, K, nullptr, epi == EPI_RESID ? R : nullptr, NO, Y, NO, M, N, K, epi, 0, variant, Wp);
+        return gemm(c, X, K, W, K, nullptr, epi == EPI_RESID ? R : nullptr, NO, Y, NO, M, N, K, epi, 0, variant, Wp, false, Wp8, wsc);
     };
     for (int i = 0; i < 3; ++i) { rc = run(); if (rc) return rc; }
     hipEventRecord(a, c->stream);
@@ -1079,7 +1130,7 @@ extern "C" int mmd_op_gemm_bench(mmd_ctx* c, int M, int N, int K, int epi, int v
     *avg_ms_out = ms / iters;
     c->prof.on = was;
     hipEventDestroy(a); hipEventDestroy(b);
-    dev_free(c, X); dev_free(c, W); dev_free(c, Y); dev_free(c, R); if (Wp) dev_free(c, Wp);
+    dev_free(c, X); dev_free(c, W); dev_free(c, Y); dev_free(c, R); if (Wp) dev_free(c, Wp); if (Wp8) dev_free(c, Wp8); if (wsc) dev_free(c, wsc);
     return MMD_OK;
 }
 extern "C" int mmd_op_rmsnorm(mmd_ctx* c, const void* x, const void* w, void* y, int M, int H, float eps) {

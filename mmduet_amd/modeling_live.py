@@ -238,6 +238,12 @@ class VideoHeadLiveLlavaQwenForCausalLM:
         self.tokens_per_frame = out_side * out_side
         c.frame_num_tokens = self.tokens_per_frame
         c.max_vit_batch, c.max_step_tokens = max_vit_batch, max_step_tokens
+        wd = getattr(config, 'weight_dtype', None)
+        if wd not in (None, 'bf16', 'model', 'fp8', 'fp8_e4m3'):
+            raise ValueError(f'unknown weight_dtype {wd!r} (None | "fp8_e4m3")')
+        c.weight_dtype = 1 if wd in ('fp8', 'fp8_e4m3') else 0
+        if c.weight_dtype and torch_dtype != torch.bfloat16:
+            raise ValueError('weight_dtype=fp8_e4m3 needs torch_dtype=bfloat16 (fp8 weights x bf16 activations, fp32 accumulate)')
         self._cfg_struct = c
         self._ctx = None
         h = C.c_void_p()

@@ -70,14 +70,20 @@ if __name__ == '__main__':
             json.dump(dict(note='tools/bench_gemm.py prod: mmd_op_gemm_bench, random bf16 operands (X ~ 0.5 N(0,1), W ~ 0.02 N(0,1)), 10 iterations after 3 warm-ups, '
                                 'HIP events on the launch stream; frac = TF/s / 2500 (dense bf16 MFMA peak)', rows=rows), open(sys.argv[2], 'w'), indent=1)
     if which in ('llm', 'all'):
+        rows = []
         for M in (1, 16, 49, 64):
             for name, N, K, epi in LLM:
                 if name == 'lm_head' and M > 1: continue
-                for variant, vn in ((2, 'skinny'), (5, 'skinny-slab')):
-                    if variant == 5 and (epi == 'swiglu' or name == 'lm_head'): continue
+                for variant, vn in ((2, 'skinny'), (5, 'skinny-slab'), (1002, 'fp8-skinny'), (1005, 'fp8-skinny-slab')):
+                    if variant % 1000 == 5 and (epi == 'swiglu' or name == 'lm_head'): continue
                     ms = run(ops, M, N, K, epi, variant)
-                    gb = (N * K + M * K + M * (N // 2 if epi == 'swiglu' else N)) * 2 / 1e9
-                    print(f'M={M:4d} {name:8s} N={N:6d} K={K:6d} {vn:10s} {ms*1e3:8.1f} us  {gb/ms*1e3:7.0f} GB/s  {2*M*N*K/ms/1e9:7.1f} TF', flush=True)
+                    wb = 1 if variant >= 1000 else 2
+                    gb = (N * K * wb + (M * K + M * (N // 2 if epi == 'swiglu' else N)) * 2) / 1e9
+                    rows.append(dict(M=M, name=name, N=N, K=K, variant=vn, us=round(ms * 1e3, 2), GBps=round(gb / ms * 1e3), frac_of_8000=round(gb / ms * 1e3 / 8000, 3)))
+                    print(f'M={M:4d} {name:8s} N={N:6d} K={K:6d} {vn:16s} {ms*1e3:8.1f} us  {gb/ms*1e3:7.0f} GB/s  {2*M*N*K/ms/1e9:7.1f} TF', flush=True)
+        if len(sys.argv) > 2:
+            json.dump(dict(note='tools/bench_gemm.py llm: weight-streaming kernels, random operands; GB/s = algorithmic bytes (weights at their stored width + activations) / time', rows=rows),
+                      open(sys.argv[2], 'w'), indent=1)
     if which in ('big', 'all'):
         for M in (392, 784, 980, 1274, 23328):
             shapes = (LLM[:4] if M < 2000 else VIT)
