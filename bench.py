@@ -89,6 +89,7 @@ def parse(argv=None):
     p.add_argument('--multi-stream', type=int, default=4, help='also measure S streams per GPU in shared forwards (reported under "multi_stream"; never the headline value; 0 = skip)')
     p.add_argument('--multi-frames-per-forward', type=int, default=13)
     p.add_argument('--weights', choices=['bf16', 'fp8'], default='bf16', help='fp8 = e4m3 per-output-channel scaled LLM weights (BASELINE configs[4]); reported with dtype fp8, never the bf16 headline')
+    p.add_argument('--phase', choices=['ab', 'b'], default='ab', help="'b': Phase B alone -- the frame embeddings come from a feature file written before the timed region (mmduet_amd/features.py); LLM-only frames/s, never the headline")
     p.add_argument('--layers', type=int, default=None, help='debug: override LLM layer count (INVALID as a measurement)')
     a = p.parse_args(argv)
     c = CONFIGS[a.config]
@@ -217,7 +218,10 @@ def run_multi_stream(args, model, tok, frames, query, n_streams, frames_per_forw
 
 def run_stream(driver, frames, query):
     driver.reset()
-    driver.input_video_stream(frames)
+    if isinstance(frames, str) or frames.dtype != torch.uint8:
+        driver.input_feature_stream(frames)               # Phase B alone: [T, tokens, C] features (a path or a resident tensor)
+    else:
+        driver.input_video_stream(frames)
     driver.input_query_stream([{'role': 'user', 'content': query, 'time': 0.0}])
     responses = driver.inference()
     scores = torch.tensor([[x['informative_score'], x['relevance_score']] for x in driver.debug_data_list], dtype=torch.float32)
@@ -309,6 +313,14 @@ def main():
     forced = sorted(random.Random(0).sample(range(1, T + 1), args.responses)) if args.responses > 0 else []   # fixed pseudo-random frames
     threshold = 1.0          # informative probability never exceeds 1: the rule is evaluated every frame but responses follow `forced`
     driver = make_driver(args, model, tok, threshold, forced)
+    if args.phase == 'b':
+        # Phase A once, outside every timed region: extract, write the reference's file layout ([T, tokens, C] bf16), read it back into HBM
+        import tempfile
+        from mmduet_amd.features import extract_features, save_frame_features, load_frame_features
+        fpath = os.path.join(tempfile.gettempdir(), f'mmduet_bench_features_rank{rank}.pt')
+        save_frame_features(fpath, extract_features(model, frames, 'embed'), to_bf16=True)
+        frames = load_frame_features(fpath, device=device, dtype=torch.bfloat16)
+        os.remove(fpath)
     multi_runner = MultiRunner(args, model, tok, frames, query, S, args.frames_per_forward) if S > 1 else None
 
     def one_step():
@@ -434,7 +446,7 @@ def main():
                        'max_new_tokens': args.max_new_tokens, 'response_frames': forced, 'llm_forwards_per_step': fwd // max(1, args.steps),
                        'kv_tokens_end': kv_end, 'weights': ('random init N(0,0.02), true shapes' if not args.tiny else 'tiny') + ('' if args.weights == 'bf16' else ', LLM matrices quantised to fp8 e4m3 per output channel'),
                        'parallelism': f'dp{world} ({S} stream(s) per GPU, one RCCL all-gather of the [{world},{S},{T}+1,2] score block per step)',
-                       'native_gather_check': native, 'tower_overlap': not args.no_overlap, 'layers_override': args.layers},
+                       'native_gather_check': native, 'tower_overlap': not args.no_overlap, 'phase': 'A+B' if args.phase == 'ab' else 'B only (frame embeddings pre-extracted to a feature file; LLM side alone)', 'layers_override': args.layers},
             'roofline': roof, 'cpu_baseline': cpu, 'multi_stream': multi,
         }
         print(json.dumps(line), flush=True)

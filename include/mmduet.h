@@ -89,6 +89,10 @@ int64_t mmd_weight_bytes(const mmd_ctx* ctx);
 /* replaces LiveMixin.visual_embed (models/modeling_live.py:26-33): tower -> connector -> pooling.
  * pixel_values [B,3,img,img] in ctx dtype; out [B*frame_num_tokens, hidden] in ctx dtype. */
 int mmd_vit_encode(mmd_ctx* ctx, const void* pixel_values, int B, void* out);
+/* second half of visual_embed for pre-extracted tower features (the reference's offline feature files, data/utils.py:99-117: per-video
+ * [T, tokens, C] written from `vision_encode`; visual_embed without a tower starts at the connector, models/modeling_live.py:26-33):
+ * tower_features [B, tokens, vit_hidden] (ctx dtype) -> mm_projector -> post_projector_pooling -> out [B*frame_num_tokens, hidden] */
+int mmd_connector_pool(mmd_ctx* ctx, const void* tower_features, int B, void* out);
 /* intermediate taps for parity tests: stage 0 = tower output [B*tokens, vit_hidden], 1 = connector output
  * [B*tokens, hidden]; valid until the next mmd_vit_encode. */
 int mmd_vit_debug_tap(mmd_ctx* ctx, int stage, void* out, int64_t out_elems);

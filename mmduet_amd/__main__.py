@@ -7,7 +7,9 @@ package, so `--test_fname` is a JSON list whose entries carry the already sample
      "video_duration": 30.0, "conversation": [{"role": "user", "content": "...", "time": 0.0}, ...]}
 An entry may instead carry the decoder's raw output -- "decoded": "clip0_raw.npy" (uint8 [N,H,W,3] BGR, decode order),
 "input_fps": 29.97[, "frame_count": header value] -- and the reference's sampling + letterbox (test/datasets.py:32-85) runs on the
-GPU (video_input.load_video_frames), `--time_instruction_format` included.
+GPU (video_input.load_video_frames), `--time_instruction_format` included.  With `--features_dir DIR` an entry may carry
+"features": "clip0.pt" instead: a pre-extracted [T, tokens, C] feature file (mmduet_amd/features.py; the reference's offline extraction format,
+data/utils.py:99-117) -- Phase A then comes from disk and only the LLM side runs.
 `--evaluator_format true` writes debug_data in the deprecated shape `test/evaluate.py --func grounding|qvh_highlight` reads.
 Everything else (flags, JSONL output format, `--start_idx/--end_idx` sharding, skip-on-unreadable) follows the reference.
 `--streams_per_gpu S` runs S videos at a time through shared LLM forwards (mmduet_amd/multistream.py), same records.
@@ -35,6 +37,14 @@ def main(argv=None):
         """One test entry -> (frames uint8 [T,3,R,R], fps, duration, conversation) or None when unreadable (test/datasets.py:102-104)."""
         conv = [dict(t) for t in ex['conversation']]
         try:
+            if 'features' in ex and args.features_dir:
+                # Phase A from disk (mmduet_amd/features.py): the driver is fed [T, tokens, C] features instead of frames
+                from .features import load_frame_features
+                feats = load_frame_features(os.path.join(args.features_dir, ex['features']), infer.frame_num_tokens)
+                fps = ex.get('fps', args.frame_fps)
+                if args.max_num_frames:
+                    feats = feats[:args.max_num_frames]
+                return feats, fps, ex.get('video_duration', len(feats) / fps), [{'role': 'system', 'content': args.system_prompt}] + conv
             if 'decoded' in ex:
                 from .video_input import load_video_frames
                 raw = torch.from_numpy(np.load(os.path.join(args.input_dir, ex['decoded'])))
@@ -57,15 +67,22 @@ def main(argv=None):
 
     with open(out_name, 'w') as f_out:
         if args.streams_per_gpu > 1:
-            # several videos share every LLM forward; records are written in input order once the batch of videos is done
+            # several videos share every LLM forward.  Clips are loaded when a slot takes them and every record is written (and flushed)
+            # as its video completes, in completion order -- a crash loses nothing, a long test file is never resident at once
             from .multistream import MultiStreamInfer
-            loaded = [(data[i], load(data[i])) for i in mine]
-            loaded = [(ex, v) for ex, v in loaded if v is not None]
             ms = MultiStreamInfer(args, model=infer.model, tokenizer=infer.tokenizer, n_slots=args.streams_per_gpu)
-            results = ms.run([dict(frames=v[0], fps=v[1], conversation=v[3]) for _, v in loaded])
-            for (ex, v), res in zip(loaded, results):
-                rec = result_record(ex['question_id'], res['responses'], v[2], res['debug_data'], evaluator_format=args.evaluator_format)
+
+            def entry(ex):
+                def make():
+                    v = load(ex)
+                    return None if v is None else dict(frames=v[0], fps=v[1], conversation=v[3], ex=ex, duration=v[2])
+                return make
+
+            def on_result(n, video, res):
+                rec = result_record(video['ex']['question_id'], res['responses'], video['duration'], res['debug_data'], evaluator_format=args.evaluator_format)
                 f_out.write(json.dumps(rec) + '\n')
+                f_out.flush()
+            ms.run([entry(data[i]) for i in mine], on_result=on_result)
             return
         for n, i in enumerate(mine):
             ex = data[i]
@@ -75,7 +92,10 @@ def main(argv=None):
             frames, fps, duration, conversation = v
             infer.reset()
             infer.set_fps(fps=fps)
-            infer.input_video_stream(frames)
+            if frames.dtype == torch.uint8:
+                infer.input_video_stream(frames)
+            else:
+                infer.input_feature_stream(frames)
             infer.input_query_stream(conversation)
             responses = infer.inference()
             rec = result_record(ex['question_id'], responses, duration, infer.debug_data_list, evaluator_format=args.evaluator_format)

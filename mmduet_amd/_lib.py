@@ -47,6 +47,7 @@ _SIGS = {
     'mmd_weight_bytes': (_I64, [_VP]),
     'mmd_vit_encode': (_I, [_VP, _VP, _I, _VP]),
     'mmd_vit_debug_tap': (_I, [_VP, _I, _VP, _I64]),
+    'mmd_connector_pool': (_I, [_VP, _VP, _I, _VP]),
     'mmd_preprocess_frames': (_I, [_VP, _VP, _I, _I, _VP]),
     'mmd_letterbox_geometry': (_I, [_I, _I, _I] + [C.POINTER(_I)] * 6),
     'mmd_letterbox_frames': (_I, [_VP, _VP, _I, _I, _I, _I, _VP, _I, _VP]),

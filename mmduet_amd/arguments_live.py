@@ -72,6 +72,7 @@ class LiveTestArguments(LiveTrainingArguments):
     overlap_vision: bool = True          # encode frames on a side HIP stream, overlapping the LLM steps
     streams_per_gpu: int = 1             # > 1: that many videos share each LLM forward (mmduet_amd/multistream.py)
     evaluator_format: bool = False       # write debug_data in the shape test/evaluate.py reads (results.result_record)
+    features_dir: Optional[str] = None   # entries of --test_fname that carry "features": "<file>" read a pre-extracted feature file from here (mmduet_amd/features.py)
     weight_dtype: Optional[str] = None   # 'fp8_e4m3': decoder linear layers stored as per-channel-scaled OCP e4m3 (bf16 activations, fp32 accumulate)
 
 

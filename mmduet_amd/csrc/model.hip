@@ -487,6 +487,7 @@ static int alloc_workspaces(mmd_ctx* c) {
 #define NEED_FINAL(c) do { if (!(c)) return MMD_EINVAL; if (!(c)->finalized) FAIL(c, MMD_EINVAL, "weights not finalized"); hipSetDevice((c)->device); } while (0)
 
 // ---- vision ----------------------------------------------------------------------------------------------------------
+static int connector_pool(mmd_ctx* c, const void* feats, int B, void* out);
 extern "C" int mmd_vit_encode(mmd_ctx* c, const void* px, int B, void* out) {
     NEED_FINAL(c);
     const mmd_config& g = c->cfg; const int dt = g.dtype; hipStream_t st = c->stream;
@@ -516,11 +517,28 @@ extern "C" int mmd_vit_encode(mmd_ctx* c, const void* px, int B, void* out) {
         rc = gemm(c, c->v_mlp, c->vit_ipad, L.w2, c->vit_ipad, L.b2, c->v_h, C, c->v_h, C, M, C, c->vit_ipad, EPI_RESID, 0, GEMM_AUTO, L.w2_p, true); if (rc) return rc;
     }
     if (g.vit_post_layernorm) { HIPCHK(c, launch_layernorm(dt, c->v_h, c->post_w, c->post_b, c->v_h, M, C, g.vit_ln_eps, st)); }
-    rc = gemm(c, c->v_h, C, c->p0w, C, c->p0b, nullptr, 0, c->v_p1, H, M, H, C, EPI_GELU_ERF, 0, GEMM_AUTO, c->p0w_p, true); if (rc) return rc;
+    c->last_vit_B = B;
+    return connector_pool(c, c->v_h, B, out);
+}
+
+// second half of LiveMixin.visual_embed (models/modeling_live.py:30-33): mm_projector (Linear, GELU(erf), Linear) -> post_projector_pooling
+static int connector_pool(mmd_ctx* c, const void* feats, int B, void* out) {
+    const mmd_config& g = c->cfg; const int dt = g.dtype; hipStream_t st = c->stream;
+    const int C = g.vit_hidden, H = g.hidden_size, M = B * c->vit_tokens;
+    int rc = gemm(c, feats, C, c->p0w, C, c->p0b, nullptr, 0, c->v_p1, H, M, H, C, EPI_GELU_ERF, 0, GEMM_AUTO, c->p0w_p, true); if (rc) return rc;
     rc = gemm(c, c->v_p1, H, c->p2w, H, c->p2b, nullptr, 0, c->v_p2, H, M, H, H, EPI_NONE, 0, GEMM_AUTO, c->p2w_p, true); if (rc) return rc;
     { ProfScope ps(c, MMD_K_OTHER, 0, 0); HIPCHK(c, launch_pool(dt, c->v_p2, out, B, c->vit_grid, H, g.pool_mode, g.pool_stride, st)); }
-    c->last_vit_B = B;
     return MMD_OK;
+}
+
+// the feature-file path (data/utils.py:99-117 writes what `vision_encode` returns, [T, tokens, C] per video; visual_embed then starts at the
+// connector, models/modeling_live.py:26-33 without `vision_encode`): tower features [B, tokens, vit_hidden] -> [B*frame_num_tokens, hidden]
+extern "C" int mmd_connector_pool(mmd_ctx* c, const void* tower_features, int B, void* out) {
+    NEED_FINAL(c);
+    if (B <= 0) return MMD_OK;
+    if (B > c->cfg.max_vit_batch) FAIL(c, MMD_ERANGE, "feature batch %d exceeds max_vit_batch %d", B, c->cfg.max_vit_batch);
+    if (!tower_features || !out) return MMD_EINVAL;
+    return connector_pool(c, tower_features, B, out);
 }
 
 extern "C" int mmd_vit_debug_tap(mmd_ctx* c, int stage, void* out, int64_t out_elems) {

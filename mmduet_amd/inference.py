@@ -183,6 +183,31 @@ class LiveInferForBenchmark:
                 ev.record(self._vit_stream)
             self._vit_events.append(ev)
 
+    @torch.no_grad()
+    def input_feature_stream(self, features, tokens_per_frame=None):
+        """Phase A from a pre-extracted feature file instead of frames (the reference's feature files, data/utils.py:99-117,
+        feed `visual_embed` at the connector when the model carries no tower, models/modeling_live.py:26-33).  `features`: a path (.pt / .npy) or a
+        tensor [T, tokens, C]: tower-level features [T, vit_tokens, vit_hidden] go through the connector + pooling on the GPU, pooled embeddings
+        [T, frame_num_tokens, hidden] are queued as they are.  The queue then holds exactly what `input_video_stream` would have produced."""
+        from .features import load_frame_features, feature_level
+        if isinstance(features, (str, os.PathLike)):
+            features = load_frame_features(features, tokens_per_frame)
+        if features.ndim == 2:
+            features = features.reshape(-1, tokens_per_frame or self.frame_num_tokens, features.shape[-1])
+        level = feature_level(self.model, features)
+        T, nt = features.shape[0], self.frame_num_tokens
+        feats = features.to(device=self.device, dtype=self.torch_dtype)
+        if level == 'tower':
+            out = torch.empty(T * nt, self.hidden_size, dtype=self.torch_dtype, device=self.device)
+            vb = _tower_batch(self.model)
+            for b0 in range(0, T, vb):
+                self.model.connector_pool(feats[b0:b0 + vb], out=out[b0 * nt:min(T, b0 + vb) * nt])
+        else:
+            out = feats.reshape(T * nt, self.hidden_size).contiguous()
+        self._vit_out = out
+        for r in range(T):
+            self.frame_embeds_queue.append((r / self.frame_fps, out[r * nt:(r + 1) * nt]))
+
     def input_query_stream(self, conversation):
         for turn in conversation:
             if turn['role'] == 'user':

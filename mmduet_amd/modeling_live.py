@@ -353,6 +353,37 @@ class VideoHeadLiveLlavaQwenForCausalLM:
                 check(lib().mmd_vit_encode(self._ctx, _ptr(frames[b0:b1]), b1 - b0, _ptr(out[b0 * self.tokens_per_frame:])), self._ctx, 'mmd_vit_encode')
         return out
 
+    def connector_pool(self, tower_features: torch.Tensor, out: torch.Tensor = None):
+        """visual_embed for pre-extracted tower features [B, vit_tokens, vit_hidden] (models/modeling_live.py:26-33 without `vision_encode`):
+        mm_projector -> post_projector_pooling -> [B*frame_num_tokens, hidden]."""
+        f = tower_features.to(device=self.device, dtype=self.dtype).contiguous()
+        if f.ndim != 3 or f.shape[1] != self.config.vit_grid ** 2 or f.shape[2] != self.config.vit_hidden_size:
+            raise ValueError(f'expected tower features [B, {self.config.vit_grid ** 2}, {self.config.vit_hidden_size}], got {tuple(f.shape)}')
+        B = f.shape[0]
+        if out is None:
+            out = torch.empty(B * self.tokens_per_frame, self.config.hidden_size, dtype=self.dtype, device=self.device)
+        with self._lock:
+            self._bind_stream()
+            for b0 in range(0, B, self.max_vit_batch):
+                b1 = min(B, b0 + self.max_vit_batch)
+                check(lib().mmd_connector_pool(self._ctx, _ptr(f[b0:b1]), b1 - b0, _ptr(out[b0 * self.tokens_per_frame:])), self._ctx, 'mmd_connector_pool')
+        return out
+
+    def tower_features(self, frames: torch.Tensor):
+        """What the reference's `vision_encode(vision_encoder, frames)` returns for the LLaVA tower (models/live_llava/video_head_live_llava_qwen.py:96-98):
+        [B, vit_tokens, vit_hidden] -- the tensor its offline feature extraction stores (data/utils.py:114)."""
+        frames = frames.to(device=self.device, dtype=self.dtype).contiguous()
+        B, T, C = frames.shape[0], self.config.vit_grid ** 2, self.config.vit_hidden_size
+        out = torch.empty(B, T, C, dtype=self.dtype, device=self.device)
+        scratch = torch.empty(min(B, self.max_vit_batch) * self.tokens_per_frame, self.config.hidden_size, dtype=self.dtype, device=self.device)
+        with self._lock:
+            self._bind_stream()
+            for b0 in range(0, B, self.max_vit_batch):
+                b1 = min(B, b0 + self.max_vit_batch)
+                check(lib().mmd_vit_encode(self._ctx, _ptr(frames[b0:b1]), b1 - b0, _ptr(scratch)), self._ctx, 'mmd_vit_encode')
+                check(lib().mmd_vit_debug_tap(self._ctx, 0, _ptr(out[b0:b1]), (b1 - b0) * T * C), self._ctx, 'mmd_vit_debug_tap')
+        return out
+
     def vit_debug_tap(self, stage: int, B: int):
         n = B * self.config.vit_grid ** 2
         width = self.config.vit_hidden_size if stage == 0 else self.config.hidden_size

@@ -108,18 +108,27 @@ class _Slot(threading.Thread):
             with torch.no_grad():
                 while self.sched.todo:
                     n, video = self.sched.todo.popleft()
+                    if callable(video):                      # lazy entry: the clip is read when a slot takes it, not when the list is built
+                        video = video()
+                        if video is None:                    # unreadable clip: skipped like the reference does (test/datasets.py:102-104)
+                            continue
                     d = self.driver = self.sched._make_driver(self, video.get('args') or self.sched.args)
                     for k, v in (video.get('driver_attrs') or {}).items():
                         setattr(d, k, v)
                     if video.get('fps'):
                         d.set_fps(fps=video['fps'])
-                    d.input_video_stream(video['frames'])
+                    if video['frames'].dtype == torch.uint8:
+                        d.input_video_stream(video['frames'])
+                    else:                                    # a pre-extracted feature tensor [T, tokens, C] (mmduet_amd/features.py)
+                        d.input_feature_stream(video['frames'])
                     d.input_query_stream(video['conversation'])
                     responses = d.inference()
                     self.sched.results[n] = dict(responses=responses, debug_data=list(d.debug_data_list), forward_calls=d.forward_calls,
                                                  replayed_frames=d.replayed_frames, response_token_ids=list(d.response_token_ids),
                                                  generated_token_ids=[int(t) for t in d.generated_token_ids],
                                                  final_kv_len=len(d.past_key_values) if d.past_key_values else 0)
+                    if self.sched.on_result is not None:
+                        self.sched.on_result(n, video, self.sched.results[n])
         except BaseException as e:          # surfaces in MultiStreamInfer.run()
             self.error = e
         finally:
@@ -187,7 +196,10 @@ class MultiStreamInfer:
                 self.round_log.append((len(group), sum(r.rows for r in group), time.perf_counter() - t0))
         self.exec_seconds += time.perf_counter() - t0
 
-    def run(self, videos):
+    def run(self, videos, on_result=None):
+        """`videos` entries may be callables returning the dict (or None to skip): they are evaluated when a slot takes them, so a long test
+        file is never resident at once; `on_result(index, video, result)` is called as each video completes (records can be flushed then)."""
+        self.on_result = on_result
         self.todo = collections.deque(enumerate(videos))
         self.results = [None] * len(videos)
         self.parked = threading.Semaphore(0)

@@ -157,12 +157,4 @@ def qvh_saliency_scores(debug_data, smooth_window_size):
     return [sum(sm[i:i + per_clip]) for i in range(0, len(sm), per_clip)]
 
 
-def save_frame_features(path, frame_embeds, to_bf16=True):
-    """frame_embeds: [T*tokens, C] or [T, tokens, C] device tensor from `model.visual_embed`."""
-    t = frame_embeds.detach().to('cpu')
-    torch.save(t.to(torch.bfloat16) if to_bf16 else t, path)
-
-
-def load_frame_features(path, tokens_per_frame, device='cuda', dtype=torch.bfloat16):
-    t = torch.load(path, map_location='cpu')
-    return t.reshape(-1, tokens_per_frame, t.shape[-1]).to(device=device, dtype=dtype)
+from .features import save_frame_features, load_frame_features      # moved to mmduet_amd/features.py (kept importable from here)  # noqa: E402,F401

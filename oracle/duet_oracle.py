@@ -446,7 +446,7 @@ class OracleModel:
                                       frame_num_tokens=cfg.frame_num_tokens, v_placeholder=cfg.v_placeholder,
                                       v_placeholder_id=cfg.v_placeholder_id, eos_token_id=cfg.eos_token_id,
                                       vocab_size=cfg.vocab_size, video_pooling_stride=cfg.video_pooling_stride,
-                                      mm_spatial_pool_mode=cfg.mm_spatial_pool_mode)
+                                      mm_spatial_pool_mode=cfg.mm_spatial_pool_mode, vit_grid=cfg.vit_grid, vit_hidden_size=cfg.vit_hidden_size)
         self._embed = _Embedding(weights['model.embed_tokens.weight'])
         self._tower = SimpleNamespace(image_processor=_ImageProcessor(cfg.vit_image_size),
                                       num_patches_per_side=cfg.vit_grid)
@@ -463,6 +463,18 @@ class OracleModel:
 
     def visual_embed(self, frames):
         return visual_embed(self.w, self.cfg, frames.to(self.dtype))
+
+    def connector_pool(self, tower_features, out=None):
+        """models/modeling_live.py:30-33 for pre-extracted tower features (no `vision_encode`): connector -> pooling -> flatten."""
+        h = post_projector_pooling(self.cfg, connector(self.w, tower_features.to(self.dtype)))
+        h = h.reshape(-1, h.shape[-1])
+        if out is not None:
+            out.copy_(h)
+            return out
+        return h
+
+    def tower_features(self, frames):
+        return vit_forward(self.w, self.cfg, frames.to(self.dtype))
 
     def cache_prefix(self, handle, length):
         return KVHandle([k[:, :length] for k in handle.k], [v[:, :length] for v in handle.v])

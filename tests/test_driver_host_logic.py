@@ -185,3 +185,31 @@ def test_mid_stream_query_lands_on_the_same_frame_for_every_chunk_size(fps, k, q
     qk, sk, nk = run(k)
     assert qk == q1 and nk == n1
     assert sk == pytest.approx(s1, abs=2e-5)
+
+
+@pytest.mark.parametrize('level', ['embed', 'tower'])
+def test_feature_file_stream_equals_frame_stream(tmp_path, level):
+    """f4: Phase A from a feature file (mmduet_amd/features.py; layout of data/utils.py:99-117) queues exactly what input_video_stream would have."""
+    from helpers import stream_frames
+    from mmduet_amd.features import extract_features, save_frame_features, load_frame_features
+    name = 'sum_remove'
+    case, opts = META['cases'][name], META['cases'][name]['opts']
+    model, _, _ = oracle_model('A')
+    d = run_stream_case(LiveInferForBenchmark, model, name, case, META)
+    feats = extract_features(model, stream_frames(name), level)
+    assert feats.shape[0] == case['T'] and feats.ndim == 3
+    save_frame_features(tmp_path / 'clip.pt', feats, to_bf16=False)
+    args = make_args(frame_fps=case['fps'], system_prompt=META['system_prompt'], max_new_tokens=12, stream_end_score_sum_threshold=opts.get('stream_end_score_sum_threshold'),
+                     stream_end_prob_threshold=opts.get('stream_end_prob_threshold'), score_heads=opts.get('score_heads', 'informative_score'),
+                     remove_assistant_turns=opts.get('remove_assistant_turns', False), repetition_penalty=opts.get('repetition_penalty'),
+                     running_list_length=opts.get('running_list_length', 20))
+    tok = tokenizer_for(model.config)
+    model.config.eos_token_id = META['eos_token_id']
+    d2 = LiveInferForBenchmark(args, model=model, tokenizer=tok)
+    d2.input_feature_stream(str(tmp_path / 'clip.pt'))
+    d2.input_query_stream(case['conversation'])
+    d2.responses = d2.inference()
+    assert d2.debug_data_list == d.debug_data_list and d2.response_token_ids == d.response_token_ids
+    assert len(d2.past_key_values) == len(d.past_key_values)
+    with pytest.raises(ValueError):
+        d2.input_feature_stream(torch.zeros(3, 5, 7))

@@ -80,6 +80,7 @@ def test_cli_over_predecoded_and_raw_decoded_entries(tmp_path, monkeypatch):
               '--output_fname', str(out2), '--frame_fps', '2', '--frame_resolution', str(R), '--max_num_frames', '6', '--time_instruction_format', 'vtimellm',
               '--stream_end_prob_threshold', '0.5', '--evaluator_format', 'true', '--max_new_tokens', '4', '--streams_per_gpu', '2'])
     recs2 = [json.loads(l) for l in open(out2)]
+    recs2.sort(key=lambda r: r['question_id'])                 # shared forwards write records as videos complete
     assert [r['question_id'] for r in recs2] == ['q0', 'q1']
     for a, b in zip(recs, recs2):
         assert a['model_response_list'] == b['model_response_list'] and len(a['debug_data']) == len(b['debug_data'])
@@ -177,3 +178,59 @@ def test_live_arena_growth_across_reallocations_matches_presized_arena():
     a = m_grow(inputs_embeds=x, past_key_values=mid).informative_logits[0, -1].clone()
     b = m_big(inputs_embeds=x, past_key_values=m_big.cache_prefix(cb, total - 448)).informative_logits[0, -1]
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['f32', 'bf16'])
+@pytest.mark.parametrize('level', ['embed', 'tower'])
+def test_feature_file_stream_is_bit_identical_to_in_hbm_stream(tmp_path, dtype, level):
+    """f4 end to end on the GPU: extract -> save ([T, tokens, C], data/utils.py:114-117 layout, model dtype) -> input_feature_stream -> Phase B.
+    The file holds the very bits the in-HBM path hands on (tower output / pooled embeddings), so every score and token is IDENTICAL."""
+    from helpers import make_args, stream_frames
+    from mmduet_amd.features import extract_features, save_frame_features
+    m = hip_model('A', dtype)[0]
+    name = 'prob_keep_pen'
+    case, opts = META['cases'][name], META['cases'][name]['opts']
+    ref = run_stream_case(LiveInferForBenchmark, m, name, case, META, dtype=dtype)
+    feats = extract_features(m, stream_frames(name), level)
+    save_frame_features(tmp_path / 'clip.pt', feats, to_bf16=(dtype == torch.bfloat16))
+    a = make_args(frame_fps=case['fps'], system_prompt=META['system_prompt'], max_new_tokens=12, stream_end_prob_threshold=opts['stream_end_prob_threshold'],
+                  score_heads=opts['score_heads'], repetition_penalty=opts['repetition_penalty'], bf16=(dtype == torch.bfloat16))
+    tok = tokenizer_for(m.config)
+    m.config.eos_token_id = META['eos_token_id']
+    d = LiveInferForBenchmark(a, model=m, tokenizer=tok)
+    d.input_feature_stream(str(tmp_path / 'clip.pt'))
+    d.input_query_stream(case['conversation'])
+    d.inference()
+    assert d.debug_data_list == ref.debug_data_list
+    assert d.response_token_ids == ref.response_token_ids and len(d.past_key_values) == len(ref.past_key_values)
+
+
+def test_cli_reads_feature_files(tmp_path, monkeypatch):
+    """`python -m mmduet_amd --features_dir ...`: entries with "features" skip Phase A; records equal the frame-fed run of the same clips."""
+    import mmduet_amd.inference as inf
+    import mmduet_amd.__main__ as cli
+    from helpers import stream_frames
+    from mmduet_amd.features import extract_features, save_frame_features
+    model, cfgd, _ = hip_model('A')
+    tok = tokenizer_for(model.config)
+    monkeypatch.setattr(inf, 'build_model_and_tokenizer', lambda **kw: (model, tok))
+    R = model.config.frame_resolution
+    names = ['grounding_q0', 'prob_keep']
+    entries_f, entries_v = [], []
+    for n in names:
+        case = META['cases'][n]
+        fr = stream_frames(n)
+        np.save(tmp_path / f'{n}.npy', fr.numpy())
+        save_frame_features(tmp_path / f'{n}.pt', extract_features(model, fr, 'embed'), to_bf16=False)
+        base = dict(question_id=n, fps=case['fps'], video_duration=case['T'] / case['fps'], conversation=case['conversation'])
+        entries_v.append(dict(base, frames=f'{n}.npy')); entries_f.append(dict(base, features=f'{n}.pt'))
+    outs = []
+    for tag, entries, extra in (('v', entries_v, []), ('f', entries_f, ['--features_dir', str(tmp_path)]), ('f2', entries_f, ['--features_dir', str(tmp_path), '--streams_per_gpu', '2'])):
+        json.dump(entries, open(tmp_path / f'{tag}.json', 'w'))
+        cli.main(['--live_version', 'test', '--llm_pretrained', 'synthetic:0', '--input_dir', str(tmp_path), '--test_fname', str(tmp_path / f'{tag}.json'),
+                  '--output_fname', str(tmp_path / f'{tag}.jsonl'), '--frame_fps', '1', '--frame_resolution', str(R), '--max_num_frames', '100',
+                  '--stream_end_prob_threshold', '0.5', '--max_new_tokens', '4'] + extra)
+        outs.append(sorted((json.loads(l) for l in open(tmp_path / f'{tag}.jsonl')), key=lambda r: r['question_id']))
+    assert outs[0] == outs[1] and len(outs[0]) == 2
+    for a, b in zip(outs[1], outs[2]):                         # shared forwards: same records up to the 3-digit score rounding
+        assert a['model_response_list'] == b['model_response_list'] and len(a['debug_data']) == len(b['debug_data'])

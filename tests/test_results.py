@@ -37,6 +37,15 @@ def test_feature_file_roundtrip(tmp_path):
     save_frame_features(tmp_path / 'v.pt', x)
     y = load_frame_features(tmp_path / 'v.pt', 4, device='cpu')
     assert y.shape == (3, 4, 8) and torch.allclose(y.float(), x.reshape(3, 4, 8), atol=2e-2)
+    # the reference's layout [T, tokens, C] (data/utils.py:114-117), bf16 and fp32, .pt and .npy
+    save_frame_features(tmp_path / 'w.pt', x, tokens_per_frame=4, to_bf16=False)
+    z = load_frame_features(tmp_path / 'w.pt')
+    assert z.dtype == torch.float32 and torch.equal(z, x.reshape(3, 4, 8))
+    import numpy as np
+    np.save(tmp_path / 'u.npy', x.reshape(3, 4, 8).numpy())
+    assert torch.equal(load_frame_features(str(tmp_path / 'u.npy')), x.reshape(3, 4, 8))
+    with pytest.raises(ValueError):
+        load_frame_features(tmp_path / 'v.pt')                 # flat file without tokens_per_frame
 
 
 @pytest.mark.parametrize('ci', range(len(GOLD['cases'])))
