@@ -55,6 +55,12 @@ typedef struct mmd_config {
     int32_t max_vit_batch;        /* frames per mmd_vit_encode call (reference: 32, test/inference.py:208) */
     int32_t max_step_tokens;      /* max rows of one mmd_llm_step call */
     int32_t weight_dtype;         /* mmd_weight_dtype (bf16 contexts only) */
+    /* secondary frame encoders (models/vision_live.py:11-64): a context may carry ONLY a tower -- HF SigLIP-L/16-384 or CLIP-L/14-336 */
+    int32_t vision_only;          /* 1: no decoder / projector; the mmd_vision_* entry points below are the product */
+    int32_t vit_class_token;      /* CLIP: class embedding prepended (tokens = grid^2 + 1) */
+    int32_t vit_pre_layernorm;    /* CLIP: pre_layrnorm after the embeddings */
+    int32_t vit_act;              /* 0 gelu_pytorch_tanh (SigLIP), 1 quick_gelu (CLIP) */
+    int32_t vit_pool_head;        /* SigLIP: SiglipMultiheadAttentionPoolingHead present (pooler_output, used when frame_token_cls) */
 } mmd_config;
 
 typedef struct mmd_ctx mmd_ctx;
@@ -93,6 +99,16 @@ int mmd_vit_encode(mmd_ctx* ctx, const void* pixel_values, int B, void* out);
  * [T, tokens, C] written from `vision_encode`; visual_embed without a tower starts at the connector, models/modeling_live.py:26-33):
  * tower_features [B, tokens, vit_hidden] (ctx dtype) -> mm_projector -> post_projector_pooling -> out [B*frame_num_tokens, hidden] */
 int mmd_connector_pool(mmd_ctx* ctx, const void* tower_features, int B, void* out);
+/* ---- secondary encoder path (models/vision_live.py:11-54 `_siglip_vision_encode` / `_clip_vision_encode`) -------------------------------
+ * mmd_normalize_frames: torchvision normalize(frames * rescale, mean, std) (:13,:36); frames uint8 (src_kind 0) or fp32 (1) [B,3,R,R] -> ctx dtype.
+ * mmd_vision_tower: `vision_model(frames).last_hidden_state` -> out [B, tokens, vit_hidden] (SigLIP: after post_layernorm; CLIP: class token first,
+ *   pre_layrnorm, quick_gelu, NO post_layernorm on the sequence).
+ * mmd_vision_pool_tokens: adaptive_avg_pool2d of the s x s spatial tokens (class token skipped) to out_h x out_w (:17-24,:40-47) -> [B, out_h*out_w, C].
+ * mmd_vision_pool_head: SigLIP pooler_output (probe attention + LayerNorm + MLP, siglip/modeling_siglip.py [3P]) -> [B, C] (:28). */
+int mmd_normalize_frames(mmd_ctx* ctx, const void* frames, int src_kind, int B, int R, const float* mean3_host, const float* std3_host, float rescale, void* out);
+int mmd_vision_tower(mmd_ctx* ctx, const void* pixel_values, int B, void* out);
+int mmd_vision_pool_tokens(mmd_ctx* ctx, const void* feats, int B, int out_h, int out_w, void* out);
+int mmd_vision_pool_head(mmd_ctx* ctx, const void* feats, int B, void* out);
 /* intermediate taps for parity tests: stage 0 = tower output [B*tokens, vit_hidden], 1 = connector output
  * [B*tokens, hidden]; valid until the next mmd_vit_encode. */
 int mmd_vit_debug_tap(mmd_ctx* ctx, int stage, void* out, int64_t out_elems);

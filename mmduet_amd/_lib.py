@@ -23,7 +23,8 @@ class MmdConfig(C.Structure):
                 ('vit_hidden', C.c_int32), ('vit_intermediate', C.c_int32), ('vit_layers', C.c_int32), ('vit_heads', C.c_int32),
                 ('vit_image', C.c_int32), ('vit_patch', C.c_int32), ('vit_ln_eps', C.c_float), ('vit_post_layernorm', C.c_int32),
                 ('pool_mode', C.c_int32), ('pool_stride', C.c_int32), ('frame_num_tokens', C.c_int32),
-                ('max_vit_batch', C.c_int32), ('max_step_tokens', C.c_int32), ('weight_dtype', C.c_int32)]
+                ('max_vit_batch', C.c_int32), ('max_step_tokens', C.c_int32), ('weight_dtype', C.c_int32),
+                ('vision_only', C.c_int32), ('vit_class_token', C.c_int32), ('vit_pre_layernorm', C.c_int32), ('vit_act', C.c_int32), ('vit_pool_head', C.c_int32)]
 
 
 class MmduetError(RuntimeError):
@@ -48,6 +49,10 @@ _SIGS = {
     'mmd_vit_encode': (_I, [_VP, _VP, _I, _VP]),
     'mmd_vit_debug_tap': (_I, [_VP, _I, _VP, _I64]),
     'mmd_connector_pool': (_I, [_VP, _VP, _I, _VP]),
+    'mmd_normalize_frames': (_I, [_VP, _VP, _I, _I, _I, C.POINTER(_F), C.POINTER(_F), _F, _VP]),
+    'mmd_vision_tower': (_I, [_VP, _VP, _I, _VP]),
+    'mmd_vision_pool_tokens': (_I, [_VP, _VP, _I, _I, _I, _VP]),
+    'mmd_vision_pool_head': (_I, [_VP, _VP, _I, _VP]),
     'mmd_preprocess_frames': (_I, [_VP, _VP, _I, _I, _VP]),
     'mmd_letterbox_geometry': (_I, [_I, _I, _I] + [C.POINTER(_I)] * 6),
     'mmd_letterbox_frames': (_I, [_VP, _VP, _I, _I, _I, _I, _VP, _I, _VP]),

@@ -55,6 +55,11 @@ struct mmd_ctx {
     void *patch_w = 0, *patch_b = 0, *pos_emb = 0, *post_w = 0, *post_b = 0, *p0w = 0, *p0b = 0, *p2w = 0, *p2b = 0;
     void *patch_w_p = 0, *p0w_p = 0, *p2w_p = 0;
     int vit_kpad = 0, vit_ipad = 0, vit_tokens = 0, vit_grid = 0, qkv_w = 0;
+    int vit_seq = 0;                    // tower sequence length = vit_tokens (+ 1 with a class token, CLIP)
+    void *cls_emb = 0, *pre_w = 0, *pre_b = 0, *v_patch = 0;      // CLIP: class embedding, pre_layrnorm; patch rows before the class token is spliced in
+    // SigLIP attention-pooling head (pooler_output): probe, MHA in_proj split into q | kv, out_proj, LayerNorm, MLP
+    void *hd_probe = 0, *hd_wq = 0, *hd_bq = 0, *hd_wkv = 0, *hd_bkv = 0, *hd_wo = 0, *hd_bo = 0, *hd_lnw = 0, *hd_lnb = 0, *hd_w1 = 0, *hd_b1 = 0, *hd_w2 = 0, *hd_b2 = 0;
+    void *hd_q = 0, *hd_kv = 0, *hd_a = 0, *hd_h = 0, *hd_n = 0, *hd_m = 0;
     float* inv_freq = nullptr; bool inv_freq_user = false;
     // workspaces
     void *v_col = 0, *v_h = 0, *v_xn = 0, *v_qkv = 0, *v_attn = 0, *v_mlp = 0, *v_p1 = 0, *v_p2 = 0;
@@ -163,7 +168,7 @@ extern "C" int mmd_create(const mmd_config* cfg, int device, mmd_ctx** out) {
     if (cfg->struct_size != (int32_t)sizeof(mmd_config)) { g_create_error = "mmd_config size mismatch (ABI)"; return MMD_EINVAL; }
     if (cfg->dtype != MMD_F32 && cfg->dtype != MMD_BF16) { g_create_error = "unsupported dtype"; return MMD_EINVAL; }
     if (cfg->weight_dtype != MMD_W_DTYPE && (cfg->weight_dtype != MMD_W_FP8_E4M3 || cfg->dtype != MMD_BF16)) { g_create_error = "weight_dtype fp8_e4m3 needs a bf16 context"; return MMD_EINVAL; }
-    if (cfg->num_heads % cfg->num_kv_heads != 0 || cfg->head_dim % 2 != 0 || cfg->head_dim > 128) { g_create_error = "unsupported head configuration"; return MMD_EINVAL; }
+    if (!cfg->vision_only && (cfg->num_heads % cfg->num_kv_heads != 0 || cfg->head_dim % 2 != 0 || cfg->head_dim > 128)) { g_create_error = "unsupported head configuration"; return MMD_EINVAL; }
     if (cfg->vit_hidden % cfg->vit_heads != 0 || cfg->vit_hidden / cfg->vit_heads > 128) { g_create_error = "unsupported ViT head configuration"; return MMD_EINVAL; }
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) { g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e); return MMD_EHIP; }
@@ -174,9 +179,10 @@ extern "C" int mmd_create(const mmd_config* cfg, int device, mmd_ctx** out) {
     c->stream = c->own_stream;
     c->vit_grid = cfg->vit_image / cfg->vit_patch;
     c->vit_tokens = c->vit_grid * c->vit_grid;
+    c->vit_seq = c->vit_tokens + (cfg->vit_class_token ? 1 : 0);
     c->vit_kpad = (int)round_up(3 * cfg->vit_patch * cfg->vit_patch, 64);
     c->vit_ipad = (int)round_up(cfg->vit_intermediate, 64);
-    c->qkv_w = (cfg->num_heads + 2 * cfg->num_kv_heads) * cfg->head_dim;
+    c->qkv_w = cfg->vision_only ? 0 : (cfg->num_heads + 2 * cfg->num_kv_heads) * cfg->head_dim;
     { const char* nf = getenv("MMDUET_NO_FUSE"); c->no_fuse = nf && nf[0] == '1'; }
     // graph replay of the decode step is opt-in (MMDUET_GRAPH=1): measured on MI355X it is not faster than eager launches
     // from this C++ loop (458 vs 480-500 ms for 128 tokens) -- the step is bound by the ~1.5 us GPU-side kernel boundaries,
@@ -336,6 +342,7 @@ extern "C" int mmd_finalize_weights(mmd_ctx* c) {
     const int dt = g.dtype; const size_t e = es(c);
     const int H = g.hidden_size, I = g.intermediate_size, V = g.vocab_size, d = g.head_dim, nh = g.num_heads, nkv = g.num_kv_heads;
     hipStream_t st = c->stream;
+    if (!g.vision_only) {
     { TAKE(t, "model.embed_tokens.weight", {V, H}); c->embed = t.p; }
     { TAKE(t, "model.norm.weight", {H}); c->fnorm = t.p; }
     { TAKE(t, "lm_head.weight", {V, H}); c->lm_head = t.p; int rc = make_packed(c, c->lm_head, V, H, &c->lm_head_p); if (rc) return rc; }
@@ -381,6 +388,7 @@ extern "C" int mmd_finalize_weights(mmd_ctx* c) {
         HIPCHK(c, hipStreamSynchronize(st));
         dev_free(c, wq.p); dev_free(c, wk.p); dev_free(c, wv.p); dev_free(c, bq.p); dev_free(c, bk.p); dev_free(c, bv.p); dev_free(c, wg.p); dev_free(c, wu.p);
     }
+    }
     // vision tower
     const int C = g.vit_hidden, CI = g.vit_intermediate, P = g.vit_patch, KP = 3 * P * P;
     {
@@ -391,7 +399,9 @@ extern "C" int mmd_finalize_weights(mmd_ctx* c) {
         HIPCHK(c, hipStreamSynchronize(st)); dev_free(c, w.p);
     }
     { TAKE(t, "vit.embeddings.patch_embedding.bias", {C}); c->patch_b = t.p; }
-    { TAKE(t, "vit.embeddings.position_embedding.weight", {c->vit_tokens, C}); c->pos_emb = t.p; }
+    { TAKE(t, "vit.embeddings.position_embedding.weight", {c->vit_seq, C}); c->pos_emb = t.p; }
+    if (g.vit_class_token) { TAKE(t, "vit.embeddings.class_embedding", {C}); c->cls_emb = t.p; }
+    if (g.vit_pre_layernorm) { { TAKE(t, "vit.pre_layrnorm.weight", {C}); c->pre_w = t.p; } { TAKE(t, "vit.pre_layrnorm.bias", {C}); c->pre_b = t.p; } }
     c->VL.resize(g.vit_layers);
     for (int i = 0; i < g.vit_layers; ++i) {
         std::string p = "vit.encoder.layers." + std::to_string(i) + ".";
@@ -428,13 +438,32 @@ extern "C" int mmd_finalize_weights(mmd_ctx* c) {
     if (g.vit_post_layernorm) {
         { TAKE(t, "vit.post_layernorm.weight", {C}); c->post_w = t.p; } { TAKE(t, "vit.post_layernorm.bias", {C}); c->post_b = t.p; }
     }
+    if (!g.vision_only) {
     { TAKE(t, "model.mm_projector.0.weight", {H, C}); c->p0w = t.p; } { TAKE(t, "model.mm_projector.0.bias", {H}); c->p0b = t.p; }
     { TAKE(t, "model.mm_projector.2.weight", {H, H}); c->p2w = t.p; } { TAKE(t, "model.mm_projector.2.bias", {H}); c->p2b = t.p; }
     { int rc = make_packed(c, c->p0w, H, C, &c->p0w_p); if (rc) return rc; rc = make_packed(c, c->p2w, H, H, &c->p2w_p); if (rc) return rc; }
+    }
+    if (g.vit_pool_head) {
+        // SiglipMultiheadAttentionPoolingHead: nn.MultiheadAttention keeps q/k/v stacked in in_proj_weight [3C, C]
+        { TAKE(t, "vit.head.probe", {C}); c->hd_probe = t.p; }
+        TAKE(wi, "vit.head.attention.in_proj_weight", {3 * C, C}); TAKE(bi, "vit.head.attention.in_proj_bias", {3 * C});
+        int rc;
+        if ((rc = dev_alloc(c, &c->hd_wq, (size_t)C * C * e, false)) || (rc = dev_alloc(c, &c->hd_bq, (size_t)C * e, false)) ||
+            (rc = dev_alloc(c, &c->hd_wkv, (size_t)2 * C * C * e, false)) || (rc = dev_alloc(c, &c->hd_bkv, (size_t)2 * C * e, false))) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->hd_wq, wi.p, (size_t)C * C * e, hipMemcpyDeviceToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->hd_wkv, (char*)wi.p + (size_t)C * C * e, (size_t)2 * C * C * e, hipMemcpyDeviceToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->hd_bq, bi.p, (size_t)C * e, hipMemcpyDeviceToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->hd_bkv, (char*)bi.p + (size_t)C * e, (size_t)2 * C * e, hipMemcpyDeviceToDevice, st));
+        HIPCHK(c, hipStreamSynchronize(st)); dev_free(c, wi.p); dev_free(c, bi.p);
+        { TAKE(t, "vit.head.attention.out_proj.weight", {C, C}); c->hd_wo = t.p; } { TAKE(t, "vit.head.attention.out_proj.bias", {C}); c->hd_bo = t.p; }
+        { TAKE(t, "vit.head.layernorm.weight", {C}); c->hd_lnw = t.p; } { TAKE(t, "vit.head.layernorm.bias", {C}); c->hd_lnb = t.p; }
+        { TAKE(t, "vit.head.mlp.fc1.weight", {CI, C}); c->hd_w1 = t.p; } { TAKE(t, "vit.head.mlp.fc1.bias", {CI}); c->hd_b1 = t.p; }
+        { TAKE(t, "vit.head.mlp.fc2.weight", {C, CI}); c->hd_w2 = t.p; } { TAKE(t, "vit.head.mlp.fc2.bias", {C}); c->hd_b2 = t.p; }
+    }
     // tensors that are on the checkpoint but not on the path (post_layernorm when unused, pooling head, ...) are dropped
     for (auto& kv : c->raw) dev_free(c, kv.second.p);
     c->raw.clear();
-    if (!c->inv_freq_user) {
+    if (!c->inv_freq_user && !g.vision_only) {
         int n = d / 2;
         std::vector<float> t(n);
         for (int i = 0; i < n; ++i) t[i] = (float)(1.0 / std::pow((double)g.rope_theta, (double)(2 * i) / (double)d));
@@ -457,11 +486,20 @@ extern "C" int mmd_finalize_weights(mmd_ctx* c) {
 static int alloc_workspaces(mmd_ctx* c) {
     const mmd_config& g = c->cfg; const size_t e = es(c);
     const int C = g.vit_hidden, H = g.hidden_size;
-    int64_t Mv = round_up((int64_t)g.max_vit_batch * c->vit_tokens, 128);
+    int64_t Mv = round_up((int64_t)g.max_vit_batch * c->vit_seq, 128);
     int rc;
 #define WS(ptr, bytes) rc = dev_alloc(c, (void**)&(ptr), (bytes)); if (rc) return rc;
     WS(c->v_col, (size_t)Mv * c->vit_kpad * e); WS(c->v_h, (size_t)Mv * C * e); WS(c->v_xn, (size_t)Mv * C * e);
     WS(c->v_qkv, (size_t)Mv * 3 * C * e); WS(c->v_attn, (size_t)Mv * C * e); WS(c->v_mlp, (size_t)Mv * c->vit_ipad * e);
+    if (g.vit_class_token) { WS(c->v_patch, (size_t)Mv * C * e); }
+    c->v_splitk_bytes = (size_t)32 << 20; WS(c->v_splitk_ws, c->v_splitk_bytes);
+    c->v_attn_bytes = (size_t)32 << 20; WS(c->v_attn_ws, c->v_attn_bytes);
+    if (g.vit_pool_head) {
+        const size_t Bm = (size_t)g.max_vit_batch;
+        WS(c->hd_q, (size_t)C * e); WS(c->hd_kv, (size_t)Mv * 2 * C * e); WS(c->hd_a, Bm * C * e); WS(c->hd_h, Bm * C * e); WS(c->hd_n, Bm * C * e);
+        WS(c->hd_m, Bm * g.vit_intermediate * e);
+    }
+    if (g.vision_only) return MMD_OK;
     WS(c->v_p1, (size_t)Mv * H * e); WS(c->v_p2, (size_t)Mv * H * e);
     int64_t S = round_up(g.max_step_tokens, 128);
     WS(c->l_h, (size_t)S * H * e); WS(c->l_xn, (size_t)S * H * e); WS(c->l_qkv, (size_t)S * c->qkv_w * e);
@@ -469,8 +507,6 @@ static int alloc_workspaces(mmd_ctx* c) {
     WS(c->l_act, (size_t)S * g.intermediate_size * e); WS(c->l_hid, (size_t)S * H * e);
     c->splitk_bytes = (size_t)64 << 20; WS(c->splitk_ws, c->splitk_bytes);
     c->attn_bytes = (size_t)128 << 20; WS(c->attn_ws, c->attn_bytes);
-    c->v_splitk_bytes = (size_t)32 << 20; WS(c->v_splitk_ws, c->v_splitk_bytes);
-    c->v_attn_bytes = (size_t)32 << 20; WS(c->v_attn_ws, c->v_attn_bytes);
     WS(c->logits_ws, (size_t)g.vocab_size * sizeof(float));
     WS(c->heads_dev, (size_t)S * 4 * sizeof(float)); WS(c->rows_dev, (size_t)S * sizeof(int32_t));
     WS(c->tok_dev, 64); WS(c->argmax_scratch, 1024); c->prev_cap = 16384; WS(c->prev_dev, (size_t)c->prev_cap * sizeof(int64_t));
@@ -488,15 +524,20 @@ static int alloc_workspaces(mmd_ctx* c) {
 
 // ---- vision ----------------------------------------------------------------------------------------------------------
 static int connector_pool(mmd_ctx* c, const void* feats, int B, void* out);
-extern "C" int mmd_vit_encode(mmd_ctx* c, const void* px, int B, void* out) {
-    NEED_FINAL(c);
+// the tower: patch-embed (+ class token, + pre-LN for CLIP) -> encoder layers -> optional post_layernorm; result [B * vit_seq, C] in c->v_h
+static int vit_tower(mmd_ctx* c, const void* px, int B) {
     const mmd_config& g = c->cfg; const int dt = g.dtype; hipStream_t st = c->stream;
-    if (B <= 0) return MMD_OK;
     if (B > g.max_vit_batch) FAIL(c, MMD_ERANGE, "vit batch %d exceeds max_vit_batch %d", B, g.max_vit_batch);
-    const int C = g.vit_hidden, H = g.hidden_size, T = c->vit_tokens, M = B * T, hd = C / g.vit_heads;
+    const int C = g.vit_hidden, T = c->vit_tokens, TS = c->vit_seq, M = B * TS, hd = C / g.vit_heads;
     { ProfScope ps(c, MMD_K_OTHER, 0, 0); HIPCHK(c, launch_im2col(dt, px, B, g.vit_image, g.vit_patch, c->vit_grid, c->vit_kpad, c->v_col, st)); }
-    int rc = gemm(c, c->v_col, c->vit_kpad, c->patch_w, c->vit_kpad, c->patch_b, nullptr, 0, c->v_h, C, M, C, c->vit_kpad, EPI_NONE, 0, GEMM_AUTO, c->patch_w_p, true); if (rc) return rc;
-    { ProfScope ps(c, MMD_K_OTHER, 0, 0); HIPCHK(c, launch_add_rows(dt, c->v_h, c->pos_emb, M, C, T, st)); }
+    void* patch_out = g.vit_class_token ? c->v_patch : c->v_h;
+    int rc = gemm(c, c->v_col, c->vit_kpad, c->patch_w, c->vit_kpad, c->patch_b, nullptr, 0, patch_out, C, B * T, C, c->vit_kpad, EPI_NONE, 0, GEMM_AUTO, c->patch_w_p, true); if (rc) return rc;
+    if (g.vit_class_token) {
+        ProfScope ps(c, MMD_K_OTHER, 0, 0); HIPCHK(c, launch_assemble_cls(dt, c->v_patch, c->cls_emb, c->pos_emb, B, T, C, c->v_h, st));
+    } else {
+        ProfScope ps(c, MMD_K_OTHER, 0, 0); HIPCHK(c, launch_add_rows(dt, c->v_h, c->pos_emb, M, C, T, st));
+    }
+    if (g.vit_pre_layernorm) { HIPCHK(c, launch_layernorm(dt, c->v_h, c->pre_w, c->pre_b, c->v_h, M, C, g.vit_ln_eps, st)); }
     for (int i = 0; i < g.vit_layers; ++i) {
         VitLayer& L = c->VL[i];
         { ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * M * C * es(c), 0); HIPCHK(c, launch_layernorm(dt, c->v_h, L.ln1w, L.ln1b, c->v_xn, M, C, g.vit_ln_eps, st)); }
@@ -505,20 +546,87 @@ extern "C" int mmd_vit_encode(mmd_ctx* c, const void* px, int B, void* out) {
             AttnArgs a; memset(&a, 0, sizeof(a));
             a.q = c->v_qkv; a.ldq = 3 * C; a.K = (char*)c->v_qkv + (size_t)C * es(c); a.V = (char*)c->v_qkv + (size_t)2 * C * es(c);
             a.k_hs = hd; a.k_ts = 3 * C; a.v_hs = hd; a.v_ts = 3 * C; a.out = c->v_attn; a.ldo = C;
-            a.S = T; a.nh = g.vit_heads; a.nkv = g.vit_heads; a.d = hd; a.n_ctx = 0; a.causal = 0;
-            a.batch = B; a.q_bstride = (int64_t)T * 3 * C; a.kv_bstride = (int64_t)T * 3 * C; a.o_bstride = (int64_t)T * C;
+            a.S = TS; a.nh = g.vit_heads; a.nkv = g.vit_heads; a.d = hd; a.n_ctx = 0; a.causal = 0;
+            a.batch = B; a.q_bstride = (int64_t)TS * 3 * C; a.kv_bstride = (int64_t)TS * 3 * C; a.o_bstride = (int64_t)TS * C;
             a.ws = c->v_attn_ws; a.ws_bytes = c->v_attn_bytes; a.variant = 0;
-            ProfScope ps(c, MMD_K_ATTN_VIT, 4.0 * M * C * es(c), 4.0 * B * (double)T * T * C);
+            ProfScope ps(c, MMD_K_ATTN_VIT, 4.0 * M * C * es(c), 4.0 * B * (double)TS * TS * C);
             HIPCHK(c, launch_attention(dt, a, st));
         }
         rc = gemm(c, c->v_attn, C, L.wo, C, L.bo, c->v_h, C, c->v_h, C, M, C, C, EPI_RESID, 0, GEMM_AUTO, L.wo_p, true); if (rc) return rc;
         { ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * M * C * es(c), 0); HIPCHK(c, launch_layernorm(dt, c->v_h, L.ln2w, L.ln2b, c->v_xn, M, C, g.vit_ln_eps, st)); }
-        rc = gemm(c, c->v_xn, C, L.w1, C, L.b1, nullptr, 0, c->v_mlp, c->vit_ipad, M, c->vit_ipad, C, EPI_GELU_TANH, 0, GEMM_AUTO, L.w1_p, true); if (rc) return rc;
+        if (g.vit_act == 1) {      // CLIP quick_gelu: plain fc1, then x * sigmoid(1.702 x) on the storage-rounded output (secondary path: not fused)
+            rc = gemm(c, c->v_xn, C, L.w1, C, L.b1, nullptr, 0, c->v_mlp, c->vit_ipad, M, c->vit_ipad, C, EPI_NONE, 0, GEMM_AUTO, L.w1_p, true); if (rc) return rc;
+            HIPCHK(c, launch_quick_gelu(dt, c->v_mlp, (int64_t)M * c->vit_ipad, st));
+        } else {
+            rc = gemm(c, c->v_xn, C, L.w1, C, L.b1, nullptr, 0, c->v_mlp, c->vit_ipad, M, c->vit_ipad, C, EPI_GELU_TANH, 0, GEMM_AUTO, L.w1_p, true); if (rc) return rc;
+        }
         rc = gemm(c, c->v_mlp, c->vit_ipad, L.w2, c->vit_ipad, L.b2, c->v_h, C, c->v_h, C, M, C, c->vit_ipad, EPI_RESID, 0, GEMM_AUTO, L.w2_p, true); if (rc) return rc;
     }
     if (g.vit_post_layernorm) { HIPCHK(c, launch_layernorm(dt, c->v_h, c->post_w, c->post_b, c->v_h, M, C, g.vit_ln_eps, st)); }
     c->last_vit_B = B;
+    return MMD_OK;
+}
+
+extern "C" int mmd_vit_encode(mmd_ctx* c, const void* px, int B, void* out) {
+    NEED_FINAL(c);
+    if (B <= 0) return MMD_OK;
+    if (c->cfg.vision_only) FAIL(c, MMD_EINVAL, "vision-only context: use mmd_vision_tower");
+    int rc = vit_tower(c, px, B); if (rc) return rc;
     return connector_pool(c, c->v_h, B, out);
+}
+
+// ---- secondary encoder path (models/vision_live.py) -------------------------------------------------------------------------------------
+extern "C" int mmd_normalize_frames(mmd_ctx* c, const void* frames, int src_kind, int B, int R, const float* mean, const float* sd, float rescale, void* out) {
+    if (!c || !frames || !out || !mean || !sd || (src_kind != 0 && src_kind != 1)) return MMD_EINVAL;
+    hipSetDevice(c->device);
+    HIPCHK(c, launch_normalize_frames(c->cfg.dtype, frames, src_kind, B, R, rescale, mean, sd, out, c->stream));
+    return MMD_OK;
+}
+extern "C" int mmd_vision_tower(mmd_ctx* c, const void* px, int B, void* out) {
+    NEED_FINAL(c);
+    if (B <= 0) return MMD_OK;
+    if (!px || !out) return MMD_EINVAL;
+    int rc = vit_tower(c, px, B); if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(out, c->v_h, (size_t)B * c->vit_seq * c->cfg.vit_hidden * es(c), hipMemcpyDeviceToDevice, c->stream));
+    return MMD_OK;
+}
+// adaptive_avg_pool2d of the spatial token grid (class token, if any, skipped) -- models/vision_live.py:17-24,40-47
+extern "C" int mmd_vision_pool_tokens(mmd_ctx* c, const void* feats, int B, int out_h, int out_w, void* out) {
+    NEED_FINAL(c);
+    if (B <= 0) return MMD_OK;
+    if (!feats || !out || out_h <= 0 || out_h != out_w) FAIL(c, MMD_EINVAL, "pool target must be square (frame_token_pooled = [%d, %d])", out_h, out_w);
+    const int C = c->cfg.vit_hidden, T = c->vit_tokens, TS = c->vit_seq; const size_t e = es(c);
+    for (int b = 0; b < B; ++b) {      // one frame at a time: with a class token the spatial rows of a frame are not contiguous with the next frame's
+        const char* src = (const char*)feats + ((size_t)b * TS + (TS - T)) * C * e;
+        HIPCHK(c, launch_pool(c->cfg.dtype, src, (char*)out + (size_t)b * out_h * out_w * C * e, 1, c->vit_grid, C, MMD_POOL_ADAPTIVE_AVG, out_h, c->stream));
+    }
+    return MMD_OK;
+}
+// SiglipMultiheadAttentionPoolingHead.forward (siglip/modeling_siglip.py [3P]): probe attends over the sequence (nn.MultiheadAttention), then
+// residual + mlp(layernorm(.)); returns hidden_state[:, 0] -> [B, C]
+extern "C" int mmd_vision_pool_head(mmd_ctx* c, const void* feats, int B, void* out) {
+    NEED_FINAL(c);
+    if (B <= 0) return MMD_OK;
+    const mmd_config& g = c->cfg; const int dt = g.dtype; hipStream_t st = c->stream; const size_t e = es(c);
+    if (!g.vit_pool_head) FAIL(c, MMD_EINVAL, "this tower has no pooling head");
+    if (B > g.max_vit_batch) FAIL(c, MMD_ERANGE, "batch %d exceeds max_vit_batch %d", B, g.max_vit_batch);
+    const int C = g.vit_hidden, CI = g.vit_intermediate, TS = c->vit_seq, hd = C / g.vit_heads;
+    int rc = gemm(c, c->hd_probe, C, c->hd_wq, C, c->hd_bq, nullptr, 0, c->hd_q, C, 1, C, C, EPI_NONE, 0, GEMM_AUTO, nullptr, true); if (rc) return rc;
+    rc = gemm(c, feats, C, c->hd_wkv, C, c->hd_bkv, nullptr, 0, c->hd_kv, 2 * C, B * TS, 2 * C, C, EPI_NONE, 0, GEMM_AUTO, nullptr, true); if (rc) return rc;
+    {
+        AttnArgs a; memset(&a, 0, sizeof(a));
+        a.q = c->hd_q; a.ldq = C; a.K = c->hd_kv; a.V = (char*)c->hd_kv + (size_t)C * e;
+        a.k_hs = hd; a.k_ts = 2 * C; a.v_hs = hd; a.v_ts = 2 * C; a.out = c->hd_a; a.ldo = C;
+        a.S = 1; a.nh = g.vit_heads; a.nkv = g.vit_heads; a.d = hd; a.n_ctx = TS - 1; a.causal = 0;      // 1 query over n_ctx + S = TS keys
+        a.batch = B; a.q_bstride = 0; a.kv_bstride = (int64_t)TS * 2 * C; a.o_bstride = C;
+        a.ws = c->v_attn_ws; a.ws_bytes = c->v_attn_bytes; a.variant = 1;
+        HIPCHK(c, launch_attention(dt, a, st));
+    }
+    rc = gemm(c, c->hd_a, C, c->hd_wo, C, c->hd_bo, nullptr, 0, c->hd_h, C, B, C, C, EPI_NONE, 0, GEMM_AUTO, nullptr, true); if (rc) return rc;
+    HIPCHK(c, launch_layernorm(dt, c->hd_h, c->hd_lnw, c->hd_lnb, c->hd_n, B, C, g.vit_ln_eps, st));
+    rc = gemm(c, c->hd_n, C, c->hd_w1, C, c->hd_b1, nullptr, 0, c->hd_m, CI, B, CI, C, EPI_GELU_TANH, 0, GEMM_AUTO, nullptr, true); if (rc) return rc;
+    rc = gemm(c, c->hd_m, CI, c->hd_w2, CI, c->hd_b2, c->hd_h, C, out, C, B, C, CI, EPI_RESID, 0, GEMM_AUTO, nullptr, true); if (rc) return rc;
+    return MMD_OK;
 }
 
 // second half of LiveMixin.visual_embed (models/modeling_live.py:30-33): mm_projector (Linear, GELU(erf), Linear) -> post_projector_pooling
@@ -543,7 +651,7 @@ extern "C" int mmd_connector_pool(mmd_ctx* c, const void* tower_features, int B,
 
 extern "C" int mmd_vit_debug_tap(mmd_ctx* c, int stage, void* out, int64_t out_elems) {
     NEED_FINAL(c);
-    int64_t M = (int64_t)c->last_vit_B * c->vit_tokens;
+    int64_t M = (int64_t)c->last_vit_B * c->vit_seq;
     int64_t n = M * (stage == 0 ? c->cfg.vit_hidden : c->cfg.hidden_size);
     if (stage < 0 || stage > 1 || out_elems < n) FAIL(c, MMD_EINVAL, "bad tap request");
     HIPCHK(c, hipMemcpyAsync(out, stage == 0 ? c->v_h : c->v_p2, (size_t)n * es(c), hipMemcpyDeviceToDevice, c->stream));

@@ -694,3 +694,58 @@ hipError_t launch_letterbox(const uint8_t* src, int T_, int H, int W, int new_w,
     hipLaunchKernelGGL(letterbox_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, src, H, W, new_w, new_h, R, top, left, xtab, ytab, area2x, flip, pad, dst, total);
     return hipGetLastError();
 }
+
+// ---- secondary encoders (models/vision_live.py: HF SigLIP-L/16-384 and CLIP-L/14-336 towers) -----------------------------------------
+// torchvision normalize(frames * rescale, mean, std) (models/vision_live.py:13,36): uint8 or float [B,3,R,R] -> ctx dtype
+template <typename S, typename T>
+__global__ void normalize_frames_kernel(const S* __restrict__ in, long long per_ch, long long total, float rescale, float m0, float m1, float m2, float s0, float s1, float s2,
+                                        T* __restrict__ out) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int ch = (int)((i / per_ch) % 3);
+    const float mean = ch == 0 ? m0 : (ch == 1 ? m1 : m2), sd = ch == 0 ? s0 : (ch == 1 ? s1 : s2);
+    out[i] = from_f<T>(((float)in[i] * rescale - mean) / sd);
+}
+hipError_t launch_normalize_frames(int dtype, const void* in, int in_kind, int B, int R, float rescale, const float* mean, const float* sd, void* out, hipStream_t st) {
+    const long long per_ch = (long long)R * R, total = (long long)B * 3 * per_ch;
+    if (total <= 0) return hipSuccess;
+    dim3 grid(cdiv(total, 256)), block(256);
+#define NF(S, T) hipLaunchKernelGGL((normalize_frames_kernel<S, T>), grid, block, 0, st, (const S*)in, per_ch, total, rescale, mean[0], mean[1], mean[2], sd[0], sd[1], sd[2], (T*)out)
+    if (dtype == MMD_F32) { if (in_kind == 0) NF(uint8_t, float); else NF(float, float); }
+    else { if (in_kind == 0) NF(uint8_t, bf16_t); else NF(float, bf16_t); }
+#undef NF
+    return hipGetLastError();
+}
+// CLIPVisionEmbeddings.forward (clip/modeling_clip.py [3P]): cat(class_embedding, patch_embeds) + position_embedding; patch [B*T, C] -> out [B, 1+T, C]
+template <typename T>
+__global__ void assemble_cls_kernel(const T* __restrict__ patch, const T* __restrict__ cls, const T* __restrict__ pos, int Tk, int C, long long total, T* __restrict__ out) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    const long long row = i / C;
+    const int t = (int)(row % (Tk + 1));
+    const long long b = row / (Tk + 1);
+    const float v = t == 0 ? to_f<T>(cls[c]) : to_f<T>(patch[(b * Tk + (t - 1)) * C + c]);
+    out[i] = from_f<T>(v + to_f<T>(pos[(long long)t * C + c]));
+}
+hipError_t launch_assemble_cls(int dtype, const void* patch, const void* cls, const void* pos, int B, int Tk, int C, void* out, hipStream_t st) {
+    const long long total = (long long)B * (Tk + 1) * C;
+    if (total <= 0) return hipSuccess;
+    if (dtype == MMD_F32) hipLaunchKernelGGL(assemble_cls_kernel<float>, dim3(cdiv(total, 256)), dim3(256), 0, st, (const float*)patch, (const float*)cls, (const float*)pos, Tk, C, total, (float*)out);
+    else hipLaunchKernelGGL(assemble_cls_kernel<bf16_t>, dim3(cdiv(total, 256)), dim3(256), 0, st, (const bf16_t*)patch, (const bf16_t*)cls, (const bf16_t*)pos, Tk, C, total, (bf16_t*)out);
+    return hipGetLastError();
+}
+// quick_gelu (CLIP): x * sigmoid(1.702 x), in place on the (storage-rounded) fc1 output
+template <typename T>
+__global__ void quick_gelu_kernel(T* __restrict__ x, long long n) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = to_f<T>(x[i]);
+    x[i] = from_f<T>(v * (1.0f / (1.0f + __expf(-1.702f * v))));
+}
+hipError_t launch_quick_gelu(int dtype, void* x, int64_t n, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    if (dtype == MMD_F32) hipLaunchKernelGGL(quick_gelu_kernel<float>, dim3(cdiv(n, 256)), dim3(256), 0, st, (float*)x, (long long)n);
+    else hipLaunchKernelGGL(quick_gelu_kernel<bf16_t>, dim3(cdiv(n, 256)), dim3(256), 0, st, (bf16_t*)x, (long long)n);
+    return hipGetLastError();
+}
