@@ -128,11 +128,15 @@ int mmd_letterbox_frames(mmd_ctx* ctx, const uint8_t* frames, int T, int H, int 
 int mmd_embed_tokens(mmd_ctx* ctx, const int64_t* ids, int k, void* out);
 
 /* KV arena of one video stream; replaces the DynamicCache / legacy tuple cache handed around as `past_key_values`
- * (test/inference.py:183,239-240).  O(1) append and O(1) truncate; grows by reallocation beyond `initial_tokens`. */
+ * (test/inference.py:183,239-240; the reference regrows it by torch.cat every step).  O(1) append and O(1) truncate.  The arena is a
+ * VIRTUAL address range sized for MMDUET_KV_VIRTUAL_TOKENS (default 4 Mi tokens ~ the 288 GB limit of the 7B model) whose first
+ * mmd_kv_capacity tokens are backed by physical pages; growth maps more pages (hipMemCreate / hipMemMap) behind the same addresses --
+ * nothing is copied and no second arena ever exists.  (MMDUET_KV_NO_VMM=1: plain allocation, growth by reallocation + copy.) */
 int mmd_stream_create(mmd_ctx* ctx, int64_t initial_tokens, mmd_stream** out);
 void mmd_stream_destroy(mmd_stream* s);
 int64_t mmd_kv_len(const mmd_stream* s);
-int64_t mmd_kv_capacity(const mmd_stream* s);
+int64_t mmd_kv_capacity(const mmd_stream* s);             /* tokens backed by memory */
+int64_t mmd_kv_stride(const mmd_stream* s);               /* tokens per (layer, kv head) row of the address range */
 int mmd_kv_truncate(mmd_stream* s, int64_t new_len);      /* rollback: remove_assistant_turns (test/inference.py:265-269), speculative chunks */
 int mmd_stream_reset(mmd_stream* s);                      /* LiveInferForBenchmark.reset (test/inference.py:169-183: past_key_values = None): length 0, arena kept */
 int mmd_kv_debug_set_len(mmd_stream* s, int64_t n);       /* measurement aid: mark n slots live without computing them */

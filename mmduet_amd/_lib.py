@@ -61,6 +61,7 @@ _SIGS = {
     'mmd_stream_destroy': (None, [_VP]),
     'mmd_kv_len': (_I64, [_VP]),
     'mmd_kv_capacity': (_I64, [_VP]),
+    'mmd_kv_stride': (_I64, [_VP]),
     'mmd_kv_truncate': (_I, [_VP, _I64]),
     'mmd_kv_debug_set_len': (_I, [_VP, _I64]),
     'mmd_stream_reset': (_I, [_VP]),

@@ -92,8 +92,15 @@ struct mmd_ctx {
 
 struct mmd_stream {
     mmd_ctx* ctx;
-    void* K = nullptr; void* V = nullptr;      // [layers][nkv][cap][d]
+    void* K = nullptr; void* V = nullptr;      // [layers][nkv][cap][d]   (cap = the row STRIDE in tokens)
     int64_t cap = 0, len = 0;
+    // virtual-memory arena (default): K / V are address ranges reserved for `cap` tokens per (layer, kv head) row; physical pages back only the
+    // first `mapped` tokens of every row and are added chunk by chunk -- growth copies nothing and never needs a second arena
+    bool vmm = false;
+    int64_t mapped = 0, chunk_tokens = 0;
+    size_t va_bytes = 0;
+    std::vector<hipMemGenericAllocationHandle_t> handles;
+    std::vector<std::pair<void*, size_t>> maps;
 };
 
 #define FAIL(ctx, code, ...) do { char _b[512]; snprintf(_b, sizeof(_b), __VA_ARGS__); (ctx)->err = _b; return (code); } while (0)
@@ -789,13 +796,87 @@ extern "C" int mmd_embed_tokens(mmd_ctx* c, const int64_t* ids, int k, void* out
 
 static size_t kv_layer_elems(const mmd_ctx* c, int64_t cap) { return (size_t)c->cfg.num_kv_heads * cap * c->cfg.head_dim; }
 
+// Map physical pages behind tokens [s->mapped, upto) of every (layer, kv head) row of K and V (whole chunks).
+static int vmm_map_upto(mmd_ctx* c, mmd_stream* s, int64_t upto) {
+    const size_t e = es(c), tok_bytes = (size_t)c->cfg.head_dim * e;
+    const size_t rows = (size_t)c->cfg.num_layers * c->cfg.num_kv_heads, row_stride = (size_t)s->cap * tok_bytes;
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = c->device;
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
+    while (s->mapped < upto) {
+        if (s->mapped + s->chunk_tokens > s->cap) FAIL(c, MMD_ENOMEM, "KV arena: %lld tokens exceed the reserved virtual capacity %lld (MMDUET_KV_VIRTUAL_TOKENS)", (long long)upto, (long long)s->cap);
+        const size_t cb = (size_t)s->chunk_tokens * tok_bytes, off = (size_t)s->mapped * tok_bytes;
+        for (int kv = 0; kv < 2; ++kv)
+            for (size_t r = 0; r < rows; ++r) {
+                char* at = (char*)(kv ? s->V : s->K) + r * row_stride + off;
+                hipMemGenericAllocationHandle_t h;
+                hipError_t er = hipMemCreate(&h, cb, &prop, 0);
+                if (er != hipSuccess) { (void)hipGetLastError(); FAIL(c, MMD_ENOMEM, "KV arena: no physical memory for tokens %lld.. (%s)", (long long)s->mapped, hipGetErrorString(er)); }
+                er = hipMemMap(at, cb, 0, h, 0);
+                if (er == hipSuccess) er = hipMemSetAccess(at, cb, &acc, 1);
+                if (er != hipSuccess) { hipMemRelease(h); FAIL(c, MMD_EHIP, "KV arena: hipMemMap failed: %s", hipGetErrorString(er)); }
+                s->handles.push_back(h); s->maps.push_back({at, cb});
+                // key tiles may cover slots beyond the live length (their P is masked to 0): keep those slots finite
+                HIPCHK(c, hipMemsetAsync(at, 0, cb, c->stream));
+            }
+        s->mapped += s->chunk_tokens;
+    }
+    return MMD_OK;
+}
+static void vmm_release(mmd_stream* s) {
+    for (auto& m : s->maps) hipMemUnmap(m.first, m.second);
+    for (auto h : s->handles) hipMemRelease(h);
+    s->maps.clear(); s->handles.clear();
+    if (s->K) hipMemAddressFree(s->K, s->va_bytes);
+    if (s->V) hipMemAddressFree(s->V, s->va_bytes);
+    s->K = s->V = nullptr;
+}
+
 extern "C" int mmd_stream_create(mmd_ctx* c, int64_t initial_tokens, mmd_stream** out) {
     if (!c || !out) return MMD_EINVAL;
     hipSetDevice(c->device);
     if (initial_tokens < 256) initial_tokens = 256;
     initial_tokens = round_up(initial_tokens, 64);
     mmd_stream* s = new mmd_stream();
-    s->ctx = c; s->cap = initial_tokens; s->len = 0;
+    s->ctx = c; s->len = 0;
+    const size_t e = es(c), tok_bytes = (size_t)c->cfg.head_dim * e;
+    const size_t rows = (size_t)c->cfg.num_layers * c->cfg.num_kv_heads;
+    // --- virtual-memory arena: reserve the row stride once (default 4 Mi tokens = the HBM limit of the 7B model), back it on demand
+    const char* nv = getenv("MMDUET_KV_NO_VMM");
+    if (!(nv && nv[0] == '1')) {
+        hipMemAllocationProp prop = {};
+        prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = c->device;
+        size_t gran = 0;
+        if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) == hipSuccess && gran > 0) {
+            int64_t ct = 64; while (((size_t)ct * tok_bytes) % gran != 0) ct += 64;          // chunk = whole 64-token V blocks and whole pages
+            while ((size_t)ct * tok_bytes < ((size_t)2 << 20)) ct *= 2;                         // at least 2 MiB per row and step
+            const char* ev = getenv("MMDUET_KV_VIRTUAL_TOKENS");
+            int64_t vcap = ev ? atoll(ev) : ((int64_t)4 << 20);
+            if (vcap < initial_tokens) vcap = initial_tokens;
+            vcap = round_up(vcap, ct);
+            for (; vcap >= round_up(initial_tokens, ct); vcap = vcap > round_up(initial_tokens, ct) ? std::max(vcap / 2, round_up(initial_tokens, ct)) : 0) {
+                const size_t va = rows * (size_t)vcap * tok_bytes;
+                void *K = nullptr, *V = nullptr;
+                if (hipMemAddressReserve(&K, va, gran, nullptr, 0) == hipSuccess && hipMemAddressReserve(&V, va, gran, nullptr, 0) == hipSuccess) {
+                    s->vmm = true; s->K = K; s->V = V; s->cap = vcap; s->chunk_tokens = ct; s->va_bytes = va; s->mapped = 0;
+                    break;
+                }
+                if (K) hipMemAddressFree(K, va);
+                (void)hipGetLastError();
+                if (vcap == round_up(initial_tokens, ct)) break;
+            }
+        }
+        (void)hipGetLastError();
+        if (s->vmm) {
+            int rc = vmm_map_upto(c, s, initial_tokens);
+            if (rc) { std::string keep = c->err; vmm_release(s); delete s; c->err = keep; return rc; }
+            *out = s;
+            return MMD_OK;
+        }
+    }
+    // --- fallback: plain allocation, growth by reallocation + copy
+    s->cap = initial_tokens; s->mapped = initial_tokens;
     size_t bytes = kv_layer_elems(c, s->cap) * c->cfg.num_layers * es(c);
     hipError_t e1 = hipMalloc(&s->K, bytes), e2 = hipMalloc(&s->V, bytes);
     if (e1 != hipSuccess || e2 != hipSuccess) { if (s->K) hipFree(s->K); if (s->V) hipFree(s->V); delete s; FAIL(c, MMD_ENOMEM, "KV arena of %lld tokens (%zu bytes x2) does not fit", (long long)initial_tokens, bytes); }
@@ -808,11 +889,12 @@ extern "C" void mmd_stream_destroy(mmd_stream* s) {
     if (!s) return;
     hipSetDevice(s->ctx->device);
     hipStreamSynchronize(s->ctx->stream);
-    hipFree(s->K); hipFree(s->V);
+    if (s->vmm) vmm_release(s); else { hipFree(s->K); hipFree(s->V); }
     delete s;
 }
 extern "C" int64_t mmd_kv_len(const mmd_stream* s) { return s ? s->len : -1; }
-extern "C" int64_t mmd_kv_capacity(const mmd_stream* s) { return s ? s->cap : -1; }
+extern "C" int64_t mmd_kv_capacity(const mmd_stream* s) { return s ? s->mapped : -1; }          // tokens with memory behind them
+extern "C" int64_t mmd_kv_stride(const mmd_stream* s) { return s ? s->cap : -1; }                // row stride in tokens (= reserved virtual capacity)
 extern "C" int mmd_kv_truncate(mmd_stream* s, int64_t n) {
     if (!s) return MMD_EINVAL;
     if (n < 0 || n > s->len) FAIL(s->ctx, MMD_ERANGE, "kv_truncate(%lld) outside [0, %lld]", (long long)n, (long long)s->len);
@@ -834,7 +916,8 @@ extern "C" int mmd_kv_debug_set_len(mmd_stream* s, int64_t n) {
 }
 
 static int kv_reserve(mmd_ctx* c, mmd_stream* s, int64_t need) {
-    if (need <= s->cap) return MMD_OK;
+    if (need <= s->mapped) return MMD_OK;
+    if (s->vmm) return vmm_map_upto(c, s, need);            // growth = more pages behind the same addresses: no copy, no second arena
     int64_t ncap = s->cap * 2; while (ncap < need) ncap *= 2;
     size_t e = es(c);
     size_t bytes = kv_layer_elems(c, ncap) * c->cfg.num_layers * e;
@@ -860,7 +943,7 @@ static int kv_reserve(mmd_ctx* c, mmd_stream* s, int64_t need) {
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     hipFree(s->K); hipFree(s->V);
-    s->K = nK; s->V = nV; s->cap = ncap;
+    s->K = nK; s->V = nV; s->cap = ncap; s->mapped = ncap;
     return MMD_OK;
 }
 

@@ -145,11 +145,14 @@ def test_demo_driver_on_gpu_with_concurrent_query_thread(model_f32):
     assert all(0.0 <= o['informative_score'] <= 1.0 for o in outs1)
 
 
-def test_live_arena_growth_across_reallocations_matches_presized_arena():
-    """A LIVE KV arena that starts at 512 tokens and grows past 100 k tokens (>= 8 reallocations, each moving the K rows and the 64-token V^T
-    blocks of every layer) must hold exactly the context of an arena that was sized for the whole stream up front: identical head logits
-    (bit for bit -- same kernels, same data) at every probe and at the end."""
+@pytest.mark.parametrize('vmm', [True, False], ids=['virtual-memory', 'realloc'])
+def test_live_arena_growth_across_reallocations_matches_presized_arena(vmm, monkeypatch):
+    """A LIVE KV arena that starts at 512 tokens and grows past 100 k tokens must hold exactly the context of an arena that was sized for the whole
+    stream up front: identical head logits (bit for bit -- same kernels, same data) at every probe and at the end.  Both growth mechanisms:
+    the virtual-memory arena (pages mapped behind a fixed address range: no copy, never a second arena) and the fallback (>= 8 reallocations,
+    each moving the K rows and the 64-token V^T blocks of every layer)."""
     from helpers import hip_model
+    monkeypatch.setenv('MMDUET_KV_NO_VMM', '0' if vmm else '1')
     m_grow = hip_model('A', torch.bfloat16)[0]
     m_grow.kv_initial_tokens = 512
     m_big = hip_model('A', torch.bfloat16)[0]
@@ -171,7 +174,9 @@ def test_live_arena_growth_across_reallocations_matches_presized_arena():
             assert torch.equal(og.informative_logits[0, -1], ob.informative_logits[0, -1]), (step, total)
             assert torch.equal(og.hidden_states[0, -1], ob.hidden_states[0, -1])
     assert total > 100_000 and len(cg) == len(cb) == total
-    assert len(caps) >= 3 and max(caps) >= total and int(lib().mmd_kv_capacity(cb.arena.h)) >= 110_000       # the live arena really was reallocated >= 2 times
+    assert len(caps) >= (2 if vmm else 3) and max(caps) >= total and int(lib().mmd_kv_capacity(cb.arena.h)) >= 110_000       # the live arena really grew
+    stride = int(lib().mmd_kv_stride(cg.arena.h))
+    assert (stride >= (4 << 20)) if vmm else (stride == max(caps))      # virtual arena: the row stride is the reserved capacity, not what is backed
     # rollback into the grown arena and replay: same result as the first time
     mid = m_grow.cache_prefix(cg, total - 448)
     x = (torch.randn(1, 448, H, generator=torch.Generator(device='cuda').manual_seed(99), device='cuda') * 0.5).to(torch.bfloat16)
