@@ -5,7 +5,8 @@ The reference decodes videos with OpenCV inside its dataset class (test/datasets
 package, so `--test_fname` is a JSON list whose entries carry the already sampled, letter-boxed frames:
     {"question_id": ..., "frames": "clip0.npy" (uint8 [T,3,R,R], relative to --input_dir), "fps": 1.0,
      "video_duration": 30.0, "conversation": [{"role": "user", "content": "...", "time": 0.0}, ...]}
-An entry may instead carry the decoder's raw output -- "decoded": "clip0_raw.npy" (uint8 [N,H,W,3] BGR, decode order),
+An entry may carry "video": "clip0.avi" -- a Motion-JPEG or uncompressed AVI, decoded by mmduet_amd/video_decode.py (what cv2.VideoCapture
+provides to the reference's load_video) -- or the decoder's raw output -- "decoded": "clip0_raw.npy" (uint8 [N,H,W,3] BGR, decode order),
 "input_fps": 29.97[, "frame_count": header value] -- and the reference's sampling + letterbox (test/datasets.py:32-85) runs on the
 GPU (video_input.load_video_frames), `--time_instruction_format` included.  With `--features_dir DIR` an entry may carry
 "features": "clip0.pt" instead: a pre-extracted [T, tokens, C] feature file (mmduet_amd/features.py; the reference's offline extraction format,
@@ -45,10 +46,14 @@ def main(argv=None):
                 if args.max_num_frames:
                     feats = feats[:args.max_num_frames]
                 return feats, fps, ex.get('video_duration', len(feats) / fps), [{'role': 'system', 'content': args.system_prompt}] + conv
-            if 'decoded' in ex:
+            if 'video' in ex or 'decoded' in ex:
                 from .video_input import load_video_frames
-                raw = torch.from_numpy(np.load(os.path.join(args.input_dir, ex['decoded'])))
-                out = load_video_frames(infer.model, raw, ex['input_fps'], ex.get('frame_count'), output_fps=args.frame_fps,
+                if 'video' in ex:            # a container this package can read without a codec library (Motion-JPEG / uncompressed AVI, video_decode.py)
+                    from .video_decode import read_avi
+                    raw, in_fps, count = read_avi(os.path.join(args.input_dir, ex['video']))
+                else:
+                    raw, in_fps, count = torch.from_numpy(np.load(os.path.join(args.input_dir, ex['decoded']))), ex['input_fps'], ex.get('frame_count')
+                out = load_video_frames(infer.model, raw, in_fps, count, output_fps=args.frame_fps,
                                         resolution=args.frame_resolution, max_num_frames=args.max_num_frames,
                                         time_instruction_format=args.time_instruction_format)
                 frames, fps, duration = out[0], out[1], out[2]
