@@ -95,6 +95,10 @@ int64_t mmd_weight_bytes(const mmd_ctx* ctx);
 /* replaces LiveMixin.visual_embed (models/modeling_live.py:26-33): tower -> connector -> pooling.
  * pixel_values [B,3,img,img] in ctx dtype; out [B*frame_num_tokens, hidden] in ctx dtype. */
 int mmd_vit_encode(mmd_ctx* ctx, const void* pixel_values, int B, void* out);
+/* preprocess + visual_embed in one call: uint8 frames [B,3,R,R] (device) -> out [B*frame_num_tokens, hidden].  The last
+ * resampler pass writes the normalised pixels straight into the im2col matrix of the patch-embed GEMM; results are bit-identical to
+ * mmd_preprocess_frames followed by mmd_vit_encode. */
+int mmd_vit_encode_frames(mmd_ctx* ctx, const uint8_t* frames, int B, int R, void* out);
 /* second half of visual_embed for pre-extracted tower features (the reference's offline feature files, data/utils.py:99-117: per-video
  * [T, tokens, C] written from `vision_encode`; visual_embed without a tower starts at the connector, models/modeling_live.py:26-33):
  * tower_features [B, tokens, vit_hidden] (ctx dtype) -> mm_projector -> post_projector_pooling -> out [B*frame_num_tokens, hidden] */

@@ -49,6 +49,7 @@ _SIGS = {
     'mmd_vit_encode': (_I, [_VP, _VP, _I, _VP]),
     'mmd_vit_debug_tap': (_I, [_VP, _I, _VP, _I64]),
     'mmd_connector_pool': (_I, [_VP, _VP, _I, _VP]),
+    'mmd_vit_encode_frames': (_I, [_VP, _VP, _I, _I, _VP]),
     'mmd_normalize_frames': (_I, [_VP, _VP, _I, _I, _I, C.POINTER(_F), C.POINTER(_F), _F, _VP]),
     'mmd_vision_tower': (_I, [_VP, _VP, _I, _VP]),
     'mmd_vision_pool_tokens': (_I, [_VP, _VP, _I, _I, _I, _VP]),

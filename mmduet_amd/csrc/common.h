@@ -139,6 +139,8 @@ hipError_t launch_copy_rows(int dtype, const void* src, int64_t lds_, void* dst,
 hipError_t launch_interleave16(int dtype, const void* a, const void* b, void* out, int rows, int cols, hipStream_t st);
 hipError_t launch_pad_cols(int dtype, const void* src, int rows, int cols, void* dst, int cols_pad, hipStream_t st);
 hipError_t launch_lora_merge(int dtype, void* W, const float* A, const float* B, int out_f, int in_f, int r, float scale, hipStream_t st);
+hipError_t launch_preprocess_im2col(int dtype, const uint8_t* frames, int T, int R, int size, const int32_t* coef, const int32_t* bounds, int ksize,
+                                    uint8_t* tmp, int patch, int grid, int Kpad, void* out, hipStream_t st);
 hipError_t launch_normalize_frames(int dtype, const void* in, int in_kind /*0 uint8, 1 fp32*/, int B, int R, float rescale, const float* mean, const float* sd, void* out, hipStream_t st);
 hipError_t launch_assemble_cls(int dtype, const void* patch, const void* cls, const void* pos, int B, int Tk, int C, void* out, hipStream_t st);
 hipError_t launch_quick_gelu(int dtype, void* x, int64_t n, hipStream_t st);

@@ -531,12 +531,13 @@ static int alloc_workspaces(mmd_ctx* c) {
 
 // ---- vision ----------------------------------------------------------------------------------------------------------
 static int connector_pool(mmd_ctx* c, const void* feats, int B, void* out);
+static int ensure_preprocess_tables(mmd_ctx* c, int T, int R);
 // the tower: patch-embed (+ class token, + pre-LN for CLIP) -> encoder layers -> optional post_layernorm; result [B * vit_seq, C] in c->v_h
-static int vit_tower(mmd_ctx* c, const void* px, int B) {
+static int vit_tower(mmd_ctx* c, const void* px, int B, bool col_ready = false) {
     const mmd_config& g = c->cfg; const int dt = g.dtype; hipStream_t st = c->stream;
     if (B > g.max_vit_batch) FAIL(c, MMD_ERANGE, "vit batch %d exceeds max_vit_batch %d", B, g.max_vit_batch);
     const int C = g.vit_hidden, T = c->vit_tokens, TS = c->vit_seq, M = B * TS, hd = C / g.vit_heads;
-    { ProfScope ps(c, MMD_K_OTHER, 0, 0); HIPCHK(c, launch_im2col(dt, px, B, g.vit_image, g.vit_patch, c->vit_grid, c->vit_kpad, c->v_col, st)); }
+    if (!col_ready) { ProfScope ps(c, MMD_K_OTHER, 0, 0); HIPCHK(c, launch_im2col(dt, px, B, g.vit_image, g.vit_patch, c->vit_grid, c->vit_kpad, c->v_col, st)); }
     void* patch_out = g.vit_class_token ? c->v_patch : c->v_h;
     int rc = gemm(c, c->v_col, c->vit_kpad, c->patch_w, c->vit_kpad, c->patch_b, nullptr, 0, patch_out, C, B * T, C, c->vit_kpad, EPI_NONE, 0, GEMM_AUTO, c->patch_w_p, true); if (rc) return rc;
     if (g.vit_class_token) {
@@ -579,6 +580,23 @@ extern "C" int mmd_vit_encode(mmd_ctx* c, const void* px, int B, void* out) {
     if (B <= 0) return MMD_OK;
     if (c->cfg.vision_only) FAIL(c, MMD_EINVAL, "vision-only context: use mmd_vision_tower");
     int rc = vit_tower(c, px, B); if (rc) return rc;
+    return connector_pool(c, c->v_h, B, out);
+}
+
+// visual_embed straight from uint8 frames: image_processor.preprocess (test/inference.py:203) and the patch-embed load are one
+// pass -- the normalised pixels go from the Pillow-exact resampler directly into the im2col matrix of the patch GEMM; no pixel_values tensor exists.
+// frames uint8 [B,3,R,R] (device) -> out [B*frame_num_tokens, hidden]; bit-identical to mmd_preprocess_frames + mmd_vit_encode.
+extern "C" int mmd_vit_encode_frames(mmd_ctx* c, const uint8_t* frames, int B, int R, void* out) {
+    NEED_FINAL(c);
+    if (B <= 0) return MMD_OK;
+    if (!frames || !out) return MMD_EINVAL;
+    if (c->cfg.vision_only) FAIL(c, MMD_EINVAL, "vision-only context: use mmd_vision_tower");
+    if (B > c->cfg.max_vit_batch) FAIL(c, MMD_ERANGE, "vit batch %d exceeds max_vit_batch %d", B, c->cfg.max_vit_batch);
+    int rc = ensure_preprocess_tables(c, B, R); if (rc) return rc;
+    { ProfScope ps(c, MMD_K_OTHER, 0, 0);
+      HIPCHK(c, launch_preprocess_im2col(c->cfg.dtype, frames, B, R, c->cfg.vit_image, c->pp_coef, c->pp_bounds, c->pp_ksize, c->pp_tmp, c->cfg.vit_patch, c->vit_grid,
+                                         c->vit_kpad, c->v_col, c->stream)); }
+    rc = vit_tower(c, nullptr, B, true); if (rc) return rc;
     return connector_pool(c, c->v_h, B, out);
 }
 
@@ -692,10 +710,8 @@ static void pil_coeffs(int in_size, int out_size, std::vector<int32_t>& coef, st
     }
 }
 
-extern "C" int mmd_preprocess_frames(mmd_ctx* c, const uint8_t* frames, int T, int R, void* pixel_values) {
-    if (!c || !frames || !pixel_values) return MMD_EINVAL;
-    hipSetDevice(c->device);
-    if (T <= 0) return MMD_OK;
+// Pillow tap tables + scratch for frames of resolution R (cached per context)
+static int ensure_preprocess_tables(mmd_ctx* c, int T, int R) {
     const int size = c->cfg.vit_image;
     if (R != size && c->pp_R != R) {
         std::vector<int32_t> coef, bounds; int ks;
@@ -710,12 +726,20 @@ extern "C" int mmd_preprocess_frames(mmd_ctx* c, const uint8_t* frames, int T, i
     }
     size_t need = (size_t)T * 3 * R * size;
     if (R != size && need > c->pp_tmp_bytes) {
-        if (c->pp_tmp) dev_free(c, c->pp_tmp);
+        if (c->pp_tmp) { HIPCHK(c, hipStreamSynchronize(c->stream)); dev_free(c, c->pp_tmp); }
         int rc = dev_alloc(c, (void**)&c->pp_tmp, need, false); if (rc) return rc;
         c->pp_tmp_bytes = need;
     }
+    return MMD_OK;
+}
+
+extern "C" int mmd_preprocess_frames(mmd_ctx* c, const uint8_t* frames, int T, int R, void* pixel_values) {
+    if (!c || !frames || !pixel_values) return MMD_EINVAL;
+    hipSetDevice(c->device);
+    if (T <= 0) return MMD_OK;
+    int rc = ensure_preprocess_tables(c, T, R); if (rc) return rc;
     ProfScope ps(c, MMD_K_OTHER, 0, 0);
-    HIPCHK(c, launch_preprocess(c->cfg.dtype, frames, T, R, size, c->pp_coef, c->pp_bounds, c->pp_ksize, c->pp_tmp, pixel_values, c->stream));
+    HIPCHK(c, launch_preprocess(c->cfg.dtype, frames, T, R, c->cfg.vit_image, c->pp_coef, c->pp_bounds, c->pp_ksize, c->pp_tmp, pixel_values, c->stream));
     return MMD_OK;
 }
 

@@ -642,6 +642,54 @@ hipError_t launch_preprocess(int dtype, const uint8_t* frames, int T_, int R, in
 }
 
 
+// the last preprocess pass fused into the patch-embed load.  Same arithmetic as resize_v_norm_kernel (vertical Pillow pass,
+// 1/255, (x - .5)/.5, rounding to the model dtype), but the result is written straight into the im2col matrix of the patch-embed GEMM
+// ([B*grid*grid][Kpad], k = (channel, ky, kx)) instead of a [B,3,size,size] pixel_values tensor that im2col would read back.
+template <typename T>
+__global__ void resize_v_norm_im2col_kernel(const uint8_t* __restrict__ tmp, int R, int size, const int32_t* __restrict__ coef, const int32_t* __restrict__ bounds,
+                                            int ksize, int identity, int patch, int grid, int Kpad, T* __restrict__ out) {
+    const int row = blockIdx.x;                        // b*grid*grid + gy*grid + gx
+    const int b = row / (grid * grid), rem = row % (grid * grid), gy = rem / grid, gx = rem % grid;
+    const int K = 3 * patch * patch;
+    for (int k = threadIdx.x; k < Kpad; k += blockDim.x) {
+        T v = 0;
+        if (k < K) {
+            const int c = k / (patch * patch), r2 = k % (patch * patch), yy = gy * patch + r2 / patch, xx = gx * patch + r2 % patch;
+            const long long pl = (long long)b * 3 + c;
+            uint8_t px;
+            if (identity) px = tmp[(pl * R + yy) * size + xx];
+            else {
+                const int ymin = bounds[2 * yy], yn = bounds[2 * yy + 1];
+                const int32_t* kk = coef + (long long)yy * ksize;
+                int acc = 1 << 21;
+                for (int y = 0; y < yn; ++y) acc += (int)tmp[(pl * R + ymin + y) * size + xx] * kk[y];
+                px = clip8_fix(acc);
+            }
+            float f = (float)px * (1.0f / 255.0f);
+            f = (f - 0.5f) / 0.5f;
+            v = from_f<T>(f);
+        }
+        out[(long long)row * Kpad + k] = v;
+    }
+}
+hipError_t launch_preprocess_im2col(int dtype, const uint8_t* frames, int T_, int R, int size, const int32_t* coef, const int32_t* bounds, int ksize,
+                                    uint8_t* tmp, int patch, int grid, int Kpad, void* out, hipStream_t st) {
+    const long long planes = (long long)T_ * 3;
+    if (planes <= 0) return hipSuccess;
+    const int identity = (R == size);
+    const uint8_t* vsrc = frames;
+    if (!identity) {
+        const long long n1 = planes * R * size;
+        hipLaunchKernelGGL(resize_h_kernel, dim3(cdiv(n1, 256)), dim3(256), 0, st, frames, R, size, coef, bounds, ksize, tmp, planes);
+        vsrc = tmp;
+    }
+    const int rows = T_ * grid * grid;
+    if (dtype == MMD_F32) hipLaunchKernelGGL(resize_v_norm_im2col_kernel<float>, dim3(rows), dim3(256), 0, st, vsrc, R, size, coef, bounds, ksize, identity, patch, grid, Kpad, (float*)out);
+    else hipLaunchKernelGGL(resize_v_norm_im2col_kernel<bf16_t>, dim3(rows), dim3(256), 0, st, vsrc, R, size, coef, bounds, ksize, identity, patch, grid, Kpad, (bf16_t*)out);
+    return hipGetLastError();
+}
+
+
 // ---------------------------------------------------------------------------------------------------------------
 // letterbox -- the resize + pad + channel flip of the reference's load_video (test/datasets.py:52-71,
 // demo/liveinfer.py:32-51): cv2.resize(frame, (new_w, new_h)) [INTER_LINEAR, 8-bit], cv2.copyMakeBorder(constant),

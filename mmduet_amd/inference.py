@@ -130,6 +130,7 @@ class LiveInferForBenchmark:
         self.consecutive_n_frames = 0
         self._frame_batch = {}               # frame embedding (data_ptr) -> tower batch index, overlap mode
         self._vit_out = self._vit_pixels = None
+        self._vit_fused = False
         self._vit_batches, self._vit_events, self._vit_waited = [], [], set()
         self.forward_calls = 0              # LLM forwards issued (diagnostics of the chunked schedule)
         self.replayed_frames = 0
@@ -139,10 +140,18 @@ class LiveInferForBenchmark:
     def input_video_stream(self, video_frames):
         """All frames of the video at once (uint8 [T,3,R,R]); queues (time, [frame_num_tokens, hidden]) per frame."""
         overlap = self.overlap_vision and self.device.type == 'cuda'
+        # preprocess fused into the patch-embed load when the model offers it (visual_embed_frames: no pixel_values tensor, same bits)
+        fused = hasattr(self.model, 'visual_embed_frames') and torch.is_tensor(video_frames) and video_frames.dtype == torch.uint8
         if not overlap:
+            vb = _tower_batch(self.model)
+            if fused:
+                frames_dev = video_frames.to(self.device)
+                for b0 in range(0, len(frames_dev), vb):
+                    embeds = self.model.visual_embed_frames(frames_dev[b0:b0 + vb]).split(self.frame_num_tokens)
+                    self.frame_embeds_queue.extend(((r + b0) / self.frame_fps, f) for r, f in enumerate(embeds))
+                return
             pixel_values = self.image_processor.preprocess(video_frames, return_tensors='pt')['pixel_values']
             pixel_values = pixel_values.to(self.device).to(self.torch_dtype)
-            vb = _tower_batch(self.model)
             for b0 in range(0, len(pixel_values), vb):
                 embeds = self.model.visual_embed(pixel_values[b0:b0 + vb]).split(self.frame_num_tokens)
                 self.frame_embeds_queue.extend(((r + b0) / self.frame_fps, f) for r, f in enumerate(embeds))
@@ -161,8 +170,12 @@ class LiveInferForBenchmark:
         T, nt = len(video_frames), self.frame_num_tokens
         self._vit_out = torch.empty(T * nt, self.hidden_size, dtype=self.torch_dtype, device=self.device)
         side.wait_stream(main)
-        with torch.cuda.stream(side):
-            self._vit_pixels = self.image_processor.preprocess(video_frames, return_tensors='pt')['pixel_values'].to(self.torch_dtype)
+        self._vit_fused = fused
+        if fused:
+            self._vit_pixels = video_frames.to(self.device)             # the raw uint8 frames stay resident; each tower batch resamples its own
+        else:
+            with torch.cuda.stream(side):
+                self._vit_pixels = self.image_processor.preprocess(video_frames, return_tensors='pt')['pixel_values'].to(self.torch_dtype)
         vb = _tower_batch(self.model)
         self._vit_batches = [(b0, min(T, b0 + vb)) for b0 in range(0, T, vb)]
         self._vit_events, self._vit_waited = [], set()
@@ -178,7 +191,10 @@ class LiveInferForBenchmark:
         while len(self._vit_events) < min(upto, len(self._vit_batches)):
             b0, b1 = self._vit_batches[len(self._vit_events)]
             with torch.cuda.stream(self._vit_stream):
-                self.model.visual_embed(self._vit_pixels[b0:b1], out=self._vit_out[b0 * nt:b1 * nt])
+                if getattr(self, '_vit_fused', False):
+                    self.model.visual_embed_frames(self._vit_pixels[b0:b1], out=self._vit_out[b0 * nt:b1 * nt])
+                else:
+                    self.model.visual_embed(self._vit_pixels[b0:b1], out=self._vit_out[b0 * nt:b1 * nt])
                 ev = torch.cuda.Event()
                 ev.record(self._vit_stream)
             self._vit_events.append(ev)

@@ -353,6 +353,23 @@ class VideoHeadLiveLlavaQwenForCausalLM:
                 check(lib().mmd_vit_encode(self._ctx, _ptr(frames[b0:b1]), b1 - b0, _ptr(out[b0 * self.tokens_per_frame:])), self._ctx, 'mmd_vit_encode')
         return out
 
+    def visual_embed_frames(self, frames_u8: torch.Tensor, out: torch.Tensor = None):
+        """image_processor.preprocess + visual_embed (test/inference.py:203,211) in one native pass per tower batch: uint8 [B,3,R,R] -> [B*frame_num_tokens, hidden].
+        The resampled, normalised pixels are written straight into the patch-embed GEMM's operand (no pixel_values tensor); bit-identical to the two-call form."""
+        fr = torch.as_tensor(frames_u8)
+        if fr.dtype != torch.uint8 or fr.ndim != 4 or fr.shape[1] != 3 or fr.shape[2] != fr.shape[3]:
+            raise ValueError(f'expected uint8 frames [T,3,R,R], got {tuple(fr.shape)} {fr.dtype}')
+        fr = fr.to(self.device).contiguous()
+        B, R = fr.shape[0], fr.shape[2]
+        if out is None:
+            out = torch.empty(B * self.tokens_per_frame, self.config.hidden_size, dtype=self.dtype, device=self.device)
+        with self._lock:
+            self._bind_stream()
+            for b0 in range(0, B, self.max_vit_batch):
+                b1 = min(B, b0 + self.max_vit_batch)
+                check(lib().mmd_vit_encode_frames(self._ctx, _ptr(fr[b0:b1]), b1 - b0, R, _ptr(out[b0 * self.tokens_per_frame:])), self._ctx, 'mmd_vit_encode_frames')
+        return out
+
     def connector_pool(self, tower_features: torch.Tensor, out: torch.Tensor = None):
         """visual_embed for pre-extracted tower features [B, vit_tokens, vit_hidden] (models/modeling_live.py:26-33 without `vision_encode`):
         mm_projector -> post_projector_pooling -> [B*frame_num_tokens, hidden]."""

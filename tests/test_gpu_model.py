@@ -260,3 +260,19 @@ def test_preprocess_336_to_384_bit_exact():
     assert torch.equal(u8, torch.from_numpy(z['up336_resized_u8']))
     ref = (torch.from_numpy(z['up336_resized_u8']).float() * np.float32(1 / 255) - 0.5) / 0.5
     assert torch.equal(pv.cpu(), ref)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['f32', 'bf16'])
+@pytest.mark.parametrize('tag', ['same', 'up', 'down'])
+def test_fused_preprocess_patch_embed_is_bit_identical(dtype, tag):
+    """SURVEY section 8 f1: mmd_vit_encode_frames (resampler output written straight into the patch-embed operand) == preprocess -> visual_embed, bit for bit;
+    the Pillow-exact pixel fixture stays the pin of the arithmetic (test_gpu_ops.py::test_preprocess_bit_exact_with_pillow)."""
+    from conftest import load_npz
+    z = load_npz('preprocess.npz')
+    m = hip_model('A', dtype)[0]
+    fr = torch.from_numpy(z[f'{tag}_frames'])
+    two = m.visual_embed(m.get_vision_tower().image_processor.preprocess(fr)['pixel_values'])
+    one = m.visual_embed_frames(fr)
+    assert one.shape == two.shape and torch.equal(one, two)
+    big = torch.cat([fr] * 5)[:11]                       # more frames than one tower batch (max_vit_batch = 8 in the test model)
+    assert torch.equal(m.visual_embed_frames(big), m.visual_embed(m.get_vision_tower().image_processor.preprocess(big)['pixel_values']))
