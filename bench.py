@@ -38,6 +38,10 @@ CONFIGS = {
                       text='grounding mode (threshold 1: scores only, no generation), KV grows to 29.4 k tokens'),
     'qvh': dict(frames=150, responses=0, k=30, streams=1, mode='grounding',
                 text='QVHighlights-style 150-frame grounding streams, scores all-gathered over RCCL'),
+    # configs[4]: scripts/inference/youcook2.sh:12-14 (--stream_end_score_sum_threshold 2 --remove_assistant_turns true, 0.5 fps sampling of
+    # ~5-10 min cooking videos), fp8 e4m3 weights.  Responses are pinned to 12 seeded frames (a YouCook2 video has ~8 annotated steps).
+    'youcook2': dict(frames=600, responses=12, k=26, streams=1, mode='response', remove=True, weights='fp8',
+                     text='YouCook2-style dense captioning: running-sum decision rule, assistant turns removed from the context, fp8 e4m3 LLM weights'),
 }
 
 
@@ -88,7 +92,7 @@ def parse(argv=None):
     p.add_argument('--no-prof', action='store_true', help='do not bracket the dominant kernel with HIP events in the timed region')
     p.add_argument('--multi-stream', type=int, default=4, help='also measure S streams per GPU in shared forwards (reported under "multi_stream"; never the headline value; 0 = skip)')
     p.add_argument('--multi-frames-per-forward', type=int, default=13)
-    p.add_argument('--weights', choices=['bf16', 'fp8'], default='bf16', help='fp8 = e4m3 per-output-channel scaled LLM weights (BASELINE configs[4]); reported with dtype fp8, never the bf16 headline')
+    p.add_argument('--weights', choices=['bf16', 'fp8'], default=None, help='fp8 = e4m3 per-output-channel scaled LLM weights (BASELINE configs[4]); reported with dtype fp8, never the bf16 headline')
     p.add_argument('--phase', choices=['ab', 'b'], default='ab', help="'b': Phase B alone -- the frame embeddings come from a feature file written before the timed region (mmduet_amd/features.py); LLM-only frames/s, never the headline")
     p.add_argument('--layers', type=int, default=None, help='debug: override LLM layer count (INVALID as a measurement)')
     a = p.parse_args(argv)
@@ -98,6 +102,8 @@ def parse(argv=None):
     if a.frames_per_forward is None: a.frames_per_forward = c['k']
     if a.streams_per_gpu is None: a.streams_per_gpu = c['streams']
     a.mode = c['mode']
+    a.remove_turns = bool(c.get('remove', False))
+    if a.weights is None: a.weights = c.get('weights', 'bf16')
     if a.mode == 'grounding':
         a.responses = 0
     return a
@@ -168,7 +174,8 @@ def bench_driver_class():
 
 def driver_args(args, threshold, frames_per_forward=None):
     from mmduet_amd.arguments_live import LiveTestArguments
-    return LiveTestArguments(llm_pretrained='synthetic:bench', frame_fps=1.0, bf16=True, stream_end_prob_threshold=threshold,
+    rule = dict(stream_end_score_sum_threshold=1e9) if getattr(args, 'remove_turns', False) else dict(stream_end_prob_threshold=threshold)     # youcook2: the running-sum rule is the one evaluated
+    return LiveTestArguments(llm_pretrained='synthetic:bench', frame_fps=1.0, bf16=True, remove_assistant_turns=getattr(args, 'remove_turns', False), **rule,
                              score_heads='informative_score', max_new_tokens=args.max_new_tokens, grounding_mode=(args.mode == 'grounding'),
                              frames_per_forward=frames_per_forward or args.frames_per_forward, overlap_vision=not args.no_overlap,
                              system_prompt='A multimodal AI assistant is helping users with some activities.')
@@ -335,6 +342,14 @@ def main():
     model.prof_enable(False)
     prof_all = model.prof_read()
     dom = max(prof_all, key=lambda k: prof_all[k]['ms'])
+    # the tile-GEMM class (MFMA-bound: tower + LLM chunk GEMMs) and the weight-streaming class (HBM-bound: decode GEMV) are within a few per cent
+    # of each other on this workload; the roofline object stays on the MFMA class whenever it is within 20 % of the largest one (so the figure
+    # tracks one kernel family from round to round), the other class is reported under `roofline_secondary`
+    second = None
+    if dom != 'gemm_tile' and prof_all['gemm_tile']['ms'] >= 0.8 * prof_all[dom]['ms']:
+        dom, second = 'gemm_tile', dom
+    elif dom == 'gemm_tile' and prof_all['gemm_skinny']['ms'] >= 0.5 * prof_all[dom]['ms']:
+        second = 'gemm_skinny'
 
     def sync():
         torch.cuda.synchronize(device)
@@ -362,7 +377,7 @@ def main():
     prof_on = not args.no_prof
     model.prof_reset()
     model.prof_set_stride(args.prof_stride)                 # every 7th launch of the class carries the two HIP events (sampling)
-    model.prof_enable([dom] if prof_on else False)        # only the dominant class is bracketed inside the timed region
+    model.prof_enable([dom] + ([second] if second else []) if prof_on else False)        # only the dominant class(es) are bracketed inside the timed region
     sync()
     t0 = time.perf_counter()
     fwd = 0
@@ -420,6 +435,10 @@ def main():
             except Exception:
                 pass
         roof['per_class_ms_untimed_pass'] = {k: round(v['ms'], 1) for k, v in prof_all.items()}
+    roof2 = None
+    if prof_on and second and prof[second]['launches'] > 0:
+        roof2 = roof_from(prof[second], second)
+        roof2['sampling_stride'] = args.prof_stride
     cpu = None
     if rank == 0 and not (args.no_cpu_baseline or args.tiny or world > 1):
         cpu = cpu_baseline()
@@ -447,7 +466,7 @@ def main():
                        'kv_tokens_end': kv_end, 'weights': ('random init N(0,0.02), true shapes' if not args.tiny else 'tiny') + ('' if args.weights == 'bf16' else ', LLM matrices quantised to fp8 e4m3 per output channel'),
                        'parallelism': f'dp{world} ({S} stream(s) per GPU, one RCCL all-gather of the [{world},{S},{T}+1,2] score block per step)',
                        'native_gather_check': native, 'tower_overlap': not args.no_overlap, 'phase': 'A+B' if args.phase == 'ab' else 'B only (frame embeddings pre-extracted to a feature file; LLM side alone)', 'layers_override': args.layers},
-            'roofline': roof, 'cpu_baseline': cpu, 'multi_stream': multi,
+            'roofline': roof, 'roofline_secondary': roof2, 'cpu_baseline': cpu, 'multi_stream': multi,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

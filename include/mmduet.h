@@ -142,6 +142,10 @@ int64_t mmd_kv_len(const mmd_stream* s);
 int64_t mmd_kv_capacity(const mmd_stream* s);             /* tokens backed by memory */
 int64_t mmd_kv_stride(const mmd_stream* s);               /* tokens per (layer, kv head) row of the address range */
 int mmd_kv_truncate(mmd_stream* s, int64_t new_len);      /* rollback: remove_assistant_turns (test/inference.py:265-269), speculative chunks */
+/* set the KV of tokens [from, to) aside / bring it back (length becomes `to`): with remove_assistant_turns (test/inference.py:265-269) a response fired in
+ * the middle of a multi-frame chunk overwrites the slots behind it and is then dropped -- the frames already encoded behind it are restored, not recomputed */
+int mmd_kv_stash(mmd_stream* s, int64_t from, int64_t to);
+int mmd_kv_unstash(mmd_stream* s);
 int mmd_stream_reset(mmd_stream* s);                      /* LiveInferForBenchmark.reset (test/inference.py:169-183: past_key_values = None): length 0, arena kept */
 int mmd_kv_debug_set_len(mmd_stream* s, int64_t n);       /* measurement aid: mark n slots live without computing them */
 

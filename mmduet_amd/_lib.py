@@ -66,6 +66,8 @@ _SIGS = {
     'mmd_kv_truncate': (_I, [_VP, _I64]),
     'mmd_kv_debug_set_len': (_I, [_VP, _I64]),
     'mmd_stream_reset': (_I, [_VP]),
+    'mmd_kv_stash': (_I, [_VP, _I64, _I64]),
+    'mmd_kv_unstash': (_I, [_VP]),
     'mmd_comm_unique_id': (_I, [_VP]),
     'mmd_comm_create': (_I, [_VP, _I, _I, _I, _VP, C.POINTER(_VP)]),
     'mmd_comm_destroy': (None, [_VP]),

@@ -101,6 +101,8 @@ struct mmd_stream {
     size_t va_bytes = 0;
     std::vector<hipMemGenericAllocationHandle_t> handles;
     std::vector<std::pair<void*, size_t>> maps;
+    // stash of a token range (mmd_kv_stash / mmd_kv_unstash)
+    void* stash_k = nullptr; void* stash_v = nullptr; size_t stash_bytes = 0; int64_t stash_from = -1, stash_to = -1;
 };
 
 #define FAIL(ctx, code, ...) do { char _b[512]; snprintf(_b, sizeof(_b), __VA_ARGS__); (ctx)->err = _b; return (code); } while (0)
@@ -914,6 +916,7 @@ extern "C" void mmd_stream_destroy(mmd_stream* s) {
     hipSetDevice(s->ctx->device);
     hipStreamSynchronize(s->ctx->stream);
     if (s->vmm) vmm_release(s); else { hipFree(s->K); hipFree(s->V); }
+    if (s->stash_k) { hipFree(s->stash_k); hipFree(s->stash_v); }
     delete s;
 }
 extern "C" int64_t mmd_kv_len(const mmd_stream* s) { return s ? s->len : -1; }
@@ -923,6 +926,44 @@ extern "C" int mmd_kv_truncate(mmd_stream* s, int64_t n) {
     if (!s) return MMD_EINVAL;
     if (n < 0 || n > s->len) FAIL(s->ctx, MMD_ERANGE, "kv_truncate(%lld) outside [0, %lld]", (long long)n, (long long)s->len);
     s->len = n;
+    return MMD_OK;
+}
+
+// Set the KV of tokens [from, to) aside and bring it back later: lets a caller roll the arena back to `from`, run something that overwrites those slots
+// (a response whose turn is NOT kept in the context, remove_assistant_turns, test/inference.py:265-269) and then continue with the frames it had
+// already encoded behind `from` instead of recomputing them.  K rows are copied as they are; V travels in whole 64-token blocks (its layout), which
+// also carry -- unchanged -- the slots just below `from`.
+extern "C" int mmd_kv_stash(mmd_stream* s, int64_t from, int64_t to) {
+    if (!s) return MMD_EINVAL;
+    mmd_ctx* c = s->ctx;
+    if (from < 0 || to < from || to > s->len) FAIL(c, MMD_ERANGE, "kv_stash [%lld, %lld) outside the context (%lld tokens)", (long long)from, (long long)to, (long long)s->len);
+    hipSetDevice(c->device);
+    const size_t e = es(c), tok = (size_t)c->cfg.head_dim * e, rows = (size_t)c->cfg.num_layers * c->cfg.num_kv_heads, pitch = (size_t)s->cap * tok;
+    const int64_t b0 = from >> 6, b1 = (to + 63) >> 6;
+    const size_t wk = (size_t)(to - from) * tok, wv = (size_t)(b1 - b0) * 64 * tok;
+    if (rows * std::max(wk, wv) > s->stash_bytes) {
+        if (s->stash_k) { HIPCHK(c, hipStreamSynchronize(c->stream)); hipFree(s->stash_k); hipFree(s->stash_v); s->stash_k = s->stash_v = nullptr; }
+        s->stash_bytes = rows * std::max(wk, wv);
+        if (hipMalloc(&s->stash_k, s->stash_bytes) != hipSuccess || hipMalloc(&s->stash_v, s->stash_bytes) != hipSuccess) { s->stash_bytes = 0; FAIL(c, MMD_ENOMEM, "kv_stash: no memory for %zu bytes x2", rows * std::max(wk, wv)); }
+    }
+    if (wk) HIPCHK(c, hipMemcpy2DAsync(s->stash_k, wk, (const char*)s->K + (size_t)from * tok, pitch, wk, rows, hipMemcpyDeviceToDevice, c->stream));
+    if (wv) HIPCHK(c, hipMemcpy2DAsync(s->stash_v, wv, (const char*)s->V + (size_t)b0 * 64 * tok, pitch, wv, rows, hipMemcpyDeviceToDevice, c->stream));
+    s->stash_from = from; s->stash_to = to;
+    return MMD_OK;
+}
+extern "C" int mmd_kv_unstash(mmd_stream* s) {
+    if (!s) return MMD_EINVAL;
+    mmd_ctx* c = s->ctx;
+    if (s->stash_from < 0) FAIL(c, MMD_EINVAL, "kv_unstash without a stash");
+    hipSetDevice(c->device);
+    const int64_t from = s->stash_from, to = s->stash_to;
+    int rc = kv_reserve(c, s, to); if (rc) return rc;
+    const size_t e = es(c), tok = (size_t)c->cfg.head_dim * e, rows = (size_t)c->cfg.num_layers * c->cfg.num_kv_heads, pitch = (size_t)s->cap * tok;
+    const int64_t b0 = from >> 6, b1 = (to + 63) >> 6;
+    const size_t wk = (size_t)(to - from) * tok, wv = (size_t)(b1 - b0) * 64 * tok;
+    if (wk) HIPCHK(c, hipMemcpy2DAsync((char*)s->K + (size_t)from * tok, pitch, s->stash_k, wk, wk, rows, hipMemcpyDeviceToDevice, c->stream));
+    if (wv) HIPCHK(c, hipMemcpy2DAsync((char*)s->V + (size_t)b0 * 64 * tok, pitch, s->stash_v, wv, wv, rows, hipMemcpyDeviceToDevice, c->stream));
+    s->len = to; s->stash_from = s->stash_to = -1;
     return MMD_OK;
 }
 

@@ -92,6 +92,7 @@ class LiveInferForBenchmark:
         self.repetition_penalty = args.repetition_penalty
         self.frames_per_forward = max(1, int(getattr(args, 'frames_per_forward', 1)))
         self.overlap_vision = bool(getattr(args, 'overlap_vision', True))
+        self.reuse_chunk_tail = True             # remove_assistant_turns: keep the chunk's frames behind a response instead of replaying them (same context)
         self._vit_stream = None
         self.vit_lookahead_batches = None      # None: the whole video is queued on the tower stream at once
 
@@ -374,17 +375,27 @@ class LiveInferForBenchmark:
                 self.debug_data_list.append(dict(time=self.video_time, **video_scores))
                 # 3./4. decide, respond
                 if self._decide(video_scores):
-                    # context = everything up to the end of frame j; later frames of the chunk are replayed
-                    self.past_key_values = cache if j == k - 1 else self.model.cache_prefix(arena_handle, ends[j])
-                    for item in reversed(chunk[j + 1:]):
-                        self.frame_embeds_queue.appendleft(item)
-                    self.replayed_frames += k - 1 - j
+                    last = j == k - 1
+                    # remove_assistant_turns: the response never stays in the context, so the frames of this chunk behind frame j are still what a
+                    # replay would compute -- set their KV aside, let the response use (and drop) those slots, bring them back, go on deciding
+                    keep_tail = (not last) and self.remove_assistant_turns and self.reuse_chunk_tail and hasattr(self.model, 'kv_stash')
+                    if keep_tail:
+                        stash = self.model.kv_stash(cache, ends[j])
+                    # context = everything up to the end of frame j; otherwise later frames of the chunk are replayed
+                    self.past_key_values = cache if last else self.model.cache_prefix(arena_handle, ends[j])
+                    if not last and not keep_tail:
+                        for item in reversed(chunk[j + 1:]):
+                            self.frame_embeds_queue.appendleft(item)
+                        self.replayed_frames += k - 1 - j
                     response = self._generate_response()
                     self.response_token_ids.append(self.last_generated_ids)
                     model_response_list.append({'time': self.video_time, 'content': response, 'role': 'assistant'})
                     self.num_frames_no_reply = 0
                     self.consecutive_n_frames = 0
                     self.video_time += 1 / self.frame_fps
+                    if keep_tail:
+                        cache = arena_handle = self.model.kv_unstash(stash)
+                        continue
                     break
                 # 5. advance the clock
                 self.video_time += 1 / self.frame_fps

@@ -441,6 +441,24 @@ class VideoHeadLiveLlavaQwenForCausalLM:
             raise ValueError('prefix longer than the context')
         return KVCacheHandle(handle.arena, length)
 
+    def kv_stash(self, handle: KVCacheHandle, start: int):
+        """Set the KV of tokens [start, len(handle)) aside (device copy, stream-ordered); `kv_unstash` brings them back after something else used those slots."""
+        if handle.stale:
+            raise RuntimeError('stale KV handle')
+        with self._lock:
+            self._bind_stream()
+            check(lib().mmd_kv_stash(handle.arena.h, int(start), int(handle.length)), self._ctx, 'mmd_kv_stash')
+        return (handle.arena, int(start), int(handle.length))
+
+    def kv_unstash(self, stash):
+        """-> a handle denoting the context as it was when `kv_stash` was called (everything below `start` must be unchanged since)."""
+        arena, start, end = stash
+        with self._lock:
+            arena.truncate(min(arena.length(), start))
+            self._bind_stream()
+            check(lib().mmd_kv_unstash(arena.h), self._ctx, 'mmd_kv_unstash')
+        return KVCacheHandle(arena, end)
+
     def new_cache(self, initial_tokens=None):
         return KVCacheHandle(_KVArena(self, initial_tokens or self.kv_initial_tokens), 0)
 

@@ -239,3 +239,29 @@ def test_cli_reads_feature_files(tmp_path, monkeypatch):
     assert outs[0] == outs[1] and len(outs[0]) == 2
     for a, b in zip(outs[1], outs[2]):                         # shared forwards: same records up to the 3-digit score rounding
         assert a['model_response_list'] == b['model_response_list'] and len(a['debug_data']) == len(b['debug_data'])
+
+
+@pytest.mark.parametrize('name', ['sum_remove', 'sum_remove_pen'])
+def test_remove_turns_mode_keeps_the_chunk_tail_instead_of_replaying(model_f32, name):
+    """remove_assistant_turns: a response in the middle of a multi-frame chunk does not stay in the context, so the frames behind it are restored from a KV stash
+    (mmd_kv_stash / mmd_kv_unstash) instead of being recomputed.  Same records as the replaying schedule and as the reference driver; no frame is replayed."""
+    case = META['cases'][name]
+    runs = {}
+    for reuse in (True, False):
+        orig = LiveInferForBenchmark.__init__
+
+        def patched(self, *a, _reuse=reuse, **k):
+            orig(self, *a, **k)
+            self.reuse_chunk_tail = _reuse
+        LiveInferForBenchmark.__init__ = patched
+        try:
+            runs[reuse] = run_stream_case(LiveInferForBenchmark, model_f32, name, case, META, frames_per_forward=5)
+        finally:
+            LiveInferForBenchmark.__init__ = orig
+    a, b = runs[True], runs[False]
+    assert a.replayed_frames == 0 and b.replayed_frames > 0 and case['n_responses'] > 0
+    assert a.response_token_ids == b.response_token_ids == case['generated']
+    assert len(a.past_key_values) == len(b.past_key_values) == case['final_kv_len']
+    for x, y, ref in zip(a.debug_data_list, b.debug_data_list, case['debug_data']):
+        assert x['informative_score'] == pytest.approx(y['informative_score'], abs=1e-5) == pytest.approx(ref['informative_score'], abs=2e-4)
+    assert a.forward_calls < b.forward_calls
