@@ -929,6 +929,7 @@ extern "C" int mmd_kv_truncate(mmd_stream* s, int64_t n) {
     return MMD_OK;
 }
 
+static int kv_reserve(mmd_ctx* c, mmd_stream* s, int64_t need);
 // Set the KV of tokens [from, to) aside and bring it back later: lets a caller roll the arena back to `from`, run something that overwrites those slots
 // (a response whose turn is NOT kept in the context, remove_assistant_turns, test/inference.py:265-269) and then continue with the frames it had
 // already encoded behind `from` instead of recomputing them.  K rows are copied as they are; V travels in whole 64-token blocks (its layout), which
