@@ -947,8 +947,9 @@ extern "C" int mmd_kv_stash(mmd_stream* s, int64_t from, int64_t to) {
         s->stash_bytes = rows * std::max(wk, wv);
         if (hipMalloc(&s->stash_k, s->stash_bytes) != hipSuccess || hipMalloc(&s->stash_v, s->stash_bytes) != hipSuccess) { s->stash_bytes = 0; FAIL(c, MMD_ENOMEM, "kv_stash: no memory for %zu bytes x2", rows * std::max(wk, wv)); }
     }
-    if (wk) HIPCHK(c, hipMemcpy2DAsync(s->stash_k, wk, (const char*)s->K + (size_t)from * tok, pitch, wk, rows, hipMemcpyDeviceToDevice, c->stream));
-    if (wv) HIPCHK(c, hipMemcpy2DAsync(s->stash_v, wv, (const char*)s->V + (size_t)b0 * 64 * tok, pitch, wv, rows, hipMemcpyDeviceToDevice, c->stream));
+    // (strided copy kernel: hipMemcpy2D rejects the GiB-scale row pitch of the virtual-memory arena)
+    if (wk) HIPCHK(c, launch_copy_rows(MMD_F32, (const char*)s->K + (size_t)from * tok, (int64_t)(pitch / 4), s->stash_k, (int64_t)(wk / 4), (int)rows, (int)(wk / 4), c->stream));
+    if (wv) HIPCHK(c, launch_copy_rows(MMD_F32, (const char*)s->V + (size_t)b0 * 64 * tok, (int64_t)(pitch / 4), s->stash_v, (int64_t)(wv / 4), (int)rows, (int)(wv / 4), c->stream));
     s->stash_from = from; s->stash_to = to;
     return MMD_OK;
 }
@@ -962,8 +963,8 @@ extern "C" int mmd_kv_unstash(mmd_stream* s) {
     const size_t e = es(c), tok = (size_t)c->cfg.head_dim * e, rows = (size_t)c->cfg.num_layers * c->cfg.num_kv_heads, pitch = (size_t)s->cap * tok;
     const int64_t b0 = from >> 6, b1 = (to + 63) >> 6;
     const size_t wk = (size_t)(to - from) * tok, wv = (size_t)(b1 - b0) * 64 * tok;
-    if (wk) HIPCHK(c, hipMemcpy2DAsync((char*)s->K + (size_t)from * tok, pitch, s->stash_k, wk, wk, rows, hipMemcpyDeviceToDevice, c->stream));
-    if (wv) HIPCHK(c, hipMemcpy2DAsync((char*)s->V + (size_t)b0 * 64 * tok, pitch, s->stash_v, wv, wv, rows, hipMemcpyDeviceToDevice, c->stream));
+    if (wk) HIPCHK(c, launch_copy_rows(MMD_F32, s->stash_k, (int64_t)(wk / 4), (char*)s->K + (size_t)from * tok, (int64_t)(pitch / 4), (int)rows, (int)(wk / 4), c->stream));
+    if (wv) HIPCHK(c, launch_copy_rows(MMD_F32, s->stash_v, (int64_t)(wv / 4), (char*)s->V + (size_t)b0 * 64 * tok, (int64_t)(pitch / 4), (int)rows, (int)(wv / 4), c->stream));
     s->len = to; s->stash_from = s->stash_to = -1;
     return MMD_OK;
 }
