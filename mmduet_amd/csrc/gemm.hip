@@ -602,6 +602,13 @@ static void launch_gemv16(const GemmP& p, const GemmArgs& a, hipStream_t st) {
         ksplit = cdiv(768, ntiles); if (ksplit > 4) ksplit = 4;
         while (ksplit > 1 && (size_t)ksplit * a.M * a.N * sizeof(float) > a.splitk_ws_bytes) --ksplit;
     }
+    else if (a.slabs_out && ntiles < 512 && a.splitk_ws) {
+        // short K, few n-tiles (qkv, o at decode): one block per n-tile is latency-bound (8.0 / 6.4 us for 33 / 26 MB); two K slabs halve each wave's
+        // dependent load chain: 6.7 / 5.3 us (fp8: 6.0 / 5.2 -> 4.7 / 4.1); the slab consumers sum them for free.  MMDUET_GEMV_KSPLIT_SHORT overrides (1..4)
+        static const int ks_short = getenv("MMDUET_GEMV_KSPLIT_SHORT") ? atoi(getenv("MMDUET_GEMV_KSPLIT_SHORT")) : 2;
+        ksplit = ks_short < 1 ? 1 : (ks_short > 4 ? 4 : ks_short);
+        while (ksplit > 1 && (size_t)ksplit * a.M * a.N * sizeof(float) > a.splitk_ws_bytes) --ksplit;
+    }
     if (a.slabs_out) *a.slabs_out = ksplit;
     set_plan(a, GEMM_K_GEMV16, ntiles, ksplit, (a.epi == EPI_SWIGLU || (ntiles % 2 == 0 && ntiles >= 2048) ? ntiles / 2 : ntiles) * ksplit);
     const bool two = a.epi == EPI_SWIGLU || (ntiles % 2 == 0 && ntiles >= 2048);

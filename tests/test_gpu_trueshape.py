@@ -139,13 +139,17 @@ for S in (49, 1, 30):
 print("RES " + json.dumps(res))
 '''
     from conftest import ROOT
-    outs = []
-    for nf in ('0', '1'):
-        env = dict(os.environ, MMD_ROOT=ROOT, MMDUET_NO_FUSE=nf)
+    def run(**kw):
+        env = dict(os.environ, MMD_ROOT=ROOT, **kw)
         r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
-        outs.append(json.loads([l for l in r.stdout.splitlines() if l.startswith('RES ')][0][4:]))
-    assert outs[0] == outs[1]           # bit-identical: same reduction order, same rounding points
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith('RES ')][0][4:])
+    # one K slab per decode GEMV: same reduction order, same rounding points -> bit-identical
+    assert run(MMDUET_NO_FUSE='0', MMDUET_GEMV_KSPLIT_SHORT='1') == run(MMDUET_NO_FUSE='1', MMDUET_GEMV_KSPLIT_SHORT='1')
+    # the shipped schedule sums the decode qkv / o products in two fp32 K slabs: a different summation order, bf16-rounding-level apart
+    a, b = run(MMDUET_NO_FUSE='0'), run(MMDUET_NO_FUSE='1')
+    for ra, rb in zip(a, b):
+        assert ra == pytest.approx(rb, abs=2e-2, rel=2e-2)
 
 
 def test_multi_stream_step_true_shape(true_shape):
