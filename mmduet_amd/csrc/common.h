@@ -85,6 +85,18 @@ enum { EPI_NONE = 0, EPI_GELU_TANH = 1, EPI_GELU_ERF = 2, EPI_RESID = 3, EPI_SWI
 enum { GEMM_AUTO = 0, GEMM_GENERIC = 1, GEMM_SKINNY = 2, GEMM_LARGE = 3, GEMM_BIG = 4, GEMM_SLAB = 5, GEMM_RING256 = 6, GEMM_RING256_SPLIT = 7,
        GEMM_RINGX = 16 /* + 1: 4-wave 256x128 blocks, + 2: 32x32x16 MFMA, + 4: split K */ };
 
+// Decode chain of the weight-streaming GEMV (M <= 16, bf16): the residual add + RMSNorm between two GEMVs costs a launch and a cold, dependent
+// load chain of its own (5.5 us + a kernel boundary, twice per layer at decode).  Instead
+//   * the PRODUCER (o_proj / down_proj) owns an n-tile over all of K (one 16-wave block per tile, K split over the waves, LDS reduce) and folds
+//     its result into the residual stream itself: h = rnd(rnd(x W^T) + h), leaving that tile's per-row sum of h^2 in ssq[m][tile];
+//   * the CONSUMER (qkv / gate_up) never reads a normalised activation: every lane builds its X fragment as rnd(gamma * rnd(h * inv)),
+//     inv = rsqrt(sum(ssq[m][:]) / K + eps) summed in a fixed order (deterministic; same rounding points as slab_resid_rmsnorm_kernel).
+constexpr int GEMV_SSQ_STRIDE = 256;   // floats per row in ssq (n-tiles of 16 columns: N <= 4096)
+constexpr int GEMV_CHAIN_ROWS = 4;     // rows a consumer keeps in LDS; K <= 4096
+struct GemvChain {
+    const void* xn_h = nullptr; const void* xn_gamma = nullptr; const float* xn_ssq = nullptr; float xn_eps = 0.f;     // consumer side
+    void* fin_h = nullptr; float* fin_ssq = nullptr;                                                                     // producer side
+};
 struct GemmArgs {
     const void* X; int64_t ldx;      // [M,K]
     const void* W; int64_t ldw;      // [N,K]  (nn.Linear layout); may be null when only Wp exists
@@ -102,6 +114,7 @@ struct GemmArgs {
     int no_gemv = 0;                            // A/B switch: use the LDS-staged skinny kernel also for M <= 16
     int* slabs_out = nullptr;                   // if set (packed skinny path only): leave [splits][M][N] fp32 slabs in splitk_ws, no
                                                 // epilogue, and return the split count here; a fused consumer kernel reduces them
+    const GemvChain* chain = nullptr;           // gemv16 path only (M <= 16, packed bf16 / fp8 weights); see GemvChain
     int* plan_out = nullptr;                    // if set: int[4] = {kernel (GEMM_K_*), output tiles, K splits, blocks launched}
 };
 // which kernel the dispatcher chose (mmd_op_gemm_last_plan; parity tests assert the production kernel really ran)

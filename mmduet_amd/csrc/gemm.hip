@@ -475,50 +475,93 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmP p, int KT, int k
 // operands directly.  The four partial accumulators meet in LDS once; wave 0 applies the epilogue (or leaves ONE fp32
 // slab for the fused consumer): no split-K slabs, no reduce launch.
 // ------------------------------------------------------------------------------------------------------------------
-template <int NT, int U, bool W8 = false>
-__global__ __launch_bounds__(256) void gemm_gemv16_kernel(GemmP p, int KT) {
-    __shared__ __attribute__((aligned(16))) float red[3][NT][64][4];
+// x fragment of the decode chain: rnd(gamma * rnd(h * inv)) (Qwen2RMSNorm's rounding points)
+__device__ __forceinline__ s16x8_t chain_norm8(const s16x8_t& h, const s16x8_t& g, float inv) {
+    s16x8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (short)f2bf(bf2f((bf16_t)g[e]) * bf2f(f2bf(bf2f((bf16_t)h[e]) * inv)));
+    return o;
+}
+
+template <int NT, int U, bool W8 = false, bool CHAIN = false, int WAVES = 4>
+__global__ __launch_bounds__(WAVES * 64) void gemm_gemv16_kernel(GemmP p, int KT, GemvChain ch) {
+    __shared__ __attribute__((aligned(16))) float red[WAVES - 1][NT][64][4];
+    // consumer side of the decode chain: each wave keeps the normalised activation of ITS K range here (rows <= GEMV_CHAIN_ROWS, <= 1024 k per wave)
+    constexpr int XW = 1024;
+    __shared__ __attribute__((aligned(16))) bf16_t xs[(CHAIN && WAVES == 4) ? WAVES * GEMV_CHAIN_ROWS * XW : 8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4;
     const int nt0 = blockIdx.x * NT;
-    // K range of this block (grid.y splits K into slabs when N alone gives too few blocks), then of this wave
-    const int ktb = (KT + gridDim.y - 1) / gridDim.y;
-    const int blk_beg = blockIdx.y * ktb, blk_end = min(KT, blk_beg + ktb);
-    const int ktw = (blk_end - blk_beg + 3) >> 2;
-    const int kt_beg = blk_beg + wave * ktw, kt_end = min(blk_end, kt_beg + ktw);
-    const bf16_t* Wp = (const bf16_t*)p.W;
+    // K range of this block (grid.y splits K into slabs when N alone gives too few blocks), then of this wave; in k-tiles of 32 (fp8: pairs of tiles)
+    constexpr int KG = W8 ? 2 : 1;
+    const int KTg = KT / KG;
+    const int ktb = (KTg + gridDim.y - 1) / gridDim.y;
+    const int blk_beg = blockIdx.y * ktb, blk_end = min(KTg, blk_beg + ktb);
+    const int ktw = (blk_end - blk_beg + WAVES - 1) / WAVES;
+    const int kt_beg = blk_beg + wave * ktw, kt_end = min(blk_end, kt_beg + ktw);      // units of KG k-tiles
+    const bool xn = CHAIN && WAVES == 4 && ch.xn_h != nullptr;        // X built from the residual stream (see GemvChain)
     const bf16_t* xrow = (const bf16_t*)p.X + (long long)lr * p.ldx + lq * 8;
+    const bf16_t* xl = xs + (wave * GEMV_CHAIN_ROWS + lr) * XW + lq * 8 - kt_beg * (32 * KG);     // + k: this wave's copy of row lr
     const bool row_ok = lr < p.M;
 
     f32x4_t acc[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[j] = f32x4_t{0, 0, 0, 0};
 
+    // chain prologue, run by each wave AFTER its first weight loads are issued: 1/rms of every row from the producer's per-n-tile partial sums
+    // (lane l takes entries 4l..4l+3; fixed order), then rnd(gamma * rnd(h * inv)) of the wave's K range into LDS
+    auto chain_prologue = [&]() {
+        const int k0 = kt_beg * (32 * KG), kn = (kt_end - kt_beg) * (32 * KG);
+        for (int r = 0; r < p.M; ++r) {
+            const f32x4_t q = *reinterpret_cast<const f32x4_t*>(ch.xn_ssq + r * GEMV_SSQ_STRIDE + lane * 4);
+            s16x8_t hv[2], gv[2];
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps) {
+                const int k = ps * 512 + lane * 8;
+                hv[ps] = s16x8_t{0, 0, 0, 0, 0, 0, 0, 0}; gv[ps] = hv[ps];
+                if (k < kn) {
+                    hv[ps] = *reinterpret_cast<const s16x8_t*>((const bf16_t*)ch.xn_h + (long long)r * p.K + k0 + k);
+                    gv[ps] = *reinterpret_cast<const s16x8_t*>((const bf16_t*)ch.xn_gamma + k0 + k);
+                }
+            }
+            const float inv = rsqrtf(wave_sum((q[0] + q[1]) + (q[2] + q[3])) / (float)p.K + ch.xn_eps);
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps) {
+                const int k = ps * 512 + lane * 8;
+                if (k < kn) *reinterpret_cast<s16x8_t*>(xs + (wave * GEMV_CHAIN_ROWS + r) * XW + k) = chain_norm8(hv[ps], gv[ps], inv);
+            }
+        }
+    };
+
     if constexpr (W8) {
         // fp8 weights: K ranges are in 64-k pairs; a 1 KiB load feeds two MFMAs; U/2 loads per n-tile in flight
         const uint8_t* W8p = (const uint8_t*)p.W;
         const int KP = KT >> 1;
-        const int kpb = (KP + gridDim.y - 1) / gridDim.y;
-        const int pb_beg = blockIdx.y * kpb, pb_end = min(KP, pb_beg + kpb);
-        const int kpw = (pb_end - pb_beg + 3) >> 2;
-        const int kp_beg = pb_beg + wave * kpw, kp_end = min(pb_end, kp_beg + kpw);
         constexpr int UP = U / 2;
-        for (int kp0 = kp_beg; kp0 < kp_end; kp0 += UP) {
+        auto iter = [&](int kp0, auto first) {
             u32x4_t wv[NT][UP]; bf16x8_t x[UP][2];
 #pragma unroll
             for (int u = 0; u < UP; ++u) {
                 const int kp = kp0 + u;
                 s16x8_t x0 = {0, 0, 0, 0, 0, 0, 0, 0}, x1 = x0;
-                if (kp < kp_end) {
+                if (kp < kt_end) {
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
                         wv[j][u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(W8p + (((long long)(nt0 + j) * KP + kp) * 64 + lane) * 16));
-                    if (row_ok) { x0 = *reinterpret_cast<const s16x8_t*>(xrow + kp * 64); x1 = *reinterpret_cast<const s16x8_t*>(xrow + kp * 64 + 32); }
+                    if (!xn && row_ok) { x0 = *reinterpret_cast<const s16x8_t*>(xrow + kp * 64); x1 = *reinterpret_cast<const s16x8_t*>(xrow + kp * 64 + 32); }
                 } else {
 #pragma unroll
                     for (int j = 0; j < NT; ++j) wv[j][u] = u32x4_t{0, 0, 0, 0};
                 }
                 x[u][0] = __builtin_bit_cast(bf16x8_t, x0); x[u][1] = __builtin_bit_cast(bf16x8_t, x1);
+            }
+            if constexpr (CHAIN) if (xn) {
+                if constexpr (decltype(first)::value) chain_prologue();
+#pragma unroll
+                for (int u = 0; u < UP; ++u) if (row_ok && kp0 + u < kt_end) {
+                    x[u][0] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const s16x8_t*>(xl + (kp0 + u) * 64));
+                    x[u][1] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const s16x8_t*>(xl + (kp0 + u) * 64 + 32));
+                }
             }
 #pragma unroll
             for (int u = 0; u < UP; ++u)
@@ -527,29 +570,44 @@ __global__ __launch_bounds__(256) void gemm_gemv16_kernel(GemmP p, int KT) {
                     acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fp8x8_to_bf16(wv[j][u][0], wv[j][u][1]), x[u][0], acc[j], 0, 0, 0);
                     acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fp8x8_to_bf16(wv[j][u][2], wv[j][u][3]), x[u][1], acc[j], 0, 0, 0);
                 }
+        };
+        if (kt_beg < kt_end) {
+            iter(kt_beg, std::true_type{});
+            for (int kp0 = kt_beg + UP; kp0 < kt_end; kp0 += UP) iter(kp0, std::false_type{});
         }
-    } else
-    for (int kt0 = kt_beg; kt0 < kt_end; kt0 += U) {
-        bf16x8_t w[NT][U], x[U];
+    } else {
+        const bf16_t* Wp = (const bf16_t*)p.W;
+        auto iter = [&](int kt0, auto first) {
+            bf16x8_t w[NT][U], x[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int kt = kt0 + u;
-            s16x8_t xv = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (kt < kt_end) {
+            for (int u = 0; u < U; ++u) {
+                const int kt = kt0 + u;
+                s16x8_t xv = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (kt < kt_end) {
 #pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    w[j][u] = __builtin_bit_cast(bf16x8_t, __builtin_nontemporal_load(reinterpret_cast<const s16x8_t*>(Wp + (((long long)(nt0 + j) * KT + kt) * 64 + lane) * 8)));
-                if (row_ok) xv = *reinterpret_cast<const s16x8_t*>(xrow + kt * 32);
-            } else {
+                    for (int j = 0; j < NT; ++j)
+                        w[j][u] = __builtin_bit_cast(bf16x8_t, __builtin_nontemporal_load(reinterpret_cast<const s16x8_t*>(Wp + (((long long)(nt0 + j) * KT + kt) * 64 + lane) * 8)));
+                    if (!xn && row_ok) xv = *reinterpret_cast<const s16x8_t*>(xrow + kt * 32);
+                } else {
 #pragma unroll
-                for (int j = 0; j < NT; ++j) w[j][u] = __builtin_bit_cast(bf16x8_t, xv);
+                    for (int j = 0; j < NT; ++j) w[j][u] = __builtin_bit_cast(bf16x8_t, xv);
+                }
+                x[u] = __builtin_bit_cast(bf16x8_t, xv);
             }
-            x[u] = __builtin_bit_cast(bf16x8_t, xv);
+            if constexpr (CHAIN) if (xn) {
+                if constexpr (decltype(first)::value) chain_prologue();
+#pragma unroll
+                for (int u = 0; u < U; ++u) if (row_ok && kt0 + u < kt_end) x[u] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const s16x8_t*>(xl + (kt0 + u) * 32));
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j][u], x[u], acc[j], 0, 0, 0);
+        };
+        if (kt_beg < kt_end) {
+            iter(kt_beg, std::true_type{});
+            for (int kt0 = kt_beg + U; kt0 < kt_end; kt0 += U) iter(kt0, std::false_type{});
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j][u], x[u], acc[j], 0, 0, 0);
     }
     if (wave > 0) {
 #pragma unroll
@@ -560,8 +618,32 @@ __global__ __launch_bounds__(256) void gemm_gemv16_kernel(GemmP p, int KT) {
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int w2 = 0; w2 < 3; ++w2) acc[j] += *reinterpret_cast<const f32x4_t*>(&red[w2][j][lane][0]);
+        for (int w2 = 0; w2 < WAVES - 1; ++w2) acc[j] += *reinterpret_cast<const f32x4_t*>(&red[w2][j][lane][0]);
     const int m = lr;
+    if constexpr (CHAIN) if (ch.fin_h) {
+        // producer side of the decode chain: the block owns its n-tile over ALL of K (grid.y == 1; the K split is over the block's waves), so the
+        // residual add and the tile's sum of squares need no other block -- cross-block hand-over inside a kernel costs an L2 write-back on this part
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            float ss = 0.f;
+            if (m < p.M) {
+                f32x4_t v = acc[j];
+                if (p.wscale) v *= *reinterpret_cast<const f32x4_t*>(p.wscale + (nt0 + j) * 16 + lq * 4);
+                bf16_t* hp = (bf16_t*)ch.fin_h + (long long)m * p.N + (nt0 + j) * 16 + lq * 4;
+                const s16x4_t r = *reinterpret_cast<const s16x4_t*>(hp);
+                s16x4_t o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float hv = bf2f(f2bf(bf2f(f2bf(v[e])) + bf2f((bf16_t)r[e])));      // rnd(rnd(gemm) + residual)
+                    ss += hv * hv; o[e] = (short)f2bf(hv);
+                }
+                *reinterpret_cast<s16x4_t*>(hp) = o;
+            }
+            ss += __shfl_xor(ss, 16, 64); ss += __shfl_xor(ss, 32, 64);
+            if (lq == 0 && m < p.M) ch.fin_ssq[m * GEMV_SSQ_STRIDE + nt0 + j] = ss;
+        }
+        return;
+    }
     if (m >= p.M) return;
     if (p.slabs) {
         float* ws = p.ws + (long long)blockIdx.y * p.M * p.N;
@@ -612,14 +694,24 @@ static void launch_gemv16(const GemmP& p, const GemmArgs& a, hipStream_t st) {
     if (a.slabs_out) *a.slabs_out = ksplit;
     set_plan(a, GEMM_K_GEMV16, ntiles, ksplit, (a.epi == EPI_SWIGLU || (ntiles % 2 == 0 && ntiles >= 2048) ? ntiles / 2 : ntiles) * ksplit);
     const bool two = a.epi == EPI_SWIGLU || (ntiles % 2 == 0 && ntiles >= 2048);
-    if (a.Wp8) {
-        GemmP q = p; q.W = a.Wp8;
-        if (two) hipLaunchKernelGGL((gemm_gemv16_kernel<2, 8, true>), dim3(ntiles / 2, ksplit), dim3(256), 0, st, q, KT);
-        else hipLaunchKernelGGL((gemm_gemv16_kernel<1, 8, true>), dim3(ntiles, ksplit), dim3(256), 0, st, q, KT);
+    const GemvChain none;
+    const bool chain = a.chain && (a.chain->xn_h || a.chain->fin_h);
+    const GemvChain& ch = chain ? *a.chain : none;
+    GemmP q = p; if (a.Wp8) q.W = a.Wp8;
+    if (chain && ch.fin_h) {
+        // producer: one 16-wave block per n-tile, K split over the waves (no slabs, no second kernel)
+        q.slabs = 0;
+        if (a.slabs_out) *a.slabs_out = 0;
+        set_plan(a, GEMM_K_GEMV16, ntiles, 1, ntiles);
+        if (a.Wp8) hipLaunchKernelGGL((gemm_gemv16_kernel<1, 8, true, true, 16>), dim3(ntiles), dim3(1024), 0, st, q, KT, ch);
+        else hipLaunchKernelGGL((gemm_gemv16_kernel<1, 8, false, true, 16>), dim3(ntiles), dim3(1024), 0, st, q, KT, ch);
         return;
     }
-    if (two) hipLaunchKernelGGL((gemm_gemv16_kernel<2, 8>), dim3(ntiles / 2, ksplit), dim3(256), 0, st, p, KT);
-    else hipLaunchKernelGGL((gemm_gemv16_kernel<1, 8>), dim3(ntiles, ksplit), dim3(256), 0, st, p, KT);
+    const dim3 grid(two ? ntiles / 2 : ntiles, ksplit);
+#define GEMV16_GO(NT_, W8_, CH_) hipLaunchKernelGGL((gemm_gemv16_kernel<NT_, 8, W8_, CH_>), grid, dim3(256), 0, st, q, KT, ch)
+    if (a.Wp8) { if (two) { if (chain) GEMV16_GO(2, true, true); else GEMV16_GO(2, true, false); } else { if (chain) GEMV16_GO(1, true, true); else GEMV16_GO(1, true, false); } }
+    else       { if (two) { if (chain) GEMV16_GO(2, false, true); else GEMV16_GO(2, false, false); } else { if (chain) GEMV16_GO(1, false, true); else GEMV16_GO(1, false, false); } }
+#undef GEMV16_GO
 }
 
 template <int MT>
@@ -1392,6 +1484,7 @@ static hipError_t launch_t(const GemmArgs& a, hipStream_t st, int* kind_out) {
         if (skinny && skinny_packed_ok(MMD_BF16, a)) {
             p.W = a.Wp;
             if (a.M <= 16 && !a.no_gemv) launch_gemv16(p, a, st);
+            else if (a.chain) return hipErrorInvalidValue;          // the decode chain exists in the GEMV kernel only
             else if (a.M <= 16) launch_skinny_mt<1>(p, a, st);
             else if (a.M <= 32) launch_skinny_mt<2>(p, a, st);
             else launch_skinny_mt<4>(p, a, st);
@@ -1399,6 +1492,7 @@ static hipError_t launch_t(const GemmArgs& a, hipStream_t st, int* kind_out) {
         }
     }
     if (a.slabs_out) return hipErrorInvalidValue;          // slab mode exists only on the packed skinny path
+    if (a.chain) return hipErrorInvalidValue;
     if (a.W == nullptr) return hipErrorInvalidValue;       // only the packed copy exists but the shape needs the generic path
     int splits = 1;
     if (skinny) {

@@ -87,6 +87,8 @@ struct mmd_ctx {
     float dec_pen = 0.f; int64_t dec_eos = 0; bool no_graph = false;
     int last_plan[4] = {-1, 0, 0, 0};   // kernel / tiles / splits / blocks of the most recent gemm() (mmd_op_gemm_last_plan)
     bool no_fuse = false;              // MMDUET_NO_FUSE=1: keep the unfused launch schedule (A/B and parity cross-check)
+    bool no_chain = false;             // MMDUET_NO_CHAIN=1: decode steps keep the separate reduce+residual+RMSNorm launches (A/B)
+    float* chain_ssq = 0;              // GemvChain scratch: per-row, per-n-tile sums of squares
     Prof prof;
 };
 
@@ -157,8 +159,8 @@ static void prof_drain(mmd_ctx* c) {
 // ---- GEMM wrapper --------------------------------------------------------------------------------------------------
 static int gemm(mmd_ctx* c, const void* X, int64_t ldx, const void* W, int64_t ldw, const void* bias, const void* R, int64_t ldr, void* Y,
                 int64_t ldy, int M, int N, int K, int epi, int out_f32 = 0, int variant = GEMM_AUTO, const void* Wp = nullptr, bool tower = false,
-                const void* Wp8 = nullptr, const float* wscale = nullptr) {
-    GemmArgs a;
+                const void* Wp8 = nullptr, const float* wscale = nullptr, const GemvChain* chain = nullptr) {
+    GemmArgs a; a.chain = chain;
     a.X = X; a.ldx = ldx; a.W = W; a.ldw = ldw; a.Wp = Wp; a.bias = bias; a.R = R; a.ldr = ldr; a.Y = Y; a.ldy = ldy;
     a.M = M; a.N = N; a.K = K; a.epi = epi; a.out_f32 = out_f32; a.variant = variant; a.Wp8 = Wp8; a.wscale = wscale;
     a.splitk_ws = tower ? c->v_splitk_ws : c->splitk_ws; a.splitk_ws_bytes = tower ? c->v_splitk_bytes : c->splitk_bytes;
@@ -193,6 +195,7 @@ extern "C" int mmd_create(const mmd_config* cfg, int device, mmd_ctx** out) {
     c->vit_ipad = (int)round_up(cfg->vit_intermediate, 64);
     c->qkv_w = cfg->vision_only ? 0 : (cfg->num_heads + 2 * cfg->num_kv_heads) * cfg->head_dim;
     { const char* nf = getenv("MMDUET_NO_FUSE"); c->no_fuse = nf && nf[0] == '1'; }
+    { const char* nf = getenv("MMDUET_NO_CHAIN"); c->no_chain = nf && nf[0] == '1'; }
     // graph replay of the decode step is opt-in (MMDUET_GRAPH=1): measured on MI355X it is not faster than eager launches
     // from this C++ loop (458 vs 480-500 ms for 128 tokens) -- the step is bound by the ~1.5 us GPU-side kernel boundaries,
     // which a graph does not remove, not by host launch latency.
@@ -515,6 +518,7 @@ static int alloc_workspaces(mmd_ctx* c) {
     WS(c->l_q, (size_t)S * g.num_heads * g.head_dim * e); WS(c->l_attn, (size_t)S * g.num_heads * g.head_dim * e);
     WS(c->l_act, (size_t)S * g.intermediate_size * e); WS(c->l_hid, (size_t)S * H * e);
     c->splitk_bytes = (size_t)64 << 20; WS(c->splitk_ws, c->splitk_bytes);
+    WS(c->chain_ssq, (size_t)GEMV_CHAIN_ROWS * GEMV_SSQ_STRIDE * sizeof(float));
     c->attn_bytes = (size_t)128 << 20; WS(c->attn_ws, c->attn_bytes);
     WS(c->logits_ws, (size_t)g.vocab_size * sizeof(float));
     WS(c->heads_dev, (size_t)S * 4 * sizeof(float)); WS(c->rows_dev, (size_t)S * sizeof(int32_t));
@@ -1056,8 +1060,15 @@ static int llm_step_segs(mmd_ctx* c, const StepSeg* segs, int nseg, const void* 
         GemmArgs p3 = probe; p3.Wp = c->L[0].wo_p; p3.N = H; p3.K = nh * d; p3.ldx = nh * d; p3.X = c->l_attn;
         fused = gemm_can_slab(dt, probe) && gemm_can_slab(dt, p2) && gemm_can_slab(dt, p3);
     }
-    auto slab_gemm = [&](const void* X, int64_t ldx, const void* Wp, int N, int K, int* splits, const void* Wp8, const float* wscale) -> int {
+    // Decode chain (S <= 4: every GEMM is the weight-streaming GEMV): o_proj / down_proj fold their result into the residual stream themselves
+    // and leave the row sums of squares, qkv / gate_up build the normalised activation per lane (GemvChain, common.h): 7 launches per layer.
+    const bool chain = fused && S <= GEMV_CHAIN_ROWS && !c->no_chain && H % 64 == 0 && H <= 4096;
+    GemvChain ch_fin, ch_xn;
+    ch_fin.fin_h = c->l_h; ch_fin.fin_ssq = c->chain_ssq;
+    ch_xn.xn_h = c->l_h; ch_xn.xn_ssq = c->chain_ssq; ch_xn.xn_eps = g.rms_norm_eps;
+    auto slab_gemm = [&](const void* X, int64_t ldx, const void* Wp, int N, int K, int* splits, const void* Wp8, const float* wscale, const GemvChain* chn = nullptr) -> int {
         GemmArgs a; memset(&a, 0, sizeof(a));
+        a.chain = chn;
         a.X = X; a.ldx = ldx; a.Wp = Wp; a.Wp8 = Wp8; a.wscale = wscale; a.M = S; a.N = N; a.K = K; a.epi = EPI_NONE; a.variant = GEMM_SKINNY;
         a.splitk_ws = c->splitk_ws; a.splitk_ws_bytes = c->splitk_bytes; a.slabs_out = splits;
         ProfScope ps(c, MMD_K_GEMM_SKINNY, (double)S * K * e + (double)N * K * (Wp8 ? 1.0 : e) + (double)S * N * e, 2.0 * S * N * K);
@@ -1073,7 +1084,8 @@ static int llm_step_segs(mmd_ctx* c, const StepSeg* segs, int nseg, const void* 
         void* Vl = (char*)s->V + (size_t)i * layer_elems * e;
         int splits = 1;
         if (fused) {
-            rc = slab_gemm(c->l_xn, H, L.wqkv_p, c->qkv_w, H, &splits, L.wqkv_8, L.sqkv); if (rc) return rc;
+            ch_xn.xn_gamma = L.ln1;
+            rc = slab_gemm(c->l_xn, H, L.wqkv_p, c->qkv_w, H, &splits, L.wqkv_8, L.sqkv, chain && i > 0 ? &ch_xn : nullptr); if (rc) return rc;
             ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * S * c->qkv_w * e, 0);
             HIPCHK(c, launch_slab_rope_append(c->splitk_ws, splits, L.bqkv, S, nh, nkv, d, c->inv_freq, n, c->l_q, Kl, Vl, s->cap, st, dyn, i));
         } else {
@@ -1106,7 +1118,17 @@ static int llm_step_segs(mmd_ctx* c, const StepSeg* segs, int nseg, const void* 
         }
         const void* next_norm = (i + 1 < g.num_layers) ? c->L[i + 1].ln1 : c->fnorm;
         void* next_xn = (i + 1 < g.num_layers) ? c->l_xn : c->l_hid;
-        if (fused) {
+        if (chain) {
+            rc = slab_gemm(c->l_attn, (int64_t)nh * d, L.wo_p, H, nh * d, &splits, L.wo_8, L.so, &ch_fin); if (rc) return rc;
+            ch_xn.xn_gamma = L.ln2;
+            rc = gemm(c, c->l_xn, H, L.wgu, H, nullptr, nullptr, 0, c->l_act, I, S, 2 * I, H, EPI_SWIGLU, 0, GEMM_AUTO, L.wgu_p, false, L.wgu_8, L.sgu, &ch_xn); if (rc) return rc;
+            const bool last = i + 1 == g.num_layers;              // the caller wants the final norm's output materialised
+            rc = slab_gemm(c->l_act, I, L.wdown_p, H, I, &splits, L.wdown_8, L.sdown, last ? nullptr : &ch_fin); if (rc) return rc;
+            if (last) {
+                ProfScope ps(c, MMD_K_NORM_ROPE, 4.0 * S * H * e, 0);
+                HIPCHK(c, launch_slab_resid_rmsnorm(c->splitk_ws, splits, S, H, c->l_h, c->l_h, next_norm, g.rms_norm_eps, next_xn, st));
+            }
+        } else if (fused) {
             rc = slab_gemm(c->l_attn, (int64_t)nh * d, L.wo_p, H, nh * d, &splits, L.wo_8, L.so); if (rc) return rc;
             { ProfScope ps(c, MMD_K_NORM_ROPE, 4.0 * S * H * e, 0);
               HIPCHK(c, launch_slab_resid_rmsnorm(c->splitk_ws, splits, S, H, c->l_h, c->l_h, L.ln2, g.rms_norm_eps, c->l_xn, st)); }

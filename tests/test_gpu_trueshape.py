@@ -132,24 +132,29 @@ m = VideoHeadLiveLlavaQwenForCausalLM(pcfg, torch_dtype=torch.bfloat16, max_vit_
 m.load_state_dict(w)
 g = torch.Generator().manual_seed(5)
 c = None; res = []
-for S in (49, 1, 30):
+for S in [int(v) for v in os.environ['MMD_SIZES'].split(',')]:
     x = (torch.randn(1, S, 3584, generator=g) * 0.5).to(torch.bfloat16).cuda()
     o = m(inputs_embeds=x, past_key_values=c); c = o.past_key_values
     res.append(o.informative_logits[0, -1].tolist() + o.logits[0, -1, :8].tolist())
 print("RES " + json.dumps(res))
 '''
     from conftest import ROOT
-    def run(**kw):
-        env = dict(os.environ, MMD_ROOT=ROOT, **kw)
+    def run(sizes='49,1,30,5,16,1,3', **kw):
+        env = dict(os.environ, MMD_ROOT=ROOT, MMD_SIZES=sizes, **kw)
         r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         return json.loads([l for l in r.stdout.splitlines() if l.startswith('RES ')][0][4:])
     # one K slab per decode GEMV: same reduction order, same rounding points -> bit-identical
-    assert run(MMDUET_NO_FUSE='0', MMDUET_GEMV_KSPLIT_SHORT='1') == run(MMDUET_NO_FUSE='1', MMDUET_GEMV_KSPLIT_SHORT='1')
-    # the shipped schedule sums the decode qkv / o products in two fp32 K slabs: a different summation order, bf16-rounding-level apart
-    a, b = run(MMDUET_NO_FUSE='0'), run(MMDUET_NO_FUSE='1')
+    assert run('49,1,30', MMDUET_NO_FUSE='0', MMDUET_GEMV_KSPLIT_SHORT='1', MMDUET_NO_CHAIN='1') == run('49,1,30', MMDUET_NO_FUSE='1', MMDUET_GEMV_KSPLIT_SHORT='1')
+    # the shipped schedule sums the decode qkv / o products in two fp32 K slabs and (rows <= 16) takes the RMSNorm statistics from per-n-tile
+    # partial sums (GemvChain): different fp32 summation orders, bf16-rounding-level apart -- and deterministic run to run
+    a, b, a2 = run(MMDUET_NO_FUSE='0'), run(MMDUET_NO_FUSE='1'), run(MMDUET_NO_FUSE='0')
+    assert a == a2
     for ra, rb in zip(a, b):
         assert ra == pytest.approx(rb, abs=2e-2, rel=2e-2)
+    c = run(MMDUET_NO_FUSE='0', MMDUET_NO_CHAIN='1')
+    for ra, rc in zip(a, c):
+        assert ra == pytest.approx(rc, abs=2e-2, rel=2e-2)
 
 
 def test_multi_stream_step_true_shape(true_shape):
