@@ -92,6 +92,10 @@ int mmd_finalize_weights(mmd_ctx* ctx);                  /* builds fused layouts
 int64_t mmd_weight_bytes(const mmd_ctx* ctx);
 
 /* ---- vision side ---------------------------------------------------------------------------------------------- */
+/* Scheduling knob, no effect on results: cap the persistent grid of the tower's / projector's ring GEMMs at `max_blocks` workgroups (0 = one per CU).
+ * The driver (mmduet_amd/inference.py) halves the tower's share while a response is being decoded on the other HIP stream: the weight-streaming
+ * decode kernels then find free CUs and tower batches hide under the decode burst instead of queueing in front of it. */
+int mmd_set_tower_share(mmd_ctx* ctx, int max_blocks);
 /* replaces LiveMixin.visual_embed (models/modeling_live.py:26-33): tower -> connector -> pooling.
  * pixel_values [B,3,img,img] in ctx dtype; out [B*frame_num_tokens, hidden] in ctx dtype. */
 int mmd_vit_encode(mmd_ctx* ctx, const void* pixel_values, int B, void* out);

@@ -44,6 +44,7 @@ _SIGS = {
     'mmd_load_tensor': (_I, [_VP, C.c_char_p, _VP, _I, C.POINTER(_I64), _I, _I]),
     'mmd_merge_lora': (_I, [_VP, C.c_char_p, _VP, _VP, _I, _F]),
     'mmd_set_rope_inv_freq': (_I, [_VP, _VP, _I]),
+    'mmd_set_tower_share': (_I, [_VP, _I]),
     'mmd_finalize_weights': (_I, [_VP]),
     'mmd_weight_bytes': (_I64, [_VP]),
     'mmd_vit_encode': (_I, [_VP, _VP, _I, _VP]),

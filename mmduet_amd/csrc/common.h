@@ -114,6 +114,8 @@ struct GemmArgs {
     int no_gemv = 0;                            // A/B switch: use the LDS-staged skinny kernel also for M <= 16
     int* slabs_out = nullptr;                   // if set (packed skinny path only): leave [splits][M][N] fp32 slabs in splitk_ws, no
                                                 // epilogue, and return the split count here; a fused consumer kernel reduces them
+    int ring_flags = 16;                        // ring GEMM instantiation the auto dispatch uses (launch_ringx flags; 16 = 8 waves, 256 x 256, early refill)
+    int ring_max_blocks = 0;                    // > 0: cap on the persistent grid (co-residency experiments: leave CU resources to another stream)
     const GemvChain* chain = nullptr;           // gemv16 path only (M <= 16, packed bf16 / fp8 weights); see GemvChain
     int* plan_out = nullptr;                    // if set: int[4] = {kernel (GEMM_K_*), output tiles, K splits, blocks launched}
 };

@@ -1341,7 +1341,8 @@ static hipError_t launch_ringx_t(const GemmP& p, const GemmArgs& a, hipStream_t 
     constexpr int BN = 64 * WN;
     const int tiles = cdiv(a.N, BN) * cdiv(a.M, 256);
     const int slots = (WN == 2 && NS == 3) ? 512 : 256;                      // resident blocks: two 4-wave blocks per CU (72 KB rings), else one
-    dim3 grid(splits > 1 || tiles <= slots ? tiles : slots, 1, splits);
+    const int cap = a.ring_max_blocks > 0 && a.ring_max_blocks < slots ? a.ring_max_blocks : slots;
+    dim3 grid(splits > 1 || tiles <= cap ? tiles : cap, 1, splits);
     set_plan(a, WN == 2 ? GEMM_K_RING128X2 : GEMM_K_RING256, tiles, splits, (int)grid.x * splits);
     const int KT = a.K >> 5;
     const size_t smem = NS * (256 * 32 + BN * 32) * sizeof(bf16_t);          // 96 KB / 72 KB (3 slots), 128 KB / 96 KB (4)
@@ -1429,7 +1430,7 @@ static hipError_t launch_t(const GemmArgs& a, hipStream_t st, int* kind_out) {
             if (!big_packed_ok(MMD_BF16, a, 16) || (a.N % 32) != 0) return hipErrorInvalidValue;
             p.W = a.Wp;
             if (kind_out) *kind_out = MMD_K_GEMM_TILE;
-            return launch_ringx(16, p, a, st);
+            return launch_ringx(a.ring_flags, p, a, st);
         }
         // long K with under one block wave of 256^2 tiles (down_proj of a chunk): split K across grid.z so ~one block per CU runs a
         // long steady state (1.05 PF at M = 1274 against 0.84 PF for the 128-row kernel's 3-way split); K = 3584 shapes lose to it

@@ -87,6 +87,7 @@ struct mmd_ctx {
     float dec_pen = 0.f; int64_t dec_eos = 0; bool no_graph = false;
     int last_plan[4] = {-1, 0, 0, 0};   // kernel / tiles / splits / blocks of the most recent gemm() (mmd_op_gemm_last_plan)
     bool no_fuse = false;              // MMDUET_NO_FUSE=1: keep the unfused launch schedule (A/B and parity cross-check)
+    int tower_ring_flags = -1, tower_ring_blocks = 0;   // MMDUET_TOWER_RING / MMDUET_TOWER_RING_BLOCKS: ring GEMM form of the tower (co-residency experiments)
     bool no_chain = false;             // MMDUET_NO_CHAIN=1: decode steps keep the separate reduce+residual+RMSNorm launches (A/B)
     float* chain_ssq = 0;              // GemvChain scratch: per-row, per-n-tile sums of squares
     Prof prof;
@@ -165,6 +166,7 @@ static int gemm(mmd_ctx* c, const void* X, int64_t ldx, const void* W, int64_t l
     a.M = M; a.N = N; a.K = K; a.epi = epi; a.out_f32 = out_f32; a.variant = variant; a.Wp8 = Wp8; a.wscale = wscale;
     a.splitk_ws = tower ? c->v_splitk_ws : c->splitk_ws; a.splitk_ws_bytes = tower ? c->v_splitk_bytes : c->splitk_bytes;
     a.plan_out = c->last_plan;
+    if (tower && c->tower_ring_flags >= 0) { a.ring_flags = c->tower_ring_flags; a.ring_max_blocks = c->tower_ring_blocks; }
     int kind = (variant == GEMM_SKINNY || (variant != GEMM_BIG && variant != GEMM_RING256 && variant != GEMM_RING256_SPLIT && variant < GEMM_RINGX && variant != GEMM_LARGE && variant != GEMM_GENERIC && M <= 64)) ? MMD_K_GEMM_SKINNY : MMD_K_GEMM_TILE;
     double e = (double)es(c);
     double bytes = (double)M * K * e + (double)N * K * ((Wp8 && M <= 64) ? 1.0 : e) + (double)M * (epi == EPI_SWIGLU ? N / 2 : N) * (out_f32 ? 4.0 : e);
@@ -196,6 +198,7 @@ extern "C" int mmd_create(const mmd_config* cfg, int device, mmd_ctx** out) {
     c->qkv_w = cfg->vision_only ? 0 : (cfg->num_heads + 2 * cfg->num_kv_heads) * cfg->head_dim;
     { const char* nf = getenv("MMDUET_NO_FUSE"); c->no_fuse = nf && nf[0] == '1'; }
     { const char* nf = getenv("MMDUET_NO_CHAIN"); c->no_chain = nf && nf[0] == '1'; }
+    { const char* e = getenv("MMDUET_TOWER_RING"); if (e) c->tower_ring_flags = atoi(e); e = getenv("MMDUET_TOWER_RING_BLOCKS"); if (e) c->tower_ring_blocks = atoi(e); }
     // graph replay of the decode step is opt-in (MMDUET_GRAPH=1): measured on MI355X it is not faster than eager launches
     // from this C++ loop (458 vs 480-500 ms for 128 tokens) -- the step is bound by the ~1.5 us GPU-side kernel boundaries,
     // which a graph does not remove, not by host launch latency.
@@ -222,6 +225,11 @@ extern "C" void mmd_destroy(mmd_ctx* c) {
 }
 
 extern "C" const char* mmd_last_error(const mmd_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+extern "C" int mmd_set_tower_share(mmd_ctx* c, int max_blocks) {
+    if (!c || max_blocks < 0) return MMD_EINVAL;
+    c->tower_ring_blocks = max_blocks; if (c->tower_ring_flags < 0) c->tower_ring_flags = 16;
+    return MMD_OK;
+}
 extern "C" int mmd_set_stream(mmd_ctx* c, void* s) { if (!c) return MMD_EINVAL; c->stream = (hipStream_t)s; return MMD_OK; }   // 0 = the (legacy) null stream, as torch's default stream
 extern "C" void* mmd_get_stream(mmd_ctx* c) { return c ? (void*)c->stream : nullptr; }
 extern "C" int mmd_synchronize(mmd_ctx* c) { if (!c) return MMD_EINVAL; HIPCHK(c, hipStreamSynchronize(c->stream)); return MMD_OK; }

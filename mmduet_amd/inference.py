@@ -94,7 +94,13 @@ class LiveInferForBenchmark:
         self.overlap_vision = bool(getattr(args, 'overlap_vision', True))
         self.reuse_chunk_tail = True             # remove_assistant_turns: keep the chunk's frames behind a response instead of replaying them (same context)
         self._vit_stream = None
-        self.vit_lookahead_batches = None      # None: the whole video is queued on the tower stream at once
+        self.vit_lookahead_batches = None      # None: the whole video is queued on the tower stream at once (unless the burst schedule below is on)
+        # Burst schedule of the tower: a response's token-by-token decoding streams weights (HBM-bound, no use for the matrix cores) while the tower
+        # is MFMA-bound -- but a persistent tower GEMM that owns every CU serialises with the decode kernels instead of sharing the chip with them.
+        # So the tower stays `vit_lookahead` batches ahead of the LLM, and when a response starts up to `vit_burst_batches` further batches are issued
+        # with their GEMM grids capped at `vit_burst_blocks` workgroups (half the CUs): decode and tower then run side by side.  0 = off.
+        self.vit_burst_batches = int(os.environ.get('MMDUET_VIT_BURST', 3))
+        self.vit_burst_blocks = int(os.environ.get('MMDUET_VIT_BURST_BLOCKS', 128))
 
         self.eos_token_id = self.model.config.eos_token_id
         dev = self.device
@@ -184,7 +190,23 @@ class LiveInferForBenchmark:
             f = self._vit_out[r * nt:(r + 1) * nt]
             self._frame_batch[f.data_ptr()] = r // vb
             self.frame_embeds_queue.append((r / self.frame_fps, f))
-        self._issue_vit(len(self._vit_batches) if self.vit_lookahead_batches is None else self.vit_lookahead_batches)
+        self._issue_vit(len(self._vit_batches) if self._vit_ahead() is None else self._vit_ahead() + 1)
+
+    def _vit_ahead(self):
+        """Tower batches kept in flight beyond the ones the LLM needs now; None = everything at once."""
+        if self.vit_lookahead_batches is not None:
+            return self.vit_lookahead_batches
+        return 1 if (self.vit_burst_batches > 0 and hasattr(self.model, 'set_tower_share')) else None
+
+    def _issue_vit_burst(self):
+        """A response is about to be decoded: let the next tower batches run beside it on half the CUs."""
+        if not self._vit_batches or self.vit_burst_batches <= 0 or len(self._vit_events) >= len(self._vit_batches) or not hasattr(self.model, 'set_tower_share'):
+            return
+        self.model.set_tower_share(self.vit_burst_blocks)
+        try:
+            self._issue_vit(len(self._vit_events) + self.vit_burst_batches)
+        finally:
+            self.model.set_tower_share(0)
 
     def _issue_vit(self, upto):
         """Enqueue tower batches [issued, upto) on the side stream."""
@@ -251,7 +273,7 @@ class LiveInferForBenchmark:
         if self._frame_batch:
             need = {self._frame_batch[f.data_ptr()] for f in frames if f.data_ptr() in self._frame_batch}
             if need:
-                self._issue_vit(max(need) + 1 + (self.vit_lookahead_batches or 0))
+                self._issue_vit(max(need) + 1 + (self._vit_ahead() or 0))
                 for b in sorted(need - self._vit_waited):
                     torch.cuda.current_stream(self.device).wait_event(self._vit_events[b])
                     self._vit_waited.add(b)
@@ -304,6 +326,7 @@ class LiveInferForBenchmark:
     def _generate_response(self):
         """test/inference.py:257-274."""
         self.last_ids = self._added_stream_generation_ids
+        self._issue_vit_burst()
         output_ids, past_key_values, self.generated_token_ids = fast_greedy_generate(
             model=self.model, inputs_embeds=self._embed(self.last_ids), past_key_values=self.past_key_values,
             eos_token_id=self.eos_token_id, inplace_output_ids=self.inplace_output_ids,

@@ -278,6 +278,11 @@ class VideoHeadLiveLlavaQwenForCausalLM:
     def _bind_stream(self):
         lib().mmd_set_stream(self._ctx, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
 
+    def set_tower_share(self, max_blocks: int):
+        """Scheduling knob (results unchanged): cap the tower's ring-GEMM grids at `max_blocks` workgroups, 0 = all CUs (mmd_set_tower_share)."""
+        with self._lock:
+            check(lib().mmd_set_tower_share(self._ctx, int(max_blocks)), self._ctx, 'mmd_set_tower_share')
+
     def eval(self):
         return self
 

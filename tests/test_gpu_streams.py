@@ -265,3 +265,22 @@ def test_remove_turns_mode_keeps_the_chunk_tail_instead_of_replaying(model_f32, 
     for x, y, ref in zip(a.debug_data_list, b.debug_data_list, case['debug_data']):
         assert x['informative_score'] == pytest.approx(y['informative_score'], abs=1e-5) == pytest.approx(ref['informative_score'], abs=2e-4)
     assert a.forward_calls < b.forward_calls
+
+
+@pytest.mark.parametrize('name', [n for n, c in META['cases'].items() if c['n_responses'] > 0][:2])
+def test_tower_schedule_does_not_change_results(model_f32, name, monkeypatch):
+    """Where the tower batches run (all up front, one batch ahead + bursts of capped-grid batches beside a response's decoding, same stream as the LLM)
+    is scheduling only: scores, responses and the final context are bit-identical."""
+    case = META['cases'][name]
+    runs = []
+    for sched in (dict(vit_burst_batches=0), dict(vit_burst_batches=3, vit_burst_blocks=128), dict(vit_burst_batches=1, vit_burst_blocks=32),
+                  dict(vit_burst_batches=0, vit_lookahead_batches=0), dict(overlap_vision=False)):
+        class D(LiveInferForBenchmark):
+            def __init__(self, *a, **k):
+                super().__init__(*a, **k)
+                for key, v in sched.items():
+                    setattr(self, key, v)
+        d = run_stream_case(D, model_f32, name, case, META, frames_per_forward=4)
+        runs.append(([(x['informative_score'], x['relevance_score']) for x in d.debug_data_list], d.response_token_ids, len(d.past_key_values)))
+    assert all(r == runs[0] for r in runs[1:])
+    assert runs[0][1] == case['generated']
