@@ -29,6 +29,7 @@ struct AttnP {
     int layer;
     int v_tr;          // V stored transposed in 64-token blocks: (tok, e) at ((tok>>6)*d + e)*64 + (tok&63) inside the head region
     float scale_log2;
+    const float* slabs; int n_slabs; const void* qkv_bias; const float2* rope_tab;     // AttnArgs::qkv_slabs (attn_gqa128<1> only)
 };
 
 __device__ __forceinline__ long long v_off(const AttnP& p, long long tok, int e) {
@@ -304,13 +305,6 @@ __global__ __launch_bounds__(256, 2) void attn_gqa128_kernel(AttnP p) {
         my_tok[rt] = row_ok[rt] ? my_row[rt] / G : 0;
         my_head[rt] = kvh * G + (row_ok[rt] ? my_row[rt] % G : 0);
         my_limit[rt] = !row_ok[rt] ? 0 : (p.causal ? n_ctx + my_tok[rt] + 1 : n_tot);
-        const bf16_t* qrow = (const bf16_t*)p.q + (long long)my_tok[rt] * p.ldq + (long long)my_head[rt] * D;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            s16x8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (row_ok[rt]) v = *reinterpret_cast<const s16x8_t*>(qrow + c * 32 + lq * 8);
-            qf[rt][c] = __builtin_bit_cast(bf16x8_t, v);
-        }
     }
     const bool wave_active = row_base < rows_total;                 // wave-uniform
     // key range of this block / split (multiples of 64 except at the very end)
@@ -353,7 +347,86 @@ __global__ __launch_bounds__(256, 2) void attn_gqa128_kernel(AttnP p) {
     };
     const int vsw = (lr >> 1) & 7;
 
+    if (RT == 1 && p.slabs) {
+        // the new tokens' K rows / V columns: written by the block (query block 0 of this kv head) whose key range holds the position, BEFORE it stages
+        // that tile.  Stores are write-through; vmcnt(0) + barrier (the loop's own, per tile) orders them before this block's DMA reads; nobody else reads them in this launch.
+        if (bx == 0) {
+            const int row_w = (p.nh + 2 * p.nkv) * D;
+            const long long MN = (long long)p.S * row_w;
+            bool in_first_tile = false;
+            for (int tok = 0; tok < p.S; ++tok) {
+                const long long pos = n_ctx + tok;
+                if (pos < kbeg || pos >= kbeg + kv_per_split) continue;
+                in_first_tile |= pos < kbeg + KT;
+                const bf16_t* bias = (const bf16_t*)p.qkv_bias;
+                if (tid < 64) {                       // k: pair (i, i + 64)
+                    const int i = tid, col = (p.nh + kvh) * D;
+                    const float* sp = p.slabs + (long long)tok * row_w + col;
+                    float q1[4], q2[4];
+#pragma unroll
+                    for (int z = 0; z < 4; ++z) { q1[z] = z < p.n_slabs ? sp[z * MN + i] : 0.f; q2[z] = z < p.n_slabs ? sp[z * MN + i + 64] : 0.f; }
+                    const float x1 = ((q1[0] + q1[1]) + q1[2]) + q1[3], x2 = ((q2[0] + q2[1]) + q2[2]) + q2[3];
+                    const float a = bf2f(f2bf(x1 + bf2f(bias[col + i]))), b = bf2f(f2bf(x2 + bf2f(bias[col + i + 64])));
+                    const float2 cs = p.rope_tab[tok * (D / 2) + i];
+                    bf16_t* dst = const_cast<bf16_t*>(Kg) + pos * p.k_ts;
+                    dst[i] = f2bf(bf2f(f2bf(a * cs.x)) + bf2f(f2bf(-b * cs.y)));
+                    dst[i + 64] = f2bf(bf2f(f2bf(b * cs.x)) + bf2f(f2bf(a * cs.y)));
+                } else if (tid < 192) {               // v: transposed 64-token blocks
+                    const int i = tid - 64, col = (p.nh + p.nkv + kvh) * D;
+                    const float* sp = p.slabs + (long long)tok * row_w + col;
+                    float q1[4];
+#pragma unroll
+                    for (int z = 0; z < 4; ++z) q1[z] = z < p.n_slabs ? sp[z * MN + i] : 0.f;
+                    const float x = ((q1[0] + q1[1]) + q1[2]) + q1[3];
+                    const_cast<bf16_t*>(Vg)[(((pos >> 6) * D + i) << 6) + (pos & 63)] = f2bf(x + bf2f(bias[col + i]));
+                }
+            }
+            // every later tile is staged behind the loop's own vmcnt(0) + barrier; only a position inside the FIRST tile must land before stage(0)
+            if (in_first_tile) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }       // block-uniform
+        }
+    }
     if (kbeg < kend) stage(0, kbeg);
+    // q fragments AFTER the first tile's DMAs are in flight (their latency covers the q loads / the slab reduction + RoPE)
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        if (RT == 1 && p.slabs) {
+            // q row from the projection's K-slabs: rnd(sum + bias), rotate-half RoPE with the unfused kernels' rounding points (ops.hip
+            // slab_rope_append_kernel).  A lane's chunks c and c + 2 hold the partner elements i and i + 64.
+            const int row_w = (p.nh + 2 * p.nkv) * D;
+            const long long MN = (long long)p.S * row_w;
+            const float* sp = p.slabs + (long long)my_tok[rt] * row_w + my_head[rt] * D + lq * 8;
+            const bf16_t* bp = (const bf16_t*)p.qkv_bias + my_head[rt] * D + lq * 8;
+            const float2* tp = p.rope_tab + my_tok[rt] * (D / 2) + lq * 8;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                s16x8_t o1 = {0, 0, 0, 0, 0, 0, 0, 0}, o2 = o1;
+                if (row_ok[rt]) {
+                    float x1[8], x2[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { x1[e] = sp[c * 32 + e]; x2[e] = sp[c * 32 + 64 + e]; }
+                    for (int z = 1; z < p.n_slabs; ++z)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { x1[e] += sp[z * MN + c * 32 + e]; x2[e] += sp[z * MN + c * 32 + 64 + e]; }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float a = bf2f(f2bf(x1[e] + bf2f(bp[c * 32 + e]))), b = bf2f(f2bf(x2[e] + bf2f(bp[c * 32 + 64 + e])));
+                        const float2 cs = tp[c * 32 + e];
+                        o1[e] = (short)f2bf(bf2f(f2bf(a * cs.x)) + bf2f(f2bf(-b * cs.y)));
+                        o2[e] = (short)f2bf(bf2f(f2bf(b * cs.x)) + bf2f(f2bf(a * cs.y)));
+                    }
+                }
+                qf[rt][c] = __builtin_bit_cast(bf16x8_t, o1); qf[rt][c + 2] = __builtin_bit_cast(bf16x8_t, o2);
+            }
+        } else {
+            const bf16_t* qrow = (const bf16_t*)p.q + (long long)my_tok[rt] * p.ldq + (long long)my_head[rt] * D;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                s16x8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (row_ok[rt]) v = *reinterpret_cast<const s16x8_t*>(qrow + c * 32 + lq * 8);
+                qf[rt][c] = __builtin_bit_cast(bf16x8_t, v);
+            }
+        }
+    }
     int slot = 0;
     for (long long k0 = kbeg; k0 < kend; k0 += KT, slot ^= 1) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -810,6 +883,7 @@ hipError_t launch_attention(int dtype, const AttnArgs& a, hipStream_t st) {
     p.n_ctx = a.n_ctx; p.S = a.S; p.nh = a.nh; p.nkv = a.nkv; p.d = a.d; p.causal = a.causal;
     p.splits = 1; p.kv_per_split = 0; p.v_tr = a.v_transposed; p.dyn = a.dyn; p.layer = a.layer;
     p.scale_log2 = (1.0f / sqrtf((float)a.d)) * 1.4426950408889634f;
+    p.slabs = a.qkv_slabs; p.n_slabs = a.n_slabs; p.qkv_bias = a.qkv_bias; p.rope_tab = (const float2*)a.rope_tab;
     bool can_mfma = dtype == MMD_BF16 && (a.d % 8) == 0 && a.d <= 128 && (a.ldq % 8) == 0 && (a.k_ts % 8) == 0 && (a.v_ts % 8) == 0 &&
                     (a.k_hs % 8) == 0 && (a.v_hs % 8) == 0 && (a.kv_bstride % 8) == 0 && (a.q_bstride % 8) == 0;
     int variant = a.variant;
@@ -817,6 +891,7 @@ hipError_t launch_attention(int dtype, const AttnArgs& a, hipStream_t st) {
     // token-major K/V rows (ViT fused qkv): the transpose-read kernel; it keeps a whole sequence per (head, batch) block
     const bool can_rowmajor = can_mfma && !a.v_transposed && a.n_ctx + a.S < (1 << 30) && (a.o_bstride % 4) == 0 && (a.ldo % 4) == 0;
     if (variant == 0) variant = can_gqa128 ? 3 : (can_rowmajor && a.S >= 64 ? 4 : (can_mfma ? 2 : 1));
+    if (a.qkv_slabs && variant != 3) return hipErrorInvalidValue;
     if (variant == 4) {
         if (!can_rowmajor) return hipErrorInvalidValue;
         if (a.d <= 32) return launch_rowmajor<1, 2>(p, a, st);
@@ -828,6 +903,7 @@ hipError_t launch_attention(int dtype, const AttnArgs& a, hipStream_t st) {
     if (variant == 3) {
         if (!can_gqa128) return hipErrorInvalidValue;
         const int rows_total = a.S * (a.nh / a.nkv);
+        if (a.qkv_slabs && (rows_total > 64 || a.k_ts != 128 || a.n_slabs < 1 || a.n_slabs > 4)) return hipErrorInvalidValue;        // the fused q/k/v preparation lives in the decode form only
         return rows_total <= 64 ? launch_gqa128<1>(p, a, st) : launch_gqa128<2>(p, a, st);
     }
     if (variant == 1) {

@@ -137,6 +137,7 @@ hipError_t launch_slab_resid_rmsnorm(const float* slabs, int splits, int M, int 
                                      void* xn_out, hipStream_t st);
 hipError_t launch_slab_rope_append(const float* slabs, int splits, const void* bias, int S, int nh, int nkv, int d, const float* inv_freq_dev,
                                    int64_t pos0, void* q_out, void* Kc, void* Vc, int64_t cap, hipStream_t st, const StepState* dyn = nullptr, int layer = 0);
+hipError_t launch_rope_table(void* tab, int S, int half, const float* inv_freq_dev, int64_t pos0, hipStream_t st, const StepState* dyn = nullptr);   // float2 [S][half], bf16-rounded
 hipError_t launch_advance_state(StepState* st_dev, const int64_t* tok_dev, int64_t* prev_dev, int prev_cap, int64_t eos, int use_penalty, hipStream_t st);
 hipError_t launch_add_rows(int dtype, void* x, const void* add, int M, int H, int period, hipStream_t st);   // x[m,:] += add[m % period,:]
 hipError_t launch_rope_append(int dtype, const void* qkv, int S, int nh, int nkv, int d, const float* inv_freq_dev, int64_t pos0, void* q_out,
@@ -177,5 +178,9 @@ struct AttnArgs {
     float* ws; size_t ws_bytes;      // split-KV partials
     int variant;
     const StepState* dyn; int layer; int dyn_splits;   // graph mode (attn_gqa128 only)
+    // decode steps (rows <= 64, attn_gqa128<1> only): q / k / v are still the qkv projection's fp32 K-slabs.  The attention kernel itself reduces
+    // them (+ bias), applies RoPE from the step's (cos, sin) table, builds its q fragments in registers and -- the block whose key range holds a new
+    // position -- appends that token's K row / V column to the arena before staging the tile: no slab_rope_append launch, no q buffer.
+    const float* qkv_slabs = nullptr; int n_slabs = 0; const void* qkv_bias = nullptr; const void* rope_tab = nullptr;   // slabs [n][S][(nh+2nkv)*d]; tab float2 [S][d/2]
 };
 hipError_t launch_attention(int dtype, const AttnArgs& a, hipStream_t st);

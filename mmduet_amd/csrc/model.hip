@@ -89,6 +89,8 @@ struct mmd_ctx {
     bool no_fuse = false;              // MMDUET_NO_FUSE=1: keep the unfused launch schedule (A/B and parity cross-check)
     int tower_ring_flags = -1, tower_ring_blocks = 0;   // MMDUET_TOWER_RING / MMDUET_TOWER_RING_BLOCKS: ring GEMM form of the tower (co-residency experiments)
     bool no_chain = false;             // MMDUET_NO_CHAIN=1: decode steps keep the separate reduce+residual+RMSNorm launches (A/B)
+    void* rope_tab = 0;                // (cos, sin) of a decode step's positions (launch_rope_table), read by the attention kernel's fused q/k/v preparation
+    bool no_rope_fuse = false;         // MMDUET_NO_ROPE_FUSE=1: decode steps keep the slab_rope_append launch (A/B)
     float* chain_ssq = 0;              // GemvChain scratch: per-row, per-n-tile sums of squares
     Prof prof;
 };
@@ -198,6 +200,7 @@ extern "C" int mmd_create(const mmd_config* cfg, int device, mmd_ctx** out) {
     c->qkv_w = cfg->vision_only ? 0 : (cfg->num_heads + 2 * cfg->num_kv_heads) * cfg->head_dim;
     { const char* nf = getenv("MMDUET_NO_FUSE"); c->no_fuse = nf && nf[0] == '1'; }
     { const char* nf = getenv("MMDUET_NO_CHAIN"); c->no_chain = nf && nf[0] == '1'; }
+    { const char* nf = getenv("MMDUET_NO_ROPE_FUSE"); c->no_rope_fuse = nf && nf[0] == '1'; }
     { const char* e = getenv("MMDUET_TOWER_RING"); if (e) c->tower_ring_flags = atoi(e); e = getenv("MMDUET_TOWER_RING_BLOCKS"); if (e) c->tower_ring_blocks = atoi(e); }
     // graph replay of the decode step is opt-in (MMDUET_GRAPH=1): measured on MI355X it is not faster than eager launches
     // from this C++ loop (458 vs 480-500 ms for 128 tokens) -- the step is bound by the ~1.5 us GPU-side kernel boundaries,
@@ -526,7 +529,7 @@ static int alloc_workspaces(mmd_ctx* c) {
     WS(c->l_q, (size_t)S * g.num_heads * g.head_dim * e); WS(c->l_attn, (size_t)S * g.num_heads * g.head_dim * e);
     WS(c->l_act, (size_t)S * g.intermediate_size * e); WS(c->l_hid, (size_t)S * H * e);
     c->splitk_bytes = (size_t)64 << 20; WS(c->splitk_ws, c->splitk_bytes);
-    WS(c->chain_ssq, (size_t)GEMV_CHAIN_ROWS * GEMV_SSQ_STRIDE * sizeof(float));
+    WS(c->chain_ssq, (size_t)GEMV_CHAIN_ROWS * GEMV_SSQ_STRIDE * sizeof(float)); WS(c->rope_tab, (size_t)GEMV_CHAIN_ROWS * 64 * 2 * sizeof(float));
     c->attn_bytes = (size_t)128 << 20; WS(c->attn_ws, c->attn_bytes);
     WS(c->logits_ws, (size_t)g.vocab_size * sizeof(float));
     WS(c->heads_dev, (size_t)S * 4 * sizeof(float)); WS(c->rows_dev, (size_t)S * sizeof(int32_t));
@@ -1086,6 +1089,9 @@ static int llm_step_segs(mmd_ctx* c, const StepSeg* segs, int nseg, const void* 
     if (dyn && !fused) FAIL(c, MMD_EINVAL, "graph decode needs the fused bf16 schedule");
     if (fused) { ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * S * H * e, 0); HIPCHK(c, launch_rmsnorm(dt, c->l_h, c->L[0].ln1, c->l_xn, S, H, g.rms_norm_eps, st)); }
 
+    // rows <= 4, head_dim 128: the attention kernel prepares q / k / v from the qkv slabs itself (AttnArgs::qkv_slabs)
+    const bool rope_fused = chain && d == 128 && !c->no_rope_fuse;
+    if (rope_fused) HIPCHK(c, launch_rope_table(c->rope_tab, S, 64, c->inv_freq, n, st, dyn));
     for (int i = 0; i < g.num_layers; ++i) {
         LlmLayer& L = c->L[i];
         void* Kl = (char*)s->K + (size_t)i * layer_elems * e;
@@ -1094,8 +1100,10 @@ static int llm_step_segs(mmd_ctx* c, const StepSeg* segs, int nseg, const void* 
         if (fused) {
             ch_xn.xn_gamma = L.ln1;
             rc = slab_gemm(c->l_xn, H, L.wqkv_p, c->qkv_w, H, &splits, L.wqkv_8, L.sqkv, chain && i > 0 ? &ch_xn : nullptr); if (rc) return rc;
-            ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * S * c->qkv_w * e, 0);
-            HIPCHK(c, launch_slab_rope_append(c->splitk_ws, splits, L.bqkv, S, nh, nkv, d, c->inv_freq, n, c->l_q, Kl, Vl, s->cap, st, dyn, i));
+            if (!rope_fused) {
+                ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * S * c->qkv_w * e, 0);
+                HIPCHK(c, launch_slab_rope_append(c->splitk_ws, splits, L.bqkv, S, nh, nkv, d, c->inv_freq, n, c->l_q, Kl, Vl, s->cap, st, dyn, i));
+            }
         } else {
             { ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * S * H * e, 0); HIPCHK(c, launch_rmsnorm(dt, c->l_h, L.ln1, c->l_xn, S, H, g.rms_norm_eps, st)); }
             rc = gemm(c, c->l_xn, H, L.wqkv, H, L.bqkv, nullptr, 0, c->l_qkv, c->qkv_w, S, c->qkv_w, H, EPI_NONE, 0, GEMM_AUTO, L.wqkv_p, false, L.wqkv_8, L.sqkv); if (rc) return rc;
@@ -1120,6 +1128,7 @@ static int llm_step_segs(mmd_ctx* c, const StepSeg* segs, int nseg, const void* 
             a.S = Sj; a.nh = nh; a.nkv = nkv; a.d = d; a.n_ctx = nj; a.causal = 1; a.v_transposed = 1;
             a.batch = 1; a.ws = c->attn_ws; a.ws_bytes = c->attn_bytes; a.variant = 0;
             a.dyn = dyn; a.layer = i; a.dyn_splits = 64;
+            if (rope_fused) { a.qkv_slabs = c->splitk_ws; a.n_slabs = splits; a.qkv_bias = L.bqkv; a.rope_tab = c->rope_tab; }
             double kvb = 2.0 * (double)(nj + Sj) * nkv * d * e;
             ProfScope ps(c, MMD_K_ATTN_LLM, kvb + 2.0 * Sj * nh * d * e, 4.0 * Sj * (double)(nj + Sj) * nh * d);
             HIPCHK(c, launch_attention(dt, a, st));

@@ -216,6 +216,21 @@ __global__ void slab_rope_append_kernel(const float* __restrict__ slabs, int spl
         dst[i + half] = f2bf(o2);
     }
 }
+// (cos, sin) of the step's positions, bf16-rounded as the RoPE consumers use them: one table per step, shared by all layers and heads
+// (the decode attention kernel's fused q / k preparation reads it instead of evaluating cosf / sinf per layer)
+__global__ void rope_table_kernel(float2* __restrict__ tab, int half, const float* __restrict__ inv_freq_tab, long long pos0, const StepState* __restrict__ dyn) {
+    if (dyn) pos0 = dyn->n_ctx;
+    const int s = blockIdx.x;
+    for (int i = threadIdx.x; i < half; i += blockDim.x) {
+        const float ang = (float)(pos0 + s) * inv_freq_tab[i];
+        tab[s * half + i] = float2{bf2f(f2bf(cosf(ang))), bf2f(f2bf(sinf(ang)))};
+    }
+}
+hipError_t launch_rope_table(void* tab, int S, int half, const float* inv_freq_dev, int64_t pos0, hipStream_t st, const StepState* dyn) {
+    if (S <= 0) return hipSuccess;
+    hipLaunchKernelGGL(rope_table_kernel, dim3(S), dim3(64), 0, st, (float2*)tab, half, inv_freq_dev, (long long)pos0, dyn);
+    return hipGetLastError();
+}
 hipError_t launch_slab_rope_append(const float* slabs, int splits, const void* bias, int S, int nh, int nkv, int d, const float* inv_freq_dev,
                                    int64_t pos0, void* q_out, void* Kc, void* Vc, int64_t cap, hipStream_t st, const StepState* dyn, int layer) {
     if (S <= 0) return hipSuccess;

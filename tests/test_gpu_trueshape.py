@@ -155,6 +155,8 @@ print("RES " + json.dumps(res))
     c = run(MMDUET_NO_FUSE='0', MMDUET_NO_CHAIN='1')
     for ra, rc in zip(a, c):
         assert ra == pytest.approx(rc, abs=2e-2, rel=2e-2)
+    # q / k / v prepared inside the decode attention kernel vs by slab_rope_append: same slabs, same rounding points, same (cos, sin) -> same bits
+    assert a == run(MMDUET_NO_FUSE='0', MMDUET_NO_ROPE_FUSE='1')
 
 
 def test_multi_stream_step_true_shape(true_shape):

@@ -54,7 +54,7 @@ if __name__ == '__main__':
         for M, shapes in ((25515, VIT), (1274, LLM[:4]), (1323, LLM[:4])):
             for name, N, K, epi in shapes:
                 for variant, vn in variants:
-                    if 'splitK' in vn and (K < 8192 or epi == 'swiglu'):
+                    if 'splitK' in vn and ((K < 8192 and not os.environ.get('BENCH_GEMM_SPLITK_ALL')) or epi == 'swiglu'):
                         continue
                     try:
                         ms = run(ops, M, N, K, epi, variant, iters=10)
