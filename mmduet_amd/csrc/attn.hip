@@ -49,6 +49,18 @@ __device__ __forceinline__ void xcd_block_id(int& bx, int& by, int& bz) {
     bx = id % gx; by = (id / gx) % gy; bz = id / (gx * gy);
 }
 
+// max over the four lanes {l, l^16, l^32, l^48} (the lq groups that share a query row in the S^T layout) without going through the LDS
+// crossbar: v_permlane16_swap / v_permlane32_swap of a register with itself leave (rows 0,0,2,2 | 1,1,3,3) resp. (lower, lower | upper, upper),
+// so one max each folds the halves.  Exact, same value in all four lanes -- what two ds_bpermute shuffles gave, at VALU latency.
+__device__ __forceinline__ float quad_lanes_max(float v) {
+    const unsigned u = __float_as_uint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const float m1 = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const unsigned w = __float_as_uint(m1);
+    const auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void attn_simple_kernel(AttnP p) {
@@ -475,8 +487,7 @@ __global__ __launch_bounds__(256, 2) void attn_gqa128_kernel(AttnP p) {
                             if (!(h * 32 + t * 4 + r < rel[rt])) sv[t * 4 + r] = -INFINITY;     // key = h*32 + lq*8 + t*4 + r, 32-bit, tile-relative
                 }
                 float mx = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
-                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                mx = quad_lanes_max(mx);
                 mx *= p.scale_log2;                                   // scale > 0: max commutes with it
                 if (mx > m_run[rt] + ATTN_DEFER) {                    // (first tile: m_run = -inf -> always)
                     const float alpha = __builtin_amdgcn_exp2f(m_run[rt] - mx);      // m_run = -inf -> 0
@@ -783,8 +794,7 @@ __global__ __launch_bounds__(256, 2) void attn_rowmajor_kernel(AttnP p) {
                         sv[t * 4 + r] = v;
                         mx = fmaxf(mx, v);
                     }
-                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                mx = quad_lanes_max(mx);
                 mx *= p.scale_log2;                                   // scale > 0: max commutes with it
                 if (mx > m_run[rt] + ATTN_DEFER) {                    // (first tile: m_run = -inf -> always)
                     const float alpha = __builtin_amdgcn_exp2f(m_run[rt] - mx);      // m_run = -inf -> 0

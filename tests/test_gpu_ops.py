@@ -35,17 +35,23 @@ def assert_close(got, ref, dtype, scale=1.0, what=''):
 GEMM_SHAPES = [(49, 64, 64), (7, 130, 72), (200, 96, 588), (64, 256, 512), (300, 384, 256), (1, 512, 64), (129, 160, 4352), (392, 512, 1152), (729, 256, 640), (1000, 1152, 1152), (520, 96, 128), (200, 64, 64), (130, 128, 192), (257, 160, 320), (300, 96, 448)]
 
 
-def _variant_ok(ops, variant, M, N, K):
-    if variant == 4 and (ops.dtype != torch.bfloat16 or M <= 64 or N % 64 or K % 64):
-        pytest.skip('big-tile kernel: bf16, M > 64, N % 64 == 0, K % 64 == 0')
-    if (variant in (6, 7) or variant >= 16) and (ops.dtype != torch.bfloat16 or M <= 64 or N % 32 or K % 64):
-        pytest.skip('256x256 kernel: bf16, M > 64, N % 32 == 0, K % 64 == 0')
+@pytest.fixture(scope='module')
+def ops_bf16():
+    from rawops import RawOps
+    return RawOps(torch.bfloat16)
 
 
-@pytest.mark.parametrize('M,N,K', GEMM_SHAPES)
-@pytest.mark.parametrize('variant', [1, 2, 3, 4, 6, 7, 16, 17, 18, 19, 21, 23, 24, 32, 33, 40, 42, 44])
-def test_gemm_bias(ops, M, N, K, variant):
-    _variant_ok(ops, variant, M, N, K)
+GENERIC_VARIANTS = [1, 2, 3]                                              # both dtypes, any shape
+TILE_VARIANTS = [4, 6, 7, 16, 17, 18, 19, 21, 23, 24, 32, 33, 40, 42, 44]     # bf16 MFMA tile kernels with shape conditions
+
+
+def _applies(variant, M, N, K):
+    if variant == 4:            # big-tile kernel
+        return M > 64 and N % 64 == 0 and K % 64 == 0
+    return M > 64 and N % 32 == 0 and K % 64 == 0      # 256x256 ring family
+
+
+def _gemm_bias(ops, M, N, K, variant):
     g = torch.Generator().manual_seed(M * 7 + N)
     X = torch.randn(M, K, generator=g); W = torch.randn(N, K, generator=g) / math.sqrt(K); b = torch.randn(N, generator=g)
     Y = ops.gemm(X, W, b, variant=variant)
@@ -53,12 +59,33 @@ def test_gemm_bias(ops, M, N, K, variant):
     assert_close(Y, ref, ops.dtype, what=f'gemm {M}x{N}x{K} v{variant}')
 
 
+@pytest.mark.parametrize('M,N,K', GEMM_SHAPES)
+@pytest.mark.parametrize('variant', GENERIC_VARIANTS)
+def test_gemm_bias(ops, M, N, K, variant):
+    _gemm_bias(ops, M, N, K, variant)
+
+
+@pytest.mark.parametrize('M,N,K,variant', [(m, n, k, v) for v in TILE_VARIANTS for (m, n, k) in GEMM_SHAPES if _applies(v, m, n, k)])
+def test_gemm_bias_tile_kernels(ops_bf16, M, N, K, variant):
+    _gemm_bias(ops_bf16, M, N, K, variant)
+
+
 @pytest.mark.parametrize('epi', ['gelu_tanh', 'gelu_erf', 'resid', 'swiglu'])
-@pytest.mark.parametrize('variant', [1, 2, 3, 4, 6, 7, 16, 17, 18, 19, 21, 23, 24, 32, 33, 40, 42, 44])
+@pytest.mark.parametrize('variant', GENERIC_VARIANTS)
 def test_gemm_epilogues(ops, epi, variant):
+    _gemm_epilogues(ops, epi, variant)
+
+
+@pytest.mark.parametrize('epi', ['gelu_tanh', 'gelu_erf', 'resid', 'swiglu'])
+@pytest.mark.parametrize('variant', TILE_VARIANTS)
+def test_gemm_epilogues_tile_kernels(ops_bf16, epi, variant):
+    _gemm_epilogues(ops_bf16, epi, variant)
+
+
+def _gemm_epilogues(ops, epi, variant):
     g = torch.Generator().manual_seed(11)
-    M, N, K = (70, 192, 136) if variant not in (4, 6, 7) and variant < 16 else (300, 320, 192)
-    _variant_ok(ops, variant, M, N, K)
+    M, N, K = (70, 192, 136) if variant in GENERIC_VARIANTS else (300, 320, 192)
+    assert variant in GENERIC_VARIANTS or _applies(variant, M, N, K)
     X = torch.randn(M, K, generator=g); W = torch.randn(N, K, generator=g) / math.sqrt(K); b = 0.1 * torch.randn(N, generator=g)
     R = torch.randn(M, N, generator=g)
     Xr, Wr, br, Rr = (rt(t, ops.dtype) for t in (X, W, b, R))
@@ -143,12 +170,17 @@ ATTN_CASES = [  # S, nh, nkv, d, n_ctx, causal
 
 
 @pytest.mark.parametrize('S,nh,nkv,d,n_ctx,causal', ATTN_CASES)
-@pytest.mark.parametrize('variant', [1, 2, 3, 4])
-def test_attention(ops, S, nh, nkv, d, n_ctx, causal, variant):
-    if variant >= 2 and ops.dtype != torch.bfloat16:
-        pytest.skip('the MFMA attention kernels are bf16 only')
-    if variant == 3 and d != 128:
-        pytest.skip('the GQA flash kernel is specialised for head_dim 128')
+def test_attention_generic_kernel(ops, S, nh, nkv, d, n_ctx, causal):
+    _attention(ops, S, nh, nkv, d, n_ctx, causal, 1)
+
+
+# the MFMA attention kernels are bf16 only; variant 3 (the GQA flash kernel) is specialised for head_dim 128
+@pytest.mark.parametrize('S,nh,nkv,d,n_ctx,causal,variant', [c + (v,) for v in (2, 3, 4) for c in ATTN_CASES if v != 3 or c[3] == 128])
+def test_attention_mfma_kernels(ops_bf16, S, nh, nkv, d, n_ctx, causal, variant):
+    _attention(ops_bf16, S, nh, nkv, d, n_ctx, causal, variant)
+
+
+def _attention(ops, S, nh, nkv, d, n_ctx, causal, variant):
     g = torch.Generator().manual_seed(S * 13 + d)
     cap = (n_ctx + S + 37 + 63) // 64 * 64
     q = torch.randn(S, nh * d, generator=g); K = torch.randn(nkv, cap, d, generator=g); V = torch.randn(nkv, cap, d, generator=g)
