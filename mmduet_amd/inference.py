@@ -196,7 +196,9 @@ class LiveInferForBenchmark:
         """Tower batches kept in flight beyond the ones the LLM needs now; None = everything at once."""
         if self.vit_lookahead_batches is not None:
             return self.vit_lookahead_batches
-        return 1 if (self.vit_burst_batches > 0 and hasattr(self.model, 'set_tower_share')) else None
+        if self.vit_burst_batches > 0 and hasattr(self.model, 'set_tower_share'):
+            return int(os.environ.get('MMDUET_VIT_LOOKAHEAD', 1))
+        return None
 
     def _issue_vit_burst(self):
         """A response is about to be decoded: let the next tower batches run beside it on half the CUs."""
