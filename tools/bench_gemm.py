@@ -84,6 +84,11 @@ if __name__ == '__main__':
         if len(sys.argv) > 2:
             json.dump(dict(note='tools/bench_gemm.py llm: weight-streaming kernels, random operands; GB/s = algorithmic bytes (weights at their stored width + activations) / time', rows=rows),
                       open(sys.argv[2], 'w'), indent=1)
+    if which == 'square':       # the guide's reference shapes (4096^3, 8192^3): where does the ring stand against its 256^2 8-phase template (1.33 / 1.47 PF, random operands)?
+        for n in (2048, 4096, 8192):
+            for variant, vn in ((32, 'rx-8w-early'), (40, 'rx-8w-ns4-early'), (4, 'big')):
+                ms = run(ops, n, n, n, 'none', variant, iters=10)
+                print(f'{n}^3 {vn:16s} {ms*1e3:9.1f} us  {2*n**3/ms/1e9:7.1f} TF  {2*n**3/ms/1e9/2500:5.3f}', flush=True)
     if which in ('big', 'all'):
         for M in (392, 784, 980, 1274, 23328):
             shapes = (LLM[:4] if M < 2000 else VIT)
