@@ -157,6 +157,9 @@ print("RES " + json.dumps(res))
         assert ra == pytest.approx(rc, abs=2e-2, rel=2e-2)
     # q / k / v prepared inside the decode attention kernel vs by slab_rope_append: same slabs, same rounding points, same (cos, sin) -> same bits
     assert a == run(MMDUET_NO_FUSE='0', MMDUET_NO_ROPE_FUSE='1')
+    # ... also when the new positions straddle a 64-key tile / split boundary (62,63 | 64), start a stream (n = 0) or sit on the last key of a split
+    edge = '3,4,55,3,2,60,4,1,1'
+    assert run(edge, MMDUET_NO_FUSE='0') == run(edge, MMDUET_NO_FUSE='0', MMDUET_NO_ROPE_FUSE='1')
 
 
 def test_multi_stream_step_true_shape(true_shape):
