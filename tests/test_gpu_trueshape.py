@@ -128,7 +128,7 @@ from mmduet_amd.modeling_live import VideoHeadLiveLlavaQwenForCausalLM
 ocfg = O.OracleConfig(vocab_size=2048, num_hidden_layers=2, vit_layers=1)
 w = {k: v for k, v in O.random_weights(ocfg, seed=3, dtype=torch.bfloat16, scale="unit").items()}
 pcfg = VideoHeadLiveLlavaQwenConfig(vocab_size=2048, num_hidden_layers=2, vit_num_hidden_layers=2, vit_layers_removed=1, frame_num_tokens=49, frame_resolution=384)
-m = VideoHeadLiveLlavaQwenForCausalLM(pcfg, torch_dtype=torch.bfloat16, max_vit_batch=1, max_step_tokens=128, kv_initial_tokens=512)
+m = VideoHeadLiveLlavaQwenForCausalLM(pcfg, torch_dtype=torch.bfloat16, max_vit_batch=1, max_step_tokens=128, kv_initial_tokens=int(os.environ.get('MMD_KV_TOKENS', 512)))
 m.load_state_dict(w)
 g = torch.Generator().manual_seed(5)
 c = None; res = []
@@ -160,6 +160,13 @@ print("RES " + json.dumps(res))
     # ... also when the new positions straddle a 64-key tile / split boundary (62,63 | 64), start a stream (n = 0) or sit on the last key of a split
     edge = '3,4,55,3,2,60,4,1,1'
     assert run(edge, MMDUET_NO_FUSE='0') == run(edge, MMDUET_NO_FUSE='0', MMDUET_NO_ROPE_FUSE='1')
+    # ... and at the benchmark's context length: 15 k keys in 64 splits, the new position in the last one
+    long_ctx = ','.join(['120'] * 125 + ['3', '1', '4', '2', '1'])
+    got = run(long_ctx, MMDUET_NO_FUSE='0', MMD_KV_TOKENS='16384')
+    assert got[-5:] == run(long_ctx, MMDUET_NO_FUSE='0', MMDUET_NO_ROPE_FUSE='1', MMD_KV_TOKENS='16384')[-5:]
+    ref = run(long_ctx, MMDUET_NO_FUSE='1', MMD_KV_TOKENS='16384')          # unfused launch schedule throughout
+    for ra, rb in zip(got[-5:], ref[-5:]):
+        assert ra == pytest.approx(rb, abs=3e-2, rel=3e-2)
 
 
 def test_multi_stream_step_true_shape(true_shape):
