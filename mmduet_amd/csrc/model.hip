@@ -1056,7 +1056,7 @@ static int llm_step_segs(mmd_ctx* c, const StepSeg* segs, int nseg, const void* 
     const int H = g.hidden_size, I = g.intermediate_size, nh = g.num_heads, nkv = g.num_kv_heads, d = g.head_dim;
     mmd_stream* s = segs[0].s;                   // the single-stream (fused) schedule below works on segment 0
     const int64_t n = s->len;
-    HIPCHK(c, hipMemcpyAsync(c->l_h, embeds, (size_t)S * H * e, hipMemcpyDeviceToDevice, st));
+    if (embeds != c->l_h) HIPCHK(c, hipMemcpyAsync(c->l_h, embeds, (size_t)S * H * e, hipMemcpyDeviceToDevice, st));
     const size_t layer_elems = kv_layer_elems(c, s->cap);
 
     // Fused schedule for the weight-streaming regime (S <= 64, packed bf16 weights): the skinny GEMMs leave fp32 split-K
@@ -1255,8 +1255,9 @@ extern "C" int mmd_frame_step(mmd_ctx* c, mmd_stream* s, const void* embeds, int
 // graph-capturable form that reads position / arena / penalty-list length from device state
 static int decode_step_enqueue(mmd_ctx* c, mmd_stream* s, bool pen, float rep_penalty, int np, int64_t eos_id, const StepState* dyn) {
     const mmd_config& g = c->cfg; hipStream_t st = c->stream; const int H = g.hidden_size;
-    HIPCHK(c, launch_embed(g.dtype, c->embed, c->tok_dev, 1, H, g.vocab_size, c->gen_embed, st));
-    int rc = llm_step_impl(c, s, c->gen_embed, 1, nullptr, dyn); if (rc) return rc;
+    // the next token's embedding is gathered straight into the residual-stream buffer (llm_step_segs skips its copy when embeds == l_h)
+    HIPCHK(c, launch_embed(g.dtype, c->embed, c->tok_dev, 1, H, g.vocab_size, c->l_h, st));
+    int rc = llm_step_impl(c, s, c->l_h, 1, nullptr, dyn); if (rc) return rc;
     rc = gemm(c, c->l_hid, H, c->lm_head, H, nullptr, nullptr, 0, c->logits_ws, g.vocab_size, 1, g.vocab_size, H, EPI_NONE, 1, GEMM_AUTO, c->lm_head_p); if (rc) return rc;
     HIPCHK(c, launch_argmax_penalty(c->logits_ws, g.vocab_size, c->prev_dev, pen ? (np < c->prev_cap ? np : c->prev_cap) : 0, pen ? rep_penalty : 1.f, c->tok_dev, st, dyn, c->argmax_scratch));
     if (dyn) HIPCHK(c, launch_advance_state(c->step_dev, c->tok_dev, c->prev_dev, c->prev_cap, eos_id, pen ? 1 : 0, st));

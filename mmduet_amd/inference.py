@@ -101,6 +101,10 @@ class LiveInferForBenchmark:
         # with their GEMM grids capped at `vit_burst_blocks` workgroups (half the CUs): decode and tower then run side by side.  0 = off.
         self.vit_burst_batches = int(os.environ.get('MMDUET_VIT_BURST', 3))
         self.vit_burst_blocks = int(os.environ.get('MMDUET_VIT_BURST_BLOCKS', 128))
+        # a burst is sized to the response it hides under: one tower batch per `vit_burst_tokens_per_batch` expected tokens (a 35-frame batch at half share
+        # takes about as long as 10 decode steps beside it), expectation = running mean of this driver's earlier responses, `max_new_tokens` before the first
+        self.vit_burst_tokens_per_batch = int(os.environ.get('MMDUET_VIT_BURST_TOKENS', 10))
+        self._resp_tokens_mean = None
 
         self.eos_token_id = self.model.config.eos_token_id
         dev = self.device
@@ -204,9 +208,13 @@ class LiveInferForBenchmark:
         """A response is about to be decoded: let the next tower batches run beside it on half the CUs."""
         if not self._vit_batches or self.vit_burst_batches <= 0 or len(self._vit_events) >= len(self._vit_batches) or not hasattr(self.model, 'set_tower_share'):
             return
+        expect = self._resp_tokens_mean if self._resp_tokens_mean is not None else float(getattr(self, 'max_new_tokens', 0) or 0)
+        n = min(self.vit_burst_batches, int(expect // max(1, self.vit_burst_tokens_per_batch)))
+        if n <= 0:
+            return
         self.model.set_tower_share(self.vit_burst_blocks)
         try:
-            self._issue_vit(len(self._vit_events) + self.vit_burst_batches)
+            self._issue_vit(len(self._vit_events) + n)
         finally:
             self.model.set_tower_share(0)
 
@@ -334,6 +342,8 @@ class LiveInferForBenchmark:
             eos_token_id=self.eos_token_id, inplace_output_ids=self.inplace_output_ids,
             repetition_penalty=self.repetition_penalty, generated_token_ids=self.generated_token_ids)
         self.last_generated_ids = output_ids[0].tolist()
+        n_tok = len(self.last_generated_ids)
+        self._resp_tokens_mean = n_tok if self._resp_tokens_mean is None else 0.7 * self._resp_tokens_mean + 0.3 * n_tok
         if not self.remove_assistant_turns:
             self.past_key_values = past_key_values
             self.last_ids = output_ids[:, -1:].clone()
