@@ -1055,7 +1055,7 @@ __global__ __launch_bounds__(WN * 128, 2) void gemm_ringx_kernel(GemmP p, int KT
         }
     };
     auto dma_x = [&](int slot, int step, int j) {
-        if constexpr (DBG >= 2) return;
+        if constexpr (DBG == 2 || DBG == 3) return;
         if constexpr (DBG == 1) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + (long long)min(m0 + (wave + NW * j) * 16, p.M - 16) * p.ldx + (long long)step * 512 + lane * 8),
                                              (__attribute__((address_space(3))) void*)(lds + slot * SE + (wave + NW * j) * 512), 16, 0, 0);
@@ -1103,7 +1103,8 @@ __global__ __launch_bounds__(WN * 128, 2) void gemm_ringx_kernel(GemmP p, int KT
         bf16x8_t a[8], b0[4], b1[4];
         auto step = [&](auto steady, int s, int slot, const bf16x8_t (&b)[4], bf16x8_t (&bn)[4]) {
             constexpr bool STEADY = decltype(steady)::value;
-            if (STEADY || s + NS - 1 < nsteps) RINGX_WAIT((NS - 2) * NDMA);
+            if (DBG == 5 && s < 2) RINGX_WAIT((NS - 2) * NDMA + 16);          // timing experiment: leave the previous tile's 16 stores pending (WRONG on the first tile)
+            else if (STEADY || s + NS - 1 < nsteps) RINGX_WAIT((NS - 2) * NDMA);
             else if (NS == 4 && s + 2 < nsteps) RINGX_WAIT(NDMA);
             else RINGX_WAIT(0);
             MMD_BAR();
@@ -1135,7 +1136,8 @@ __global__ __launch_bounds__(WN * 128, 2) void gemm_ringx_kernel(GemmP p, int KT
         int tile = blockIdx.x;
         tile_origin(tile); tile_sources(); prologue();
         for (; tile < nblk; tile += G) {
-            if (NS > 3 && nsteps > 3) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(3 * NDMA) : "memory");
+            if (DBG == 5) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(VM_TWO + 16) : "memory");
+            else if (NS > 3 && nsteps > 3) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(3 * NDMA) : "memory");
             else if (nsteps > 2) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(VM_TWO) : "memory");
             else if (nsteps > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(VM_ONE) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1173,6 +1175,12 @@ __global__ __launch_bounds__(WN * 128, 2) void gemm_ringx_kernel(GemmP p, int KT
                 }
                 return;
             }
+            if constexpr (DBG == 4) {          // timing only: no conversion, no stores (the accumulators stay live)
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(acc[i][j][0]), "v"(acc[i][j][1]), "v"(acc[i][j][2]), "v"(acc[i][j][3]));
+            } else
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int m = em0 + wr * 128 + i * 16 + lr;
@@ -1447,6 +1455,8 @@ static hipError_t launch_t(const GemmArgs& a, hipStream_t st, int* kind_out) {
                 return launch_ringx(16, p, a, st, sp);
             }
         }
+        if (variant == 95) { if (!big_packed_ok(MMD_BF16, a, 16) || (a.N % 32) != 0) return hipErrorInvalidValue; p.W = a.Wp; return launch_ringx_dbg<5>(p, a, st); }
+        if (variant == 99) { if (!big_packed_ok(MMD_BF16, a, 16) || (a.N % 32) != 0) return hipErrorInvalidValue; p.W = a.Wp; return launch_ringx_dbg<4>(p, a, st); }
         if (variant >= 96 && variant <= 98) {                               // timing experiments (WRONG results): see gemm_ringx_kernel DBG
             if (!big_packed_ok(MMD_BF16, a, 16) || (a.N % 32) != 0) return hipErrorInvalidValue;
             p.W = a.Wp;
