@@ -1197,6 +1197,8 @@ __global__ __launch_bounds__(WN * 128, 2) void gemm_ringx_kernel(GemmP p, int KT
                         const int nb = en0 + wc * 64 + j * 16;
                         const int na = nb + 16 <= p.N ? nb : p.N - 16, nc = nb + 32 <= p.N ? nb + 16 : p.N - 16;
                         const s16x8_t v = pair_to_row8(big_value<EPI>(p, mc, na + lq * 4, acc[i][j]), big_value<EPI>(p, mc, nc + lq * 4, acc[i][j + 1]));
+                        if constexpr (DBG == 6) { const u32x4_t w = __builtin_bit_cast(u32x4_t, v); asm volatile("" :: "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3])); }      // timing only: converted, not stored
+                        else
                         if (m < p.M && nb + 16 * (lq & 1) + 16 <= p.N) *reinterpret_cast<s16x8_t*>((bf16_t*)p.Y + (long long)m * p.ldy + nb + (lq & 1) * 16 + (lq >> 1) * 8) = v;
                     }
                 }
@@ -1455,6 +1457,7 @@ static hipError_t launch_t(const GemmArgs& a, hipStream_t st, int* kind_out) {
                 return launch_ringx(16, p, a, st, sp);
             }
         }
+        if (variant == 94) { if (!big_packed_ok(MMD_BF16, a, 16) || (a.N % 32) != 0) return hipErrorInvalidValue; p.W = a.Wp; return launch_ringx_dbg<6>(p, a, st); }
         if (variant == 95) { if (!big_packed_ok(MMD_BF16, a, 16) || (a.N % 32) != 0) return hipErrorInvalidValue; p.W = a.Wp; return launch_ringx_dbg<5>(p, a, st); }
         if (variant == 99) { if (!big_packed_ok(MMD_BF16, a, 16) || (a.N % 32) != 0) return hipErrorInvalidValue; p.W = a.Wp; return launch_ringx_dbg<4>(p, a, st); }
         if (variant >= 96 && variant <= 98) {                               // timing experiments (WRONG results): see gemm_ringx_kernel DBG
