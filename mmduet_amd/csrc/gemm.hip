@@ -1079,6 +1079,12 @@ __global__ __launch_bounds__(WN * 128, 2) void gemm_ringx_kernel(GemmP p, int KT
     auto dma_k = [&](int slot, int step, int k) { if (k < XP) dma_x(slot, step, k); else if (k < XP + WP) dma_w(slot, step, k - XP); };
 
     constexpr int VM_ONE = NDMA, VM_TWO = 2 * NDMA;       // vmcnt leaving one / two slices in flight
+    constexpr int NST = EPI == EPI_SWIGLU ? 8 : 16;       // output store instructions per wave and tile (16x16x32 schedule), ALWAYS issued (masked lanes write to a dump slot)
+#ifdef MMDUET_NO_PST
+    constexpr bool PST = false;                            // A/B build (tools/probes/nt_ab.sh)
+#else
+    constexpr bool PST = !M32 && NS == 3 && DBG == 0;      // output stores may stay pending across the next tile's start
+#endif
 #define RINGX_WAIT(n) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(n) : "memory")
     const int G = gridDim.x;
     const int rswz = (0x1230 >> (((lr >> 2) & 3) * 4)) & 3;
@@ -1101,9 +1107,11 @@ __global__ __launch_bounds__(WN * 128, 2) void gemm_ringx_kernel(GemmP p, int KT
         const int aoff = (wr * 8) * 512 + lr * 32 + ((lq ^ rswz) * 8);
         const int boff = XE + (wc * 4) * 512 + lane * 8;
         bf16x8_t a[8], b0[4], b1[4];
-        auto step = [&](auto steady, int s, int slot, const bf16x8_t (&b)[4], bf16x8_t (&bn)[4]) {
+        auto step = [&](auto steady, int s, int slot, const bf16x8_t (&b)[4], bf16x8_t (&bn)[4], auto pending) {
             constexpr bool STEADY = decltype(steady)::value;
+            constexpr bool PEND = decltype(pending)::value;          // first two slices of a tile whose predecessor's NST stores may still be in flight (see the epilogue)
             if (DBG == 5 && s < 2) RINGX_WAIT((NS - 2) * NDMA + 16);          // timing experiment: leave the previous tile's 16 stores pending (WRONG on the first tile)
+            else if (PEND) RINGX_WAIT((NS - 2) * NDMA + NST);
             else if (STEADY || s + NS - 1 < nsteps) RINGX_WAIT((NS - 2) * NDMA);
             else if (NS == 4 && s + 2 < nsteps) RINGX_WAIT(NDMA);
             else RINGX_WAIT(0);
@@ -1136,7 +1144,12 @@ __global__ __launch_bounds__(WN * 128, 2) void gemm_ringx_kernel(GemmP p, int KT
         int tile = blockIdx.x;
         tile_origin(tile); tile_sources(); prologue();
         for (; tile < nblk; tile += G) {
+            // pend: this block's previous tile left exactly NST output stores in flight behind the DMAs of slices 0..2 issued before them.  vmcnt retires loads
+            // and stores in issue order (hipcc itself waits vmcnt(2) for "load; store; store; use"), so slice 0 has landed once at most (its 2 NDMA younger DMAs +
+            // NST stores) are outstanding -- the stores need not drain here, nor in front of slices 1 and 2 (step's PEND waits); slice 3's wait is behind them.
+            const bool pend = PST && tile != (int)blockIdx.x && p.ws != nullptr && nsteps >= NS + 3 && gridDim.z == 1;
             if (DBG == 5) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(VM_TWO + 16) : "memory");
+            else if (pend) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(VM_TWO + NST) : "memory");
             else if (NS > 3 && nsteps > 3) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(3 * NDMA) : "memory");
             else if (nsteps > 2) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(VM_TWO) : "memory");
             else if (nsteps > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(VM_ONE) : "memory");
@@ -1147,22 +1160,29 @@ __global__ __launch_bounds__(WN * 128, 2) void gemm_ringx_kernel(GemmP p, int KT
 #pragma unroll
             for (int j = 0; j < 4; ++j) b0[j] = *reinterpret_cast<const bf16x8_t*>(lds + boff + j * 512);
             int slot = 0, s = 0;
+            if (pend) {       // (pend implies nsteps >= NS + 3: the first pair is a steady pair)
+                step(std::true_type{}, 0, 0, b0, b1, std::true_type{});
+                step(std::true_type{}, 1, 1, b1, b0, std::true_type{});
+                slot = 2 % NS; s = 2;
+            }
             for (; s + NS + 1 < nsteps; s += 2) {
-                step(std::true_type{}, s, slot, b0, b1);
+                step(std::true_type{}, s, slot, b0, b1, std::false_type{});
                 slot = slot == NS - 1 ? 0 : slot + 1;
-                step(std::true_type{}, s + 1, slot, b1, b0);
+                step(std::true_type{}, s + 1, slot, b1, b0, std::false_type{});
                 slot = slot == NS - 1 ? 0 : slot + 1;
             }
             for (; s < nsteps; s += 2) {
-                step(std::false_type{}, s, slot, b0, b1);
+                step(std::false_type{}, s, slot, b0, b1, std::false_type{});
                 slot = slot == NS - 1 ? 0 : slot + 1;
                 if (s + 1 < nsteps) {
-                    step(std::false_type{}, s + 1, slot, b1, b0);
+                    step(std::false_type{}, s + 1, slot, b1, b0, std::false_type{});
                     slot = slot == NS - 1 ? 0 : slot + 1;
                 }
             }
             const int em0 = m0, en0 = n0;
+            bf16_t* const dump = (bf16_t*)p.ws + tid * 8;          // masked lanes store here: the store COUNT per wave must not depend on the tile (16 bytes per thread, content irrelevant)
             if (tile + G < nblk) { tile_origin(tile + G); tile_sources(); prologue(); }
+            __builtin_amdgcn_sched_barrier(0);          // the output stores below stay BEHIND the next tile's first DMAs (the counted waits rely on that order)
             if (gridDim.z > 1) {
                 float* wsl = p.ws + (long long)blockIdx.z * p.M * p.N;
 #pragma unroll
@@ -1190,7 +1210,9 @@ __global__ __launch_bounds__(WN * 128, 2) void gemm_ringx_kernel(GemmP p, int KT
                     const int ob = (nb >> 5) * 16;
                     const int ns0 = min(nb, p.N - 32) + lq * 4, ns1 = min(nb + 32, p.N - 32) + lq * 4;      // N tail: clamp the scale reads
                     const s16x8_t v = pair_to_row8(big_value_swiglu(acc[i][0], acc[i][1], p.wscale, ns0), big_value_swiglu(acc[i][2], acc[i][3], p.wscale, ns1));
-                    if (m < p.M && nb + 32 * (lq & 1) + 32 <= p.N) *reinterpret_cast<s16x8_t*>((bf16_t*)p.Y + (long long)m * p.ldy + ob + (lq & 1) * 16 + (lq >> 1) * 8) = v;
+                    const bool ok = m < p.M && nb + 32 * (lq & 1) + 32 <= p.N;
+                    if (PST && p.ws) *reinterpret_cast<s16x8_t*>(ok ? (bf16_t*)p.Y + (long long)m * p.ldy + ob + (lq & 1) * 16 + (lq >> 1) * 8 : dump) = v;
+                    else if (ok) *reinterpret_cast<s16x8_t*>((bf16_t*)p.Y + (long long)m * p.ldy + ob + (lq & 1) * 16 + (lq >> 1) * 8) = v;
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; j += 2) {
@@ -1198,8 +1220,11 @@ __global__ __launch_bounds__(WN * 128, 2) void gemm_ringx_kernel(GemmP p, int KT
                         const int na = nb + 16 <= p.N ? nb : p.N - 16, nc = nb + 32 <= p.N ? nb + 16 : p.N - 16;
                         const s16x8_t v = pair_to_row8(big_value<EPI>(p, mc, na + lq * 4, acc[i][j]), big_value<EPI>(p, mc, nc + lq * 4, acc[i][j + 1]));
                         if constexpr (DBG == 6) { const u32x4_t w = __builtin_bit_cast(u32x4_t, v); asm volatile("" :: "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3])); }      // timing only: converted, not stored
-                        else
-                        if (m < p.M && nb + 16 * (lq & 1) + 16 <= p.N) *reinterpret_cast<s16x8_t*>((bf16_t*)p.Y + (long long)m * p.ldy + nb + (lq & 1) * 16 + (lq >> 1) * 8) = v;
+                        else {
+                            const bool ok = m < p.M && nb + 16 * (lq & 1) + 16 <= p.N;
+                            if (PST && p.ws) *reinterpret_cast<s16x8_t*>(ok ? (bf16_t*)p.Y + (long long)m * p.ldy + nb + (lq & 1) * 16 + (lq >> 1) * 8 : dump) = v;
+                            else if (ok) *reinterpret_cast<s16x8_t*>((bf16_t*)p.Y + (long long)m * p.ldy + nb + (lq & 1) * 16 + (lq >> 1) * 8) = v;
+                        }
                     }
                 }
             }
