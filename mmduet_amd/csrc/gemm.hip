@@ -783,6 +783,31 @@ __device__ __forceinline__ s16x4_t big_value(const GemmP& p, int m, int n, const
     }
     return s16x4_t{(short)f2bf(v[0]), (short)f2bf(v[1]), (short)f2bf(v[2]), (short)f2bf(v[3])};
 }
+// the same value from operands the caller already holds: per-column weight scale / bias quads (one load per TILE, not per row) and the residual quad of
+// this row (prefetched one row ahead).  Same arithmetic, same rounding points.
+template <int EPI>
+__device__ __forceinline__ s16x4_t big_value_pre(const f32x4_t& a, bool has_scale, const f32x4_t& sc, bool has_bias, const s16x4_t& b, const s16x4_t& rr) {
+    float v[4] = {a[0], a[1], a[2], a[3]};
+    if (has_scale) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= sc[r];
+    }
+    if (has_bias) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += bf2f((bf16_t)b[r]);
+    }
+    if constexpr (EPI == EPI_GELU_TANH) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_fast(bf2f(f2bf(v[r])));
+    } else if constexpr (EPI == EPI_GELU_ERF) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_erf_fast(bf2f(f2bf(v[r])));
+    } else if constexpr (EPI == EPI_RESID) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = bf2f(f2bf(v[r])) + bf2f((bf16_t)rr[r]);
+    }
+    return s16x4_t{(short)f2bf(v[0]), (short)f2bf(v[1]), (short)f2bf(v[2]), (short)f2bf(v[3])};
+}
 template <int EPI>
 __device__ __forceinline__ void big_store(const GemmP& p, int m, int n, const f32x4_t& a) {
     if (m >= p.M) return;
@@ -1147,7 +1172,7 @@ __global__ __launch_bounds__(WN * 128, 2) void gemm_ringx_kernel(GemmP p, int KT
             // pend: this block's previous tile left exactly NST output stores in flight behind the DMAs of slices 0..2 issued before them.  vmcnt retires loads
             // and stores in issue order (hipcc itself waits vmcnt(2) for "load; store; store; use"), so slice 0 has landed once at most (its 2 NDMA younger DMAs +
             // NST stores) are outstanding -- the stores need not drain here, nor in front of slices 1 and 2 (step's PEND waits); slice 3's wait is behind them.
-            const bool pend = PST && tile != (int)blockIdx.x && p.ws != nullptr && nsteps >= NS + 3 && gridDim.z == 1;
+            const bool pend = PST && tile != (int)blockIdx.x && nsteps >= NS + 3 && gridDim.z == 1;
             if (DBG == 5) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(VM_TWO + 16) : "memory");
             else if (pend) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(VM_TWO + NST) : "memory");
             else if (NS > 3 && nsteps > 3) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(3 * NDMA) : "memory");
@@ -1180,7 +1205,8 @@ __global__ __launch_bounds__(WN * 128, 2) void gemm_ringx_kernel(GemmP p, int KT
                 }
             }
             const int em0 = m0, en0 = n0;
-            bf16_t* const dump = (bf16_t*)p.ws + tid * 8;          // masked lanes store here: the store COUNT per wave must not depend on the tile (16 bytes per thread, content irrelevant)
+            bf16_t* const dump = (bf16_t*)p.ws + tid * 8;          // masked lanes store here: the store COUNT per wave must not depend on the tile (16 bytes per thread, content irrelevant;
+                                                                   // the launcher guarantees p.ws, a process-wide 8 KB slot when the caller has no split-K workspace)
             if (tile + G < nblk) { tile_origin(tile + G); tile_sources(); prologue(); }
             __builtin_amdgcn_sched_barrier(0);          // the output stores below stay BEHIND the next tile's first DMAs (the counted waits rely on that order)
             if (gridDim.z > 1) {
@@ -1195,6 +1221,27 @@ __global__ __launch_bounds__(WN * 128, 2) void gemm_ringx_kernel(GemmP p, int KT
                 }
                 return;
             }
+            // per-column operands of this wave's four 16-column tiles: ONE load per tile (they do not depend on the row); the residual quads of a row are
+            // fetched while the previous row is converted and stored -- a load issued BEFORE a row's stores is older than them, so waiting for it does not
+            // drain them (the compiler, left alone, loaded one residual quad at a time with a full vmcnt(0) after each)
+            f32x4_t scq[4]; s16x4_t biq[4], rq[4], rnext[4];
+            int ncol[4];
+            const bool has_sc = p.wscale != nullptr, has_bi = p.bias != nullptr;
+            if constexpr (EPI != EPI_SWIGLU) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int nb = en0 + wc * 64 + (j & ~1) * 16;
+                    ncol[j] = ((j & 1) ? (nb + 32 <= p.N ? nb + 16 : p.N - 16) : (nb + 16 <= p.N ? nb : p.N - 16)) + lq * 4;      // N tail: clamp the reads, mask the stores
+                    scq[j] = has_sc ? *reinterpret_cast<const f32x4_t*>(p.wscale + ncol[j]) : f32x4_t{1, 1, 1, 1};
+                    biq[j] = has_bi ? *reinterpret_cast<const s16x4_t*>((const bf16_t*)p.bias + ncol[j]) : s16x4_t{0, 0, 0, 0};
+                    rq[j] = rnext[j] = s16x4_t{0, 0, 0, 0};
+                }
+                if constexpr (EPI == EPI_RESID) {
+                    const int m = min(em0 + wr * 128 + lr, p.M - 1);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) rnext[j] = *reinterpret_cast<const s16x4_t*>((const bf16_t*)p.R + (long long)m * p.ldr + ncol[j]);
+                }
+            }
             if constexpr (DBG == 4) {          // timing only: no conversion, no stores (the accumulators stay live)
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
@@ -1205,24 +1252,33 @@ __global__ __launch_bounds__(WN * 128, 2) void gemm_ringx_kernel(GemmP p, int KT
             for (int i = 0; i < 8; ++i) {
                 const int m = em0 + wr * 128 + i * 16 + lr;
                 const int mc = m < p.M ? m : p.M - 1;
+                if constexpr (EPI == EPI_RESID) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) rq[j] = rnext[j];
+                    if (i < 7) {
+                        const int mn = min(m + 16, p.M - 1);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) rnext[j] = *reinterpret_cast<const s16x4_t*>((const bf16_t*)p.R + (long long)mn * p.ldr + ncol[j]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);          // keep the next row's residual loads AHEAD of this row's stores (older => waiting for them leaves the stores in flight)
+                }
                 if constexpr (EPI == EPI_SWIGLU) {
                     const int nb = en0 + wc * 64;
                     const int ob = (nb >> 5) * 16;
                     const int ns0 = min(nb, p.N - 32) + lq * 4, ns1 = min(nb + 32, p.N - 32) + lq * 4;      // N tail: clamp the scale reads
                     const s16x8_t v = pair_to_row8(big_value_swiglu(acc[i][0], acc[i][1], p.wscale, ns0), big_value_swiglu(acc[i][2], acc[i][3], p.wscale, ns1));
                     const bool ok = m < p.M && nb + 32 * (lq & 1) + 32 <= p.N;
-                    if (PST && p.ws) *reinterpret_cast<s16x8_t*>(ok ? (bf16_t*)p.Y + (long long)m * p.ldy + ob + (lq & 1) * 16 + (lq >> 1) * 8 : dump) = v;
+                    if constexpr (PST) *reinterpret_cast<s16x8_t*>(ok ? (bf16_t*)p.Y + (long long)m * p.ldy + ob + (lq & 1) * 16 + (lq >> 1) * 8 : dump) = v;
                     else if (ok) *reinterpret_cast<s16x8_t*>((bf16_t*)p.Y + (long long)m * p.ldy + ob + (lq & 1) * 16 + (lq >> 1) * 8) = v;
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; j += 2) {
                         const int nb = en0 + wc * 64 + j * 16;
-                        const int na = nb + 16 <= p.N ? nb : p.N - 16, nc = nb + 32 <= p.N ? nb + 16 : p.N - 16;
-                        const s16x8_t v = pair_to_row8(big_value<EPI>(p, mc, na + lq * 4, acc[i][j]), big_value<EPI>(p, mc, nc + lq * 4, acc[i][j + 1]));
+                        const s16x8_t v = pair_to_row8(big_value_pre<EPI>(acc[i][j], has_sc, scq[j], has_bi, biq[j], rq[j]), big_value_pre<EPI>(acc[i][j + 1], has_sc, scq[j + 1], has_bi, biq[j + 1], rq[j + 1]));
                         if constexpr (DBG == 6) { const u32x4_t w = __builtin_bit_cast(u32x4_t, v); asm volatile("" :: "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3])); }      // timing only: converted, not stored
                         else {
                             const bool ok = m < p.M && nb + 16 * (lq & 1) + 16 <= p.N;
-                            if (PST && p.ws) *reinterpret_cast<s16x8_t*>(ok ? (bf16_t*)p.Y + (long long)m * p.ldy + nb + (lq & 1) * 16 + (lq >> 1) * 8 : dump) = v;
+                            if constexpr (PST) *reinterpret_cast<s16x8_t*>(ok ? (bf16_t*)p.Y + (long long)m * p.ldy + nb + (lq & 1) * 16 + (lq >> 1) * 8 : dump) = v;
                             else if (ok) *reinterpret_cast<s16x8_t*>((bf16_t*)p.Y + (long long)m * p.ldy + nb + (lq & 1) * 16 + (lq >> 1) * 8) = v;
                         }
                     }
@@ -1390,6 +1446,11 @@ static hipError_t launch_ringx_t(const GemmP& p, const GemmArgs& a, hipStream_t 
     }
     const dim3 block(WN * 128);
     GemmP q = p;
+    if (!q.ws) {           // the kernel's masked output lanes need somewhere harmless to store (see PST in the kernel)
+        static float* dump_slot = nullptr;
+        if (!dump_slot && hipMalloc((void**)&dump_slot, 8192) != hipSuccess) return hipErrorOutOfMemory;
+        q.ws = dump_slot;
+    }
     // start-up stagger of the second-slot blocks in ~4 us units: about half a tile (K/32 steps of ~0.75 us) -- see the kernel
     q.kper = (!stagger || splits > 1) ? 0 : ((a.K / 32) * 10) / 100 + 1;
     switch (a.epi) {
