@@ -941,10 +941,29 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(GemmP p, int KT) {
         }
         return;
     }
+    // operands of the epilogue, fetched in ONE batch: per-column scale / bias quads (once per tile) and every residual quad of the wave's TM x TN tiles
+    // (left to the compiler, each quad was loaded right before its use behind a full vmcnt(0): up to 24 serial round trips per tile)
+    [[maybe_unused]] f32x4_t scq[TN]; [[maybe_unused]] s16x4_t biq[TN]; [[maybe_unused]] s16x4_t rq[TM][TN];
+    const bool has_sc = p.wscale != nullptr, has_bi = p.bias != nullptr;
+    if constexpr (EPI != EPI_SWIGLU) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn + j * 16 + lq * 4;
+            scq[j] = has_sc ? *reinterpret_cast<const f32x4_t*>(p.wscale + n) : f32x4_t{1, 1, 1, 1};
+            biq[j] = has_bi ? *reinterpret_cast<const s16x4_t*>((const bf16_t*)p.bias + n) : s16x4_t{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                rq[i][j] = s16x4_t{0, 0, 0, 0};
+                if constexpr (EPI == EPI_RESID) rq[i][j] = *reinterpret_cast<const s16x4_t*>((const bf16_t*)p.R + (long long)min(m0 + wm + i * 16 + lr, p.M - 1) * p.ldr + n0 + wn + j * 16 + lq * 4);
+            }
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + wm + i * 16 + lr;
-        const int mc = m < p.M ? m : p.M - 1;                                       // rows past M compute on a valid row and are not stored
+        [[maybe_unused]] const int mc = m < p.M ? m : p.M - 1;                      // rows past M compute on a valid row and are not stored
         if constexpr (EPI == EPI_SWIGLU) {
             if constexpr (TN == 4) {                                                // two output tiles: row-contiguous 16-byte stores (pair_to_row8)
                 const int nb = n0 + wn, ob = (nb >> 5) * 16;
@@ -958,7 +977,7 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(GemmP p, int KT) {
 #pragma unroll
             for (int j = 0; j < TN; j += 2) {
                 const int nb = n0 + wn + j * 16;
-                const s16x8_t v = pair_to_row8(big_value<EPI>(p, mc, nb + lq * 4, acc[i][j]), big_value<EPI>(p, mc, nb + 16 + lq * 4, acc[i][j + 1]));
+                const s16x8_t v = pair_to_row8(big_value_pre<EPI>(acc[i][j], has_sc, scq[j], has_bi, biq[j], rq[i][j]), big_value_pre<EPI>(acc[i][j + 1], has_sc, scq[j + 1], has_bi, biq[j + 1], rq[i][j + 1]));
                 if (m < p.M) *reinterpret_cast<s16x8_t*>((bf16_t*)p.Y + (long long)m * p.ldy + nb + (lq & 1) * 16 + (lq >> 1) * 8) = v;
             }
         }
