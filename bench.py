@@ -382,9 +382,11 @@ def main():
     sync()
     t0 = time.perf_counter()
     fwd = 0
+    step_blocks = []
     for _ in range(args.steps):
         scs, n_resp = one_step()
         allsc, lens = gather_scores(scs, t_max=T, n_max=S)                 # ONE RCCL all-gather of the padded score block
+        step_blocks.append(allsc)
         fwd += driver.forward_calls if multi_runner is None else multi_runner.ms.rounds
     sync()
     dt = time.perf_counter() - t0
@@ -395,6 +397,16 @@ def main():
     dt = float(tmax.item())
     prof = model.prof_read()
     assert allsc.shape == (world, S, T, 2) and int(lens.min()) == T
+    # what was timed is checked (outside the timed region): every gathered score of every step is a finite probability, and -- same frames, same weights,
+    # fixed reduction orders, no atomics -- every timed step produced the SAME bits whatever the tower / decode overlap did
+    blocks = [b.cpu() for b in step_blocks]
+    finite = all(bool(torch.isfinite(b).all()) and bool(((b >= 0) & (b <= 1)).all()) for b in blocks)
+    identical = all(torch.equal(b, blocks[0]) for b in blocks[1:])
+    step_maxdiff = max([float((b - blocks[0]).abs().max()) for b in blocks[1:]], default=0.0)
+    if not finite:
+        raise SystemExit('bench.py: non-finite / out-of-range scores in the timed region')
+    verified = dict(scores_finite_in_0_1=finite, steps_bit_identical=identical, max_abs_step_to_step_diff=step_maxdiff, steps_compared=len(blocks),
+                    note='all per-frame scores of all timed steps; parity of this workload against the fp32 oracle: tests/test_gpu_fullsize.py')
 
     def roof_from(p, name):
         avg_ms = p['ms'] / p['launches']
@@ -474,7 +486,7 @@ def main():
                        'kv_tokens_end': kv_end, 'weights': ('random init N(0,0.02), true shapes' if not args.tiny else 'tiny') + ('' if args.weights == 'bf16' else ', LLM matrices quantised to fp8 e4m3 per output channel'),
                        'parallelism': f'dp{world} ({S} stream(s) per GPU, one RCCL all-gather of the [{world},{S},{T}+1,2] score block per step)',
                        'native_gather_check': native, 'tower_overlap': not args.no_overlap, 'phase': 'A+B' if args.phase == 'ab' else 'B only (frame embeddings pre-extracted to a feature file; LLM side alone)', 'layers_override': args.layers},
-            'roofline': roof, 'roofline_secondary': roof2, 'cpu_baseline': cpu, 'multi_stream': multi,
+            'verified': verified, 'roofline': roof, 'roofline_secondary': roof2, 'cpu_baseline': cpu, 'multi_stream': multi,
         }
         import ctypes
         ctypes.CDLL(None).fflush(None)          # RCCL's banner sits in C stdio's buffer when stdout is a pipe: push it out BEFORE the JSON line

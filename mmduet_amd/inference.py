@@ -92,6 +92,7 @@ class LiveInferForBenchmark:
         self.repetition_penalty = args.repetition_penalty
         self.frames_per_forward = max(1, int(getattr(args, 'frames_per_forward', 1)))
         self.overlap_vision = bool(getattr(args, 'overlap_vision', True))
+        self.record_head_logits = False          # diagnostics (parity tests, bench.py's self-check): debug_data entries also carry the 4 raw head logits of the frame
         self.reuse_chunk_tail = True             # remove_assistant_turns: keep the chunk's frames behind a response instead of replaying them (same context)
         self._vit_stream = None
         self.vit_lookahead_batches = None      # None: the whole video is queued on the tower stream at once (unless the burst schedule below is on)
@@ -304,7 +305,8 @@ class LiveInferForBenchmark:
         # 2-way softmax of the head logits on the host, in plain Python: a CPU torch op here wakes torch's intra-op thread pool
         # (one spinning thread per visible core), which on a CPU-quota'd box gets the process throttled for tens of ms at a time
         probs_inf, probs_rel = [], []
-        for l0, l1, r0, r1 in head_logits.tolist():
+        self._chunk_head_logits = head_logits.tolist()
+        for l0, l1, r0, r1 in self._chunk_head_logits:
             probs_inf.append(_p1(l0, l1)); probs_rel.append(_p1(r0, r1))
         ends = [n0 + P + (j + 1) * nt for j in range(len(frames))]
         return list(zip(probs_inf, probs_rel)), ends, cache
@@ -408,6 +410,8 @@ class LiveInferForBenchmark:
                 self.last_role = 'stream'
                 video_scores = {'informative_score': scores[j][0], 'relevance_score': scores[j][1]}
                 self.debug_data_list.append(dict(time=self.video_time, **video_scores))
+                if self.record_head_logits:
+                    self.debug_data_list[-1]['head_logits'] = self._chunk_head_logits[j]
                 # 3./4. decide, respond
                 if self._decide(video_scores):
                     last = j == k - 1
