@@ -109,7 +109,7 @@ def test_production_gemm_shapes_take_the_production_kernel_and_match_fp32(ops, n
         assert plan['kernel'] in RING and plan['splits'] >= expect['min_splits'], plan                                        # automatic split-K over grid.z
 
 
-@pytest.mark.parametrize('variant', [16, 17, 18, 19, 24, 32, 33, 40, 42])
+@pytest.mark.parametrize('variant', [16, 17, 18, 19, 24, 32, 33, 40, 42, 160])
 @pytest.mark.parametrize('name,M,N,K,epi', [('vit_fc1', 25515, 4352, 1152, 'gelu_tanh'), ('vit_o', 25515, 1152, 1152, 'resid'), ('gate_up_tail', 1303, 37888, 3584, 'swiglu'),
                                             ('ragged', 3000, 1184, 704, 'none')])
 def test_every_ring_instantiation_at_production_shapes(ops, variant, name, M, N, K, epi):

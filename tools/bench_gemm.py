@@ -48,7 +48,7 @@ if __name__ == '__main__':
     which = sys.argv[1] if len(sys.argv) > 1 else 'prod'
     if which == 'prod':
         rows = []
-        variants = [(0, 'auto'), (4, 'big'), (6, 'ring256'), (16, 'rx-8w'), (17, 'rx-4w'), (24, 'rx-8w-ns4'), (32, 'rx-8w-early'), (33, 'rx-4w-early'), (40, 'rx-8w-ns4-early'), (42, 'rx-8w-m32-ns4-early'),
+        variants = [(0, 'auto'), (4, 'big'), (6, 'ring256'), (16, 'rx-8w'), (17, 'rx-4w'), (24, 'rx-8w-ns4'), (32, 'rx-8w-early'), (33, 'rx-4w-early'), (40, 'rx-8w-ns4-early'), (42, 'rx-8w-m32-ns4-early'), (160, 'rx-8w-early-defer'),
                     (7, 'ring256-splitK'), (44, 'rx-8w-ns4-early-splitK'), (49, 'rx-4w-nostagger'), (65, 'rx-4w-early-nostagger'), (96, 'DBG-x-contig'), (97, 'DBG-no-x'), (98, 'DBG-no-dma'), (99, 'DBG-no-epilogue'), (95, 'DBG-stores-pending'), (94, 'DBG-convert-no-store')]
         if len(sys.argv) > 3: variants = [v for v in variants if v[1] in sys.argv[3].split(',')]
         for M, shapes in ((25515, VIT), (1274, LLM[:4]), (1323, LLM[:4])):
