@@ -342,6 +342,20 @@ def main():
     one_step()
     model.prof_enable(False)
     prof_all = model.prof_read()
+    # the same with tower and LLM on ONE HIP stream and a wall clock around it: what fraction of the wall is no kernel of ours running (host scheduling,
+    # launch gaps, syncs).  Diagnostic for an N-rank run on a CPU-quota'd box: a rank that gets fewer cores shows a larger idle fraction, not slower kernels.
+    gpu_idle = None
+    if multi_runner is None:
+        d1 = make_driver(argparse.Namespace(**{**vars(args), 'no_overlap': True}), model, tok, threshold, forced)
+        run_stream(d1, frames, query)                           # (workspaces / arenas warm)
+        model.prof_reset(); model.prof_set_stride(1); model.prof_enable(True)
+        torch.cuda.synchronize(device); tw = time.perf_counter()
+        run_stream(d1, frames, query)
+        torch.cuda.synchronize(device); tw = time.perf_counter() - tw
+        model.prof_enable(False)
+        busy = sum(v['ms'] for v in model.prof_read().values()) * 1e-3
+        gpu_idle = dict(frac=round(max(0.0, 1.0 - busy / tw), 4), wall_ms=round(tw * 1e3, 1), kernel_ms=round(busy * 1e3, 1),
+                        note='one stream, every launch bracketed with HIP events (untimed pass; the event pairs themselves add ~2 us per launch to the wall)')
     dom = max(prof_all, key=lambda k: prof_all[k]['ms'])
     # the tile-GEMM class (MFMA-bound: tower + LLM chunk GEMMs) and the weight-streaming class (HBM-bound: decode GEMV) are within a few per cent
     # of each other on this workload; the roofline object stays on the MFMA class whenever it is within 20 % of the largest one (so the figure
@@ -358,38 +372,38 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
-    # the C-ABI gather (mmd_gather_scores: ncclAllGather issued by libmmduet_hip) is checked against torch.distributed's outside
-    # the timed region; the timed region uses the torch.distributed transport
-    native = None
+    # The timed region gathers through the C ABI (mmd_gather_block: ONE ncclAllGather issued by libmmduet_hip on the current stream); torch.distributed's
+    # all_gather_into_tensor is the cross-check, outside the timed region.  Constructing the communicator is collective and agrees on success across ranks.
+    ng, native = None, None
+    try:
+        ng = NativeScoreGather(device)
+    except Exception as e:
+        native = f'unavailable, timed region uses torch.distributed: {type(e).__name__}: {e}'
+
+    def gather(scs):
+        return ng.gather_streams(scs, T, S) if ng is not None else gather_scores(scs, t_max=T, n_max=S)
+
     n_resp = 0
     for w in range(max(1, args.warmup) if world > 1 else args.warmup):
         scs, n_resp = one_step()
-        allsc, lens = gather_scores(scs, t_max=T, n_max=S)
-        if w == 0:
-            try:
-                ng = NativeScoreGather(device)
-                a2, l2 = ng.gather(scs[0].to(device), T)
-                torch.cuda.synchronize(device)
-                ok = torch.equal(l2.cpu(), lens[:, 0].cpu()) and torch.equal(torch.nan_to_num(a2.cpu()), torch.nan_to_num(allsc[:, 0].cpu()))
-                native = 'ok' if ok else 'MISMATCH vs torch.distributed'
-                ng.close()
-            except Exception as e:
-                native = f'error: {type(e).__name__}: {e}'
+        allsc, lens = gather(scs)
     prof_on = not args.no_prof
     model.prof_reset()
     model.prof_set_stride(args.prof_stride)                 # every 7th launch of the class carries the two HIP events (sampling)
     model.prof_enable([dom] + ([second] if second else []) if prof_on else False)        # only the dominant class(es) are bracketed inside the timed region
     sync()
     t0 = time.perf_counter()
+    cpu0 = time.process_time()
     fwd = 0
     step_blocks = []
     for _ in range(args.steps):
         scs, n_resp = one_step()
-        allsc, lens = gather_scores(scs, t_max=T, n_max=S)                 # ONE RCCL all-gather of the padded score block
+        allsc, lens = gather(scs)                                          # ONE RCCL all-gather of the padded score block
         step_blocks.append(allsc)
         fwd += driver.forward_calls if multi_runner is None else multi_runner.ms.rounds
     sync()
     dt = time.perf_counter() - t0
+    host_cpu_s = time.process_time() - cpu0                                # user + system CPU seconds of this rank's process (all its threads) inside the timed region
     model.prof_enable(False)
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1:
@@ -397,6 +411,11 @@ def main():
     dt = float(tmax.item())
     prof = model.prof_read()
     assert allsc.shape == (world, S, T, 2) and int(lens.min()) == T
+    if ng is not None:          # cross-check of the native transport against torch.distributed's, same scores, outside the timed region
+        a2, l2 = gather_scores(scs, t_max=T, n_max=S)
+        same = torch.equal(l2.cpu(), lens.cpu()) and torch.equal(torch.nan_to_num(a2.cpu()), torch.nan_to_num(allsc.cpu()))
+        native = 'ok' if same else 'MISMATCH vs torch.distributed'
+        ng.close()
     # what was timed is checked (outside the timed region): every gathered score of every step is a finite probability, and -- same frames, same weights,
     # fixed reduction orders, no atomics -- every timed step produced the SAME bits whatever the tower / decode overlap did
     blocks = [b.cpu() for b in step_blocks]
@@ -479,12 +498,14 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 2),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16' if args.weights == 'bf16' else 'fp8_e4m3 weights x bf16 activations',
             'data': 'synthetic', 'rccl_ranks': rccl_ranks,
+            'host_cpu_s_per_step': round(host_cpu_s / max(1, args.steps), 3), 'nproc_granted': effective_cpus(), 'nproc_visible': os.cpu_count(),
+            'torch_threads': torch.get_num_threads(), 'gpu_idle_frac': gpu_idle,
             'config': {'workload': ('tiny-plumbing' if args.tiny else 'llava-onevision-qwen2-7b + siglip-so400m-384') +
                        f', {args.frames}-frame 1fps {R}px stream{"s" if S > 1 else ""} ({S} per GPU), ' + CONFIGS[args.config]['text'],
                        'name': args.config, 'frames_per_forward': args.frames_per_forward, 'streams_per_gpu': S, 'responses_per_stream': int(n_resp),
                        'max_new_tokens': args.max_new_tokens, 'response_frames': forced, 'llm_forwards_per_step': fwd // max(1, args.steps),
                        'kv_tokens_end': kv_end, 'weights': ('random init N(0,0.02), true shapes' if not args.tiny else 'tiny') + ('' if args.weights == 'bf16' else ', LLM matrices quantised to fp8 e4m3 per output channel'),
-                       'parallelism': f'dp{world} ({S} stream(s) per GPU, one RCCL all-gather of the [{world},{S},{T}+1,2] score block per step)',
+                       'parallelism': f'dp{world} ({S} stream(s) per GPU, one RCCL all-gather of the [{world},{S},{T}+1,2] score block per step, issued by libmmduet_hip (mmd_gather_block))',
                        'native_gather_check': native, 'tower_overlap': not args.no_overlap, 'phase': 'A+B' if args.phase == 'ab' else 'B only (frame embeddings pre-extracted to a feature file; LLM side alone)', 'layers_override': args.layers},
             'verified': verified, 'roofline': roof, 'roofline_secondary': roof2, 'cpu_baseline': cpu, 'multi_stream': multi,
         }

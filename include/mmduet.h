@@ -203,6 +203,9 @@ void mmd_comm_destroy(mmd_comm* comm);
 int mmd_comm_world(const mmd_comm* comm);
 const char* mmd_comm_last_error(const mmd_comm* comm);    /* comm may be NULL: error of the last failed create / unique_id */
 int mmd_gather_scores(mmd_comm* comm, const float* local, int T, int t_max, float* all);
+int mmd_comm_probe(void);                                          /* MMD_OK if librccl can be bound (asked by every rank before the collective create) */
+int mmd_comm_set_stream(mmd_comm* comm, void* hip_stream);         /* the stream the following gathers are issued on */
+int mmd_gather_block(mmd_comm* comm, const float* block, int64_t n_floats, float* all);   /* raw: [n_floats] per rank -> [world, n_floats], one ncclAllGather */
 
 /* ---- measurement ---------------------------------------------------------------------------------------------- */
 /* HIP-event timing of kernel classes on the context's stream (bench.py `roofline`).  While enabled every launch of a

@@ -75,6 +75,9 @@ _SIGS = {
     'mmd_comm_world': (_I, [_VP]),
     'mmd_comm_last_error': (C.c_char_p, [_VP]),
     'mmd_gather_scores': (_I, [_VP, _VP, _I, _I, _VP]),
+    'mmd_comm_probe': (_I, []),
+    'mmd_comm_set_stream': (_I, [_VP, _VP]),
+    'mmd_gather_block': (_I, [_VP, _VP, C.c_int64, _VP]),
     'mmd_llm_step': (_I, [_VP, _VP, _VP, _I, _VP]),
     'mmd_video_heads': (_I, [_VP, _VP, _I, _VP]),
     'mmd_lm_head': (_I, [_VP, _VP, _I, _VP]),

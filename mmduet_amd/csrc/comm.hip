@@ -31,11 +31,14 @@ static std::once_flag g_rccl_once;
 static bool rccl_load() {
     std::call_once(g_rccl_once, []() {
         Rccl& r = g_rccl;
+        std::string first;
         for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
             r.h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
             if (r.h) break;
+            const char* e = dlerror();          // ONE call: dlerror() clears the error state, a second call returns NULL
+            if (first.empty()) first = std::string(name) + ": " + (e ? e : "?");
         }
-        if (!r.h) { r.err = std::string("dlopen(librccl.so.1) failed: ") + (dlerror() ? dlerror() : "?"); return; }
+        if (!r.h) { r.err = "dlopen of librccl failed (" + first + ")"; return; }
 #define SYM(field, sym) r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.h, sym)); if (!r.field) { r.err = std::string("librccl lacks ") + sym; return; }
         SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommDestroy, "ncclCommDestroy")
         SYM(AllGather, "ncclAllGather") SYM(GetErrorString, "ncclGetErrorString")
@@ -92,6 +95,19 @@ extern "C" void mmd_comm_destroy(mmd_comm* c) {
 }
 
 extern "C" int mmd_comm_world(const mmd_comm* c) { return c ? c->world : -1; }
+// can librccl be bound at all?  (every rank asks BEFORE the collective mmd_comm_create, so that a rank without the library fails with the others instead of leaving them hanging)
+extern "C" int mmd_comm_probe(void) { if (!rccl_load()) { g_comm_error = g_rccl.err; return MMD_ENOENT; } return MMD_OK; }
+// the HIP stream the next gathers are issued on (the caller's current stream: the gather is then ordered behind the kernels that produced its input and ahead of its consumers)
+extern "C" int mmd_comm_set_stream(mmd_comm* c, void* hip_stream) { if (!c) return MMD_EINVAL; c->stream = (hipStream_t)hip_stream; return MMD_OK; }
+// raw form: every rank contributes `n_floats` fp32 (device) -> all [world, n_floats] (device); ONE ncclAllGather, no staging (the padded [n_max, t_max + 1, 2]
+// block of several streams per rank, assembled by the caller)
+extern "C" int mmd_gather_block(mmd_comm* c, const float* block, int64_t n_floats, float* all) {
+    if (!c || !block || !all || n_floats <= 0) return MMD_EINVAL;
+    hipSetDevice(c->device);
+    ncclResult_t r = g_rccl.AllGather(block, all, (size_t)n_floats, ncclFloat32, c->comm, c->stream);
+    if (r != ncclSuccess) { c->err = std::string("ncclAllGather: ") + g_rccl.GetErrorString(r); return MMD_EHIP; }
+    return MMD_OK;
+}
 
 // local [T,2] fp32 (device) -> all [world, t_max + 1, 2] fp32 (device): row 0 of every rank's block carries (T, 0), rows
 // 1..T the scores, the rest NaN.  ONE ncclAllGather on the communicator's stream; no host synchronisation.

@@ -914,7 +914,7 @@ static void launch_big(const GemmP& p, const GemmArgs& a, hipStream_t st) {
 }
 
 
-template <int WN, bool M32, int NS, bool EARLY, bool DEFER = false>
+template <int WN, bool M32, int NS, bool EARLY>
 static hipError_t launch_ringx_t(const GemmP& p, const GemmArgs& a, hipStream_t st, int splits, bool stagger = true) {
     while (splits > 1 && (a.epi == EPI_SWIGLU || !a.splitk_ws || (size_t)splits * a.M * a.N * sizeof(float) > a.splitk_ws_bytes)) --splits;
     constexpr int BN = 64 * WN;
@@ -924,29 +924,32 @@ static hipError_t launch_ringx_t(const GemmP& p, const GemmArgs& a, hipStream_t 
     dim3 grid(splits > 1 || tiles <= cap ? tiles : cap, 1, splits);
     set_plan(a, WN == 2 ? GEMM_K_RING128X2 : GEMM_K_RING256, tiles, splits, (int)grid.x * splits);
     const int KT = a.K >> 5;
-    const size_t smem = NS * (256 * 32 + BN * 32) * sizeof(bf16_t) + (DEFER ? 65536 : 0);          // 96 KB / 72 KB (3 slots), 128 KB / 96 KB (4); DEFER: + the 64 KB output staging area = all 160 KB
-    static bool attr_set = false;
-    if (!attr_set) {
-#define RX_ATTR(E) hipFuncSetAttribute((const void*)gemm_ringx_kernel<E, WN, M32, NS, EARLY, 0, DEFER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    const size_t smem = NS * (256 * 32 + BN * 32) * sizeof(bf16_t);          // 96 KB / 72 KB (3 slots), 128 KB / 96 KB (4)
+    static bool attr_set[64] = {};          // per device (hipFuncSetAttribute applies to the current device's code object)
+    int adev = 0; hipGetDevice(&adev);
+    if (adev >= 0 && adev < 64 && !attr_set[adev]) {
+#define RX_ATTR(E) hipFuncSetAttribute((const void*)gemm_ringx_kernel<E, WN, M32, NS, EARLY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         RX_ATTR(EPI_NONE) RX_ATTR(EPI_GELU_TANH) RX_ATTR(EPI_GELU_ERF) RX_ATTR(EPI_RESID) RX_ATTR(EPI_SWIGLU)
 #undef RX_ATTR
-        attr_set = true;
+        attr_set[adev] = true;
     }
     const dim3 block(WN * 128);
     GemmP q = p;
-    if (!q.ws) {           // the kernel's masked output lanes need somewhere harmless to store (see PST in the kernel)
-        static float* dump_slot = nullptr;
-        if (!dump_slot && hipMalloc((void**)&dump_slot, 8192) != hipSuccess) return hipErrorOutOfMemory;
-        q.ws = dump_slot;
+    {                      // the kernel's masked output lanes need somewhere harmless to store (see PST in the kernel): one 8 KB buffer per device
+        static void* dump_slot[64] = {};
+        int dev = 0; hipGetDevice(&dev);
+        if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+        if (!dump_slot[dev] && hipMalloc(&dump_slot[dev], 8192) != hipSuccess) return hipErrorOutOfMemory;
+        q.dump = dump_slot[dev];
     }
     // start-up stagger of the second-slot blocks in ~4 us units: about half a tile (K/32 steps of ~0.75 us) -- see the kernel
     q.kper = (!stagger || splits > 1) ? 0 : ((a.K / 32) * 10) / 100 + 1;
     switch (a.epi) {
-        case EPI_GELU_TANH: hipLaunchKernelGGL((gemm_ringx_kernel<EPI_GELU_TANH, WN, M32, NS, EARLY, 0, DEFER>), grid, block, smem, st, q, KT); break;
-        case EPI_GELU_ERF: hipLaunchKernelGGL((gemm_ringx_kernel<EPI_GELU_ERF, WN, M32, NS, EARLY, 0, DEFER>), grid, block, smem, st, q, KT); break;
-        case EPI_RESID: hipLaunchKernelGGL((gemm_ringx_kernel<EPI_RESID, WN, M32, NS, EARLY, 0, DEFER>), grid, block, smem, st, q, KT); break;
-        case EPI_SWIGLU: hipLaunchKernelGGL((gemm_ringx_kernel<EPI_SWIGLU, WN, M32, NS, EARLY, 0, DEFER>), grid, block, smem, st, q, KT); break;
-        default: hipLaunchKernelGGL((gemm_ringx_kernel<EPI_NONE, WN, M32, NS, EARLY, 0, DEFER>), grid, block, smem, st, q, KT); break;
+        case EPI_GELU_TANH: hipLaunchKernelGGL((gemm_ringx_kernel<EPI_GELU_TANH, WN, M32, NS, EARLY>), grid, block, smem, st, q, KT); break;
+        case EPI_GELU_ERF: hipLaunchKernelGGL((gemm_ringx_kernel<EPI_GELU_ERF, WN, M32, NS, EARLY>), grid, block, smem, st, q, KT); break;
+        case EPI_RESID: hipLaunchKernelGGL((gemm_ringx_kernel<EPI_RESID, WN, M32, NS, EARLY>), grid, block, smem, st, q, KT); break;
+        case EPI_SWIGLU: hipLaunchKernelGGL((gemm_ringx_kernel<EPI_SWIGLU, WN, M32, NS, EARLY>), grid, block, smem, st, q, KT); break;
+        default: hipLaunchKernelGGL((gemm_ringx_kernel<EPI_NONE, WN, M32, NS, EARLY>), grid, block, smem, st, q, KT); break;
     }
     if (splits > 1) {
         long long work = (long long)a.M * ((a.N + 3) / 4);
@@ -954,6 +957,7 @@ static hipError_t launch_ringx_t(const GemmP& p, const GemmArgs& a, hipStream_t 
     }
     return hipGetLastError();
 }
+#ifdef MMDUET_DEBUG_VARIANTS
 template <int DBG>
 static hipError_t launch_ringx_dbg(const GemmP& p, const GemmArgs& a, hipStream_t st) {
     const int tiles = cdiv(a.N, 256) * cdiv(a.M, 256);
@@ -964,11 +968,10 @@ static hipError_t launch_ringx_dbg(const GemmP& p, const GemmArgs& a, hipStream_
     hipLaunchKernelGGL((gemm_ringx_kernel<EPI_NONE, 4, false, 3, true, DBG>), grid, dim3(512), smem, st, p, a.K >> 5);
     return hipGetLastError();
 }
-// flags: bit 0 = 4-wave 256x128 blocks (two per CU), bit 1 = 32x32x16 MFMA, bit 3 = 4-slot ring, bit 4 = refill DMAs in the first rows of a step,
-// bit 7 = DEFER (with 16 only: half of a tile's output stores staged in LDS and sent during the next tile's K loop; needs one K split and an output under 2 GB)
+#endif
+// flags: bit 0 = 4-wave 256x128 blocks (two per CU), bit 1 = 32x32x16 MFMA, bit 3 = 4-slot ring, bit 4 = refill DMAs in the first rows of a step
 static hipError_t launch_ringx(int flags, const GemmP& p, const GemmArgs& a, hipStream_t st, int splits = 1) {
     const int f = flags & 27;
-    if ((flags & 128) && f == 16 && splits == 1 && (((long long)a.M - 1) * a.ldy + a.N) * 2 < (1ll << 31)) return launch_ringx_t<4, false, 3, true, true>(p, a, st, 1);
     if ((flags & 32) && f == 1) return launch_ringx_t<2, false, 3, false>(p, a, st, splits, false);
     if ((flags & 32) && f == 17) return launch_ringx_t<2, false, 3, true>(p, a, st, splits, false);
     switch (f) {
@@ -1004,7 +1007,7 @@ static hipError_t launch_t(const GemmArgs& a, hipStream_t st, int* kind_out) {
     GemmP p;
     p.X = a.X; p.W = a.W; p.bias = a.bias; p.R = a.R; p.Y = a.Y; p.ws = a.splitk_ws; p.wscale = a.wscale;
     p.ldx = a.ldx; p.ldw = a.ldw; p.ldr = a.ldr; p.ldy = a.ldy;
-    p.M = a.M; p.N = a.N; p.K = a.K; p.epi = a.epi; p.out_f32 = a.out_f32; p.slabs = a.slabs_out ? 1 : 0;
+    p.M = a.M; p.N = a.N; p.K = a.K; p.epi = a.epi; p.out_f32 = a.out_f32; p.slabs = a.slabs_out ? 1 : 0; p.dump = nullptr;
     p.vec = (sizeof(T) == 2 && (a.ldx % 8) == 0 && (a.ldw % 8) == 0 && ((uintptr_t)a.X % 16) == 0 && ((uintptr_t)a.W % 16) == 0) ? 1 : 0;
     if (a.M <= 0 || a.N <= 0) return hipSuccess;
     int variant = a.variant;
@@ -1035,6 +1038,8 @@ static hipError_t launch_t(const GemmArgs& a, hipStream_t st, int* kind_out) {
                 return launch_ringx(16, p, a, st, sp);
             }
         }
+#ifdef MMDUET_DEBUG_VARIANTS          // timing experiments of tools/bench_gemm.py (most give WRONG results): `make DEBUG_VARIANTS=1`; never in the shipped library
+        if (variant == 93) { if (!big_packed_ok(MMD_BF16, a, 16) || (a.N % 32) != 0) return hipErrorInvalidValue; p.W = a.Wp; return launch_ringx_dbg<7>(p, a, st); }
         if (variant == 94) { if (!big_packed_ok(MMD_BF16, a, 16) || (a.N % 32) != 0) return hipErrorInvalidValue; p.W = a.Wp; return launch_ringx_dbg<6>(p, a, st); }
         if (variant == 95) { if (!big_packed_ok(MMD_BF16, a, 16) || (a.N % 32) != 0) return hipErrorInvalidValue; p.W = a.Wp; return launch_ringx_dbg<5>(p, a, st); }
         if (variant == 99) { if (!big_packed_ok(MMD_BF16, a, 16) || (a.N % 32) != 0) return hipErrorInvalidValue; p.W = a.Wp; return launch_ringx_dbg<4>(p, a, st); }
@@ -1043,6 +1048,7 @@ static hipError_t launch_t(const GemmArgs& a, hipStream_t st, int* kind_out) {
             p.W = a.Wp;
             return variant == 96 ? launch_ringx_dbg<1>(p, a, st) : (variant == 97 ? launch_ringx_dbg<2>(p, a, st) : launch_ringx_dbg<3>(p, a, st));
         }
+#endif
         if (variant >= GEMM_RINGX && variant < GEMM_RINGX + 256) {          // forced ring variants (A/B and parity of every instantiation)
             if (!big_packed_ok(MMD_BF16, a, 16) || (a.N % 32) != 0 || !ring_size_ok(a)) return hipErrorInvalidValue;
             const int flags = variant - GEMM_RINGX;

@@ -12,6 +12,7 @@ struct GemmP {
     long long ldx, ldw, ldr, ldy;
     int M, N, K, epi, out_f32, kper, vec;
     int slabs;         // skinny kernel: always leave fp32 slabs in ws (the consumer kernel reduces them)
+    void* dump;        // ring kernel: 8 KB nobody reads -- masked output lanes store here (a per-device buffer of the launcher, never the split-K workspace)
 };
 
 // guard-free epilogue of the big-tile kernel: N % BN == 0, ldy/ldr % 4 == 0 (dispatch conditions), one 8-byte access
@@ -145,12 +146,7 @@ __device__ __forceinline__ s16x8_t halves_to_row8(const s16x4_t& q0, const s16x4
 }
 
 // DBG != 0: timing experiments only (results are WRONG): 1 = X pieces fetched as contiguous 1 KB runs, 2 = no X DMA, 3 = no DMA at all
-// DEFER (8 waves, 16x16x32, 3 slots): the block owns all 160 KB of LDS -- 96 KB ring + 64 KB in which a finished tile's bf16 output waits.  Half of a
-// tile's 16 output stores per wave (SwiGLU: all 8) are written there at the tile seam and leave for HBM ONE PER K-STEP during the next tile's first eight
-// steps (same wave, same lanes: the LDS region is spill space, no cross-wave hand-over), so the per-CU store path (~14 B/clk: 4.7 us for a 128 KB tile,
-// during which the next tile's refill DMAs queue behind the stores) works beside the MFMAs instead of in front of them.  Stores are raw buffer stores
-// (out-of-range lanes are dropped by the bounds check: the store COUNT per wave never depends on the tile, which the counted waits need).
-template <int EPI, int WN, bool M32, int NS, bool EARLY, int DBG = 0, bool DEFER = false>
+template <int EPI, int WN, bool M32, int NS, bool EARLY, int DBG = 0>
 __global__ __launch_bounds__(WN * 128, 2) void gemm_ringx_kernel(GemmP p, int KT) {
     constexpr int BM = 256, BN = 64 * WN, BK = 32, NW = 2 * WN;
     constexpr int XE = BM * BK, WE = BN * BK, SE = XE + WE;    // elements per ring slot (32 KB / 24 KB)
@@ -257,33 +253,11 @@ __global__ __launch_bounds__(WN * 128, 2) void gemm_ringx_kernel(GemmP p, int KT
         const int aoff = (wr * 8) * 512 + lr * 32 + ((lq ^ rswz) * 8);
         const int boff = XE + (wc * 4) * 512 + lane * 8;
         bf16x8_t a[8], b0[4], b1[4];
-        // DEFER state: the tile whose staged pieces sit in this wave's 8 KB of the staging area (pieces q = 0..7, 1 KB each, lane-linear)
-        constexpr int ND = DEFER ? 8 : 0, NI = DEFER ? NST - 8 : NST;      // staged / immediate output stores per wave and tile
-        bf16_t* const stg = lds + NS * SE + wave * (8 * 512) + lane * 8;
-        int dvo = 0, drows = 0; bool dcol1 = false, staged = false;      // the staged tile: per-lane byte offset / rows left below M, is its column pair 1 inside N (uniform)
-        const int NOUT = EPI == EPI_SWIGLU ? p.N >> 1 : p.N;
-        const auto yrs = __builtin_amdgcn_make_buffer_rsrc(p.Y, 0, DEFER ? (int)((((long long)p.M - 1) * p.ldy + NOUT) * 2) : 0, 0x00020000);
-        // byte offset in Y of this lane's 16 bytes in row group 0 / column pair 0 of tile (em0, en0); 0x80000000 (fails the bounds check) where its columns lie outside N (N % 32 == 0)
-        auto lane_off = [&](int em0, int en0) {
-            const int nb = en0 + wc * 64;
-            const int col = (EPI == EPI_SWIGLU ? (nb >> 5) * 16 : nb) + (lq & 1) * 16 + (lq >> 1) * 8;
-            const bool ok = EPI == EPI_SWIGLU ? nb + 32 * (lq & 1) + 32 <= p.N : nb + 32 <= p.N;
-            return ok ? ((em0 + wr * 128 + lr) * (int)p.ldy + col) * 2 : (int)0x80000000;
-        };
-        // one output store: row group i (16 rows further per step), column pair jp (32 columns further); the per-piece part of the address is wave-uniform (soffset)
-        auto put = [&](int voff, int rows_left, bool col1, int i, int jp, const s16x8_t& v) {
-            const bool ok = rows_left > i * 16 && (jp == 0 || col1);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), yrs, ok ? voff : (int)0x80000000, (i * 16 * (int)p.ldy + jp * 32) * 2, 0);
-        };
-        auto drain_store = [&](int q, const s16x8_t& v) { if constexpr (EPI == EPI_SWIGLU) put(dvo, drows, true, q, 0, v); else put(dvo, drows, dcol1, 4 + (q >> 1), q & 1, v); };
-        auto step_q = [&](auto steady, int s, int slot, const bf16x8_t (&b)[4], bf16x8_t (&bn)[4], auto pending, auto drainq) {
+        auto step = [&](auto steady, int s, int slot, const bf16x8_t (&b)[4], bf16x8_t (&bn)[4], auto pending) {
             constexpr bool STEADY = decltype(steady)::value;
-            // PEND: number of output stores younger than the DMAs this step waits for (bool true = NST: the non-DEFER form, whose predecessor's NST stores may still be in flight)
-            constexpr int PEND = std::is_same<decltype(pending), std::true_type>::value ? NST : (int)decltype(pending)::value;
-            constexpr int DQ = decltype(drainq)::value;                 // staged piece this step sends to HBM (-1: none)
-            s16x8_t dv;
+            constexpr bool PEND = decltype(pending)::value;          // first two slices of a tile whose predecessor's NST stores may still be in flight (see the epilogue)
             if (DBG == 5 && s < 2) RINGX_WAIT((NS - 2) * NDMA + 16);          // timing experiment: leave the previous tile's 16 stores pending (WRONG on the first tile)
-            else if (PEND) RINGX_WAIT((NS - 2) * NDMA + PEND);
+            else if (PEND) RINGX_WAIT((NS - 2) * NDMA + NST);
             else if (STEADY || s + NS - 1 < nsteps) RINGX_WAIT((NS - 2) * NDMA);
             else if (NS == 4 && s + 2 < nsteps) RINGX_WAIT(NDMA);
             else RINGX_WAIT(0);
@@ -293,6 +267,30 @@ __global__ __launch_bounds__(WN * 128, 2) void gemm_ringx_kernel(GemmP p, int KT
             const bf16_t* nbase = lds + (slot == NS - 1 ? 0 : slot + 1) * SE;
             bf16x8_t a6n, a7n;
             __builtin_amdgcn_s_setprio(1);
+            if constexpr (DBG == 7) {
+                // experiment (correct results): every LDS read / DMA sits BETWEEN two MFMAs of a row instead of behind the row's four, so its issue hides in the
+                // matrix pipe's shadow of this wave's own previous MFMA.  Row i refills a[i-1] (dead since row i-1); a[7] travels in a7n from row 0.
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[0], a[i], acc[i][0], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more) { if (i == 0) a7n = *reinterpret_cast<const bf16x8_t*>(nbase + aoff + 7 * 512); else a[i - 1] = *reinterpret_cast<const bf16x8_t*>(nbase + aoff + (i - 1) * 512); }
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[1], a[i], acc[i][1], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more && i < 4) bn[i] = *reinterpret_cast<const bf16x8_t*>(nbase + boff + i * 512);
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[i][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[2], a[i], acc[i][2], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (refill && i < XP + WP) dma_k(slot, s + NS, i);
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[i][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[3], a[i], acc[i][3], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (more) a[7] = a7n;
+                __builtin_amdgcn_s_setprio(0);
+                return;
+            }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
 #pragma unroll
@@ -301,28 +299,17 @@ __global__ __launch_bounds__(WN * 128, 2) void gemm_ringx_kernel(GemmP p, int KT
                 if (more) {
                     if (i < 6) a[i] = *reinterpret_cast<const bf16x8_t*>(nbase + aoff + i * 512);
                     if (i < 4) bn[i] = *reinterpret_cast<const bf16x8_t*>(nbase + boff + i * 512);
-                    if constexpr (DQ < 0) {
-                        if (i == 0) a6n = *reinterpret_cast<const bf16x8_t*>(nbase + aoff + 6 * 512);
-                        if (i == 1) a7n = *reinterpret_cast<const bf16x8_t*>(nbase + aoff + 7 * 512);
-                    } else {          // a step that carries a staged piece has no spare registers for the two travelling rows: they are fetched in place, behind their own MFMAs
-                        if (i >= 6) a[i] = *reinterpret_cast<const bf16x8_t*>(nbase + aoff + i * 512);
-                    }
+                    if (i == 0) a6n = *reinterpret_cast<const bf16x8_t*>(nbase + aoff + 6 * 512);
+                    if (i == 1) a7n = *reinterpret_cast<const bf16x8_t*>(nbase + aoff + 7 * 512);
                 }
                 if (refill) {       // NDMA = 4: rows 4..7; NDMA = 6: rows 2..7
                     if (EARLY ? i < XP + WP : i >= 8 - (XP + WP)) dma_k(slot, s + NS, i - (EARLY ? 0 : 8 - (XP + WP)));
                 }
-#ifndef RP_NODRAIN
-                if constexpr (DQ >= 0) {          // the staged piece: out of LDS once row 6's MFMAs are issued (a[6] is dead from there on: its successor travels in a6n), to HBM behind row 7's
-                    if (i == 6) dv = *reinterpret_cast<const s16x8_t*>(stg + DQ * 512);
-                    if (i == 7) drain_store(DQ, dv);
-                }
-#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if constexpr (DQ < 0) { if (more) { a[6] = a6n; a[7] = a7n; } }
+            if (more) { a[6] = a6n; a[7] = a7n; }
             __builtin_amdgcn_s_setprio(0);
         };
-        auto step = [&](auto steady, int s, int slot, const bf16x8_t (&b)[4], bf16x8_t (&bn)[4], auto pending) { step_q(steady, s, slot, b, bn, pending, std::integral_constant<int, -1>{}); };
         auto prologue = [&]() { stage(0, 0); if (nsteps > 1) stage(1, 1); if (nsteps > 2) stage(2, 2); if (NS > 3 && nsteps > 3) stage(3, 3); };
         int tile = blockIdx.x;
         tile_origin(tile); tile_sources(); prologue();
@@ -330,9 +317,8 @@ __global__ __launch_bounds__(WN * 128, 2) void gemm_ringx_kernel(GemmP p, int KT
             // pend: this block's previous tile left exactly NST output stores in flight behind the DMAs of slices 0..2 issued before them.  vmcnt retires loads
             // and stores in issue order (hipcc itself waits vmcnt(2) for "load; store; store; use"), so slice 0 has landed once at most (its 2 NDMA younger DMAs +
             // NST stores) are outstanding -- the stores need not drain here, nor in front of slices 1 and 2 (step's PEND waits); slice 3's wait is behind them.
-            const bool pend = !DEFER && PST && tile != (int)blockIdx.x && nsteps >= NS + 3 && gridDim.z == 1;
+            const bool pend = PST && tile != (int)blockIdx.x && nsteps >= NS + 3 && gridDim.z == 1;
             if (DBG == 5) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(VM_TWO + 16) : "memory");
-            else if (DEFER && staged) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(VM_TWO + NI) : "memory");          // (staged implies nsteps >= 16 and gridDim.z == 1)
             else if (pend) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(VM_TWO + NST) : "memory");
             else if (NS > 3 && nsteps > 3) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(3 * NDMA) : "memory");
             else if (nsteps > 2) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(VM_TWO) : "memory");
@@ -344,25 +330,6 @@ __global__ __launch_bounds__(WN * 128, 2) void gemm_ringx_kernel(GemmP p, int KT
 #pragma unroll
             for (int j = 0; j < 4; ++j) b0[j] = *reinterpret_cast<const bf16x8_t*>(lds + boff + j * 512);
             int slot = 0, s = 0;
-            if constexpr (DEFER) {
-                if (staged) {
-                    // Issue order behind this point: [DMA 0..2 of this tile, NI seam stores] then per step s: DMA(s+3), drain store D(s) (s < 8).  Step s waits for
-                    // DMA(s+1) (issued in step s-2, or above): younger than it are DMA(s+2), the seam stores (s < 2) and D(s-2), D(s-1) where they exist.
-#define RX_IC(n) std::integral_constant<int, (n)>{}
-                    step_q(std::true_type{}, 0, 0, b0, b1, RX_IC(NI), RX_IC(0));
-                    step_q(std::true_type{}, 1, 1, b1, b0, RX_IC(NI + 1), RX_IC(1));
-                    step_q(std::true_type{}, 2, 2, b0, b1, RX_IC(2), RX_IC(2));
-                    step_q(std::true_type{}, 3, 0, b1, b0, RX_IC(2), RX_IC(3));
-                    step_q(std::true_type{}, 4, 1, b0, b1, RX_IC(2), RX_IC(4));
-                    step_q(std::true_type{}, 5, 2, b1, b0, RX_IC(2), RX_IC(5));
-                    step_q(std::true_type{}, 6, 0, b0, b1, RX_IC(2), RX_IC(6));
-                    step_q(std::true_type{}, 7, 1, b1, b0, RX_IC(2), RX_IC(7));
-                    step(std::true_type{}, 8, 2, b0, b1, RX_IC(2));
-                    step(std::true_type{}, 9, 0, b1, b0, RX_IC(1));
-#undef RX_IC
-                    slot = 1; s = 10; staged = false;
-                }
-            }
             if (pend) {       // (pend implies nsteps >= NS + 3: the first pair is a steady pair)
                 step(std::true_type{}, 0, 0, b0, b1, std::true_type{});
                 step(std::true_type{}, 1, 1, b1, b0, std::true_type{});
@@ -383,8 +350,7 @@ __global__ __launch_bounds__(WN * 128, 2) void gemm_ringx_kernel(GemmP p, int KT
                 }
             }
             const int em0 = m0, en0 = n0;
-            bf16_t* const dump = (bf16_t*)p.ws + tid * 8;          // masked lanes store here: the store COUNT per wave must not depend on the tile (16 bytes per thread, content irrelevant;
-                                                                   // the launcher guarantees p.ws, a process-wide 8 KB slot when the caller has no split-K workspace)
+            bf16_t* const dump = (bf16_t*)p.dump + tid * 8;        // masked lanes store here: the store COUNT per wave must not depend on the tile (16 bytes per thread, content irrelevant)
             if (tile + G < nblk) { tile_origin(tile + G); tile_sources(); prologue(); }
             __builtin_amdgcn_sched_barrier(0);          // the output stores below stay BEHIND the next tile's first DMAs (the counted waits rely on that order)
             if (gridDim.z > 1) {
@@ -402,10 +368,6 @@ __global__ __launch_bounds__(WN * 128, 2) void gemm_ringx_kernel(GemmP p, int KT
             // per-column operands of this wave's four 16-column tiles: ONE load per tile (they do not depend on the row); the residual quads of a row are
             // fetched while the previous row is converted and stored -- a load issued BEFORE a row's stores is older than them, so waiting for it does not
             // drain them (the compiler, left alone, loaded one residual quad at a time with a full vmcnt(0) after each)
-            // DEFER: this tile's second half waits in LDS if a next tile of this block exists to carry it out (else everything leaves now)
-            const bool defer_tile = DEFER && tile + G < nblk && nsteps >= 16;
-            const int evo = DEFER ? lane_off(em0, en0) : 0, erows = p.M - (em0 + wr * 128 + lr);
-            const bool ecol1 = en0 + wc * 64 + 64 <= p.N;
             f32x4_t scq[4]; s16x4_t biq[4], rq[4], rnext[4];
             int ncol[4];
             const bool has_sc = p.wscale != nullptr, has_bi = p.bias != nullptr;
@@ -450,8 +412,7 @@ __global__ __launch_bounds__(WN * 128, 2) void gemm_ringx_kernel(GemmP p, int KT
                     const int ns0 = min(nb, p.N - 32) + lq * 4, ns1 = min(nb + 32, p.N - 32) + lq * 4;      // N tail: clamp the scale reads
                     const s16x8_t v = pair_to_row8(big_value_swiglu(acc[i][0], acc[i][1], p.wscale, ns0), big_value_swiglu(acc[i][2], acc[i][3], p.wscale, ns1));
                     const bool ok = m < p.M && nb + 32 * (lq & 1) + 32 <= p.N;
-                    if constexpr (DEFER) { if (defer_tile) *reinterpret_cast<s16x8_t*>(stg + i * 512) = v; else put(evo, erows, true, i, 0, v); }
-                    else if constexpr (PST) *reinterpret_cast<s16x8_t*>(ok ? (bf16_t*)p.Y + (long long)m * p.ldy + ob + (lq & 1) * 16 + (lq >> 1) * 8 : dump) = v;
+                    if constexpr (PST) *reinterpret_cast<s16x8_t*>(ok ? (bf16_t*)p.Y + (long long)m * p.ldy + ob + (lq & 1) * 16 + (lq >> 1) * 8 : dump) = v;
                     else if (ok) *reinterpret_cast<s16x8_t*>((bf16_t*)p.Y + (long long)m * p.ldy + ob + (lq & 1) * 16 + (lq >> 1) * 8) = v;
                 } else {
 #pragma unroll
@@ -461,8 +422,7 @@ __global__ __launch_bounds__(WN * 128, 2) void gemm_ringx_kernel(GemmP p, int KT
                         if constexpr (DBG == 6) { const u32x4_t w = __builtin_bit_cast(u32x4_t, v); asm volatile("" :: "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3])); }      // timing only: converted, not stored
                         else {
                             const bool ok = m < p.M && nb + 16 * (lq & 1) + 16 <= p.N;
-                            if constexpr (DEFER) { if (defer_tile && i >= 4) *reinterpret_cast<s16x8_t*>(stg + ((i - 4) * 2 + (j >> 1)) * 512) = v; else put(evo, erows, ecol1, i, j >> 1, v); }
-                            else if constexpr (PST) *reinterpret_cast<s16x8_t*>(ok ? (bf16_t*)p.Y + (long long)m * p.ldy + nb + (lq & 1) * 16 + (lq >> 1) * 8 : dump) = v;
+                            if constexpr (PST) *reinterpret_cast<s16x8_t*>(ok ? (bf16_t*)p.Y + (long long)m * p.ldy + nb + (lq & 1) * 16 + (lq >> 1) * 8 : dump) = v;
                             else if (ok) *reinterpret_cast<s16x8_t*>((bf16_t*)p.Y + (long long)m * p.ldy + nb + (lq & 1) * 16 + (lq >> 1) * 8) = v;
                         }
                     }
@@ -472,7 +432,6 @@ __global__ __launch_bounds__(WN * 128, 2) void gemm_ringx_kernel(GemmP p, int KT
             for (int i = 0; i < 8; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0, 0, 0, 0};
-            if constexpr (DEFER) { if (defer_tile) { staged = true; dvo = evo; drows = erows; dcol1 = ecol1; } }
         }
     } else {
         // ---------------- 32x32x16: 4 (m) x 2 (n) accumulator tiles of 32 x 32 ----------------

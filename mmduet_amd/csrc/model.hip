@@ -848,16 +848,27 @@ static int vmm_map_upto(mmd_ctx* c, mmd_stream* s, int64_t upto) {
     while (s->mapped < upto) {
         if (s->mapped + s->chunk_tokens > s->cap) FAIL(c, MMD_ENOMEM, "KV arena: %lld tokens exceed the reserved virtual capacity %lld (MMDUET_KV_VIRTUAL_TOKENS)", (long long)upto, (long long)s->cap);
         const size_t cb = (size_t)s->chunk_tokens * tok_bytes, off = (size_t)s->mapped * tok_bytes;
+        const size_t done0 = s->handles.size();
+        // a chunk is all-or-nothing: `mapped` advances only when every row has its pages, so on a failure (out of HBM near the limit this arena is built
+        // for) the rows already mapped for THIS chunk are unmapped again -- a later kv_reserve then retries on clean addresses instead of failing for good
+        auto undo = [&]() {
+            while (s->handles.size() > done0) {
+                hipMemUnmap(s->maps.back().first, s->maps.back().second); hipMemRelease(s->handles.back());
+                s->maps.pop_back(); s->handles.pop_back();
+            }
+            (void)hipGetLastError();
+        };
         for (int kv = 0; kv < 2; ++kv)
             for (size_t r = 0; r < rows; ++r) {
                 char* at = (char*)(kv ? s->V : s->K) + r * row_stride + off;
                 hipMemGenericAllocationHandle_t h;
                 hipError_t er = hipMemCreate(&h, cb, &prop, 0);
-                if (er != hipSuccess) { (void)hipGetLastError(); FAIL(c, MMD_ENOMEM, "KV arena: no physical memory for tokens %lld.. (%s)", (long long)s->mapped, hipGetErrorString(er)); }
+                if (er != hipSuccess) { undo(); FAIL(c, MMD_ENOMEM, "KV arena: no physical memory for tokens %lld.. (%s)", (long long)s->mapped, hipGetErrorString(er)); }
                 er = hipMemMap(at, cb, 0, h, 0);
-                if (er == hipSuccess) er = hipMemSetAccess(at, cb, &acc, 1);
-                if (er != hipSuccess) { hipMemRelease(h); FAIL(c, MMD_EHIP, "KV arena: hipMemMap failed: %s", hipGetErrorString(er)); }
+                if (er != hipSuccess) { hipMemRelease(h); undo(); FAIL(c, MMD_EHIP, "KV arena: hipMemMap failed: %s", hipGetErrorString(er)); }
                 s->handles.push_back(h); s->maps.push_back({at, cb});
+                er = hipMemSetAccess(at, cb, &acc, 1);
+                if (er != hipSuccess) { undo(); FAIL(c, MMD_EHIP, "KV arena: hipMemSetAccess failed: %s", hipGetErrorString(er)); }
                 // key tiles may cover slots beyond the live length (their P is masked to 0): keep those slots finite
                 HIPCHK(c, hipMemsetAsync(at, 0, cb, c->stream));
             }
@@ -896,7 +907,8 @@ extern "C" int mmd_stream_create(mmd_ctx* c, int64_t initial_tokens, mmd_stream*
             int64_t vcap = ev ? atoll(ev) : ((int64_t)4 << 20);
             if (vcap < initial_tokens) vcap = initial_tokens;
             vcap = round_up(vcap, ct);
-            for (; vcap >= round_up(initial_tokens, ct); vcap = vcap > round_up(initial_tokens, ct) ? std::max(vcap / 2, round_up(initial_tokens, ct)) : 0) {
+            // (a halved reservation is rounded to whole chunks again: the row stride must stay a multiple of the allocation granularity)
+            for (; vcap >= round_up(initial_tokens, ct); vcap = vcap > round_up(initial_tokens, ct) ? std::max((int64_t)round_up(vcap / 2, ct), (int64_t)round_up(initial_tokens, ct)) : 0) {
                 const size_t va = rows * (size_t)vcap * tok_bytes;
                 void *K = nullptr, *V = nullptr;
                 if (hipMemAddressReserve(&K, va, gran, nullptr, 0) == hipSuccess && hipMemAddressReserve(&V, va, gran, nullptr, 0) == hipSuccess) {
@@ -941,6 +953,7 @@ extern "C" int mmd_kv_truncate(mmd_stream* s, int64_t n) {
     if (!s) return MMD_EINVAL;
     if (n < 0 || n > s->len) FAIL(s->ctx, MMD_ERANGE, "kv_truncate(%lld) outside [0, %lld]", (long long)n, (long long)s->len);
     s->len = n;
+    if (n < s->stash_from) s->stash_from = s->stash_to = -1;          // the context a stash continued no longer exists
     return MMD_OK;
 }
 
@@ -971,7 +984,10 @@ extern "C" int mmd_kv_stash(mmd_stream* s, int64_t from, int64_t to) {
 extern "C" int mmd_kv_unstash(mmd_stream* s) {
     if (!s) return MMD_EINVAL;
     mmd_ctx* c = s->ctx;
-    if (s->stash_from < 0) FAIL(c, MMD_EINVAL, "kv_unstash without a stash");
+    if (s->stash_from < 0) FAIL(c, MMD_EINVAL, "kv_unstash without a (still valid) stash");
+    // the stash continues the context [0, from): the arena must stand exactly there (tokens >= from are overwritten, tokens of the V blocks just below `from`
+    // come back with their stash-time values, so nothing below `from` may have changed either -- a truncate below `from` or a reset drops the stash)
+    if (s->len != s->stash_from) FAIL(c, MMD_EINVAL, "kv_unstash: the arena holds %lld tokens, the stash continues a context of %lld (truncate to it first)", (long long)s->len, (long long)s->stash_from);
     hipSetDevice(c->device);
     const int64_t from = s->stash_from, to = s->stash_to;
     int rc = kv_reserve(c, s, to); if (rc) return rc;
@@ -984,7 +1000,7 @@ extern "C" int mmd_kv_unstash(mmd_stream* s) {
     return MMD_OK;
 }
 
-extern "C" int mmd_stream_reset(mmd_stream* s) { if (!s) return MMD_EINVAL; s->len = 0; return MMD_OK; }
+extern "C" int mmd_stream_reset(mmd_stream* s) { if (!s) return MMD_EINVAL; s->len = 0; s->stash_from = s->stash_to = -1; return MMD_OK; }
 
 static int kv_reserve(mmd_ctx* c, mmd_stream* s, int64_t need);
 // measurement aid (tools/kv_growth_sweep.py): declare the first n slots of the arena live without computing them, to time a

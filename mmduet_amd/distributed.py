@@ -108,15 +108,25 @@ class NativeScoreGather:
         self.rank = dist.get_rank() if rank is None and dist.is_initialized() else (rank or 0)
         self.world = dist.get_world_size() if world is None and dist.is_initialized() else (world or 1)
         self.device = torch.device(device)
+        self._h = None
+        # Construction is collective (broadcast + ncclCommInitRank): first agree that EVERY rank can bind librccl and that rank 0 drew an id -- a rank that
+        # cannot must make all of them raise here, not leave the others waiting inside ncclCommInitRank.
+        ok = 1 if self._lib.mmd_comm_probe() == 0 else 0
         ident = torch.zeros(128, dtype=torch.uint8)
-        if self.rank == 0:
-            rc = self._lib.mmd_comm_unique_id(C.c_void_p(ident.data_ptr()))
-            if rc:
-                raise MmduetError(f'mmd_comm_unique_id failed ({rc}): {self._lib.mmd_comm_last_error(None).decode()}')
+        if ok and self.rank == 0 and self._lib.mmd_comm_unique_id(C.c_void_p(ident.data_ptr())) != 0:
+            ok = 0
+        why = '' if ok else self._lib.mmd_comm_last_error(None).decode()
         if self.world > 1:
-            on = ident.to(self.device) if dist.get_backend() == 'nccl' else ident
+            nccl = dist.get_backend() == 'nccl'
+            flag = torch.tensor([ok], dtype=torch.int32, device=self.device if nccl else 'cpu')
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                raise MmduetError(f'NativeScoreGather: RCCL is not usable on every rank (rank {self.rank}: {why or "ok here"})')
+            on = ident.to(self.device) if nccl else ident
             dist.broadcast(on, src=0)
             ident = on.cpu()
+        elif not ok:
+            raise MmduetError(f'NativeScoreGather: {why}')
         self._id = ident
         h = C.c_void_p()
         st = stream if stream is not None else torch.cuda.current_stream(self.device).cuda_stream
@@ -125,14 +135,39 @@ class NativeScoreGather:
             raise MmduetError(f'mmd_comm_create failed ({rc}): {self._lib.mmd_comm_last_error(None).decode()}')
         self._h = h
 
+    def _on_current_stream(self):
+        """Every gather is issued on torch's CURRENT stream: its input was produced there and its output is consumed there, so stream order is the only
+        ordering needed (a communicator bound to the stream of its construction would race with work on any other stream)."""
+        self._lib.mmd_comm_set_stream(self._h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+
     def gather(self, scores, t_max):
         """scores [T,2] fp32 on the device -> (all [world, t_max, 2] fp32 NaN-padded, lengths [world] int32), device tensors."""
         s = scores.to(device=self.device, dtype=torch.float32).contiguous()
         out = torch.empty(self.world, t_max + 1, 2, dtype=torch.float32, device=self.device)
+        self._on_current_stream()
         rc = self._lib.mmd_gather_scores(self._h, C.c_void_p(s.data_ptr()), int(s.shape[0]), int(t_max), C.c_void_p(out.data_ptr()))
         if rc:
             raise self._err(f'mmd_gather_scores failed ({rc}): {self._lib.mmd_comm_last_error(self._h).decode()}')
         return out[:, 1:], out[:, 0, 0].to(torch.int32)
+
+    def gather_streams(self, local_scores, t_max, n_max):
+        """Several streams per rank, same result layout as `gather_scores`: list of [T_i,2] -> (scores [world, n_max, t_max, 2] NaN-padded, lengths [world, n_max] int32).
+        The padded block [n_max, t_max + 1, 2] (row 0 of a stream = its length) is assembled once on the host -- the scores are host values, the driver decided on
+        them frame by frame -- and crosses to the device in ONE copy; ONE ncclAllGather issued by the library."""
+        if len(local_scores) > n_max or any(int(s.shape[0]) > t_max for s in local_scores):
+            raise ValueError('local block exceeds the agreed [n_max, t_max]')
+        buf = torch.full((n_max, t_max + 1, 2), float('nan'), dtype=torch.float32)
+        buf[:, 0] = 0.0
+        for i, s in enumerate(local_scores):
+            buf[i, 0, 0] = float(s.shape[0])
+            buf[i, 1:1 + s.shape[0]] = s.detach().to(device='cpu', dtype=torch.float32)
+        blk = buf.to(self.device, non_blocking=True)
+        out = torch.empty(self.world, n_max, t_max + 1, 2, dtype=torch.float32, device=self.device)
+        self._on_current_stream()
+        rc = self._lib.mmd_gather_block(self._h, C.c_void_p(blk.data_ptr()), blk.numel(), C.c_void_p(out.data_ptr()))
+        if rc:
+            raise self._err(f'mmd_gather_block failed ({rc}): {self._lib.mmd_comm_last_error(self._h).decode()}')
+        return out[:, :, 1:], out[:, :, 0, 0].to(torch.int32)
 
     def close(self):
         if getattr(self, '_h', None):

@@ -276,3 +276,39 @@ def test_fused_preprocess_patch_embed_is_bit_identical(dtype, tag):
     assert one.shape == two.shape and torch.equal(one, two)
     big = torch.cat([fr] * 5)[:11]                       # more frames than one tower batch (max_vit_batch = 8 in the test model)
     assert torch.equal(m.visual_embed_frames(big), m.visual_embed(m.get_vision_tower().image_processor.preprocess(big)['pixel_values']))
+
+
+def test_kv_stash_is_dropped_when_its_context_goes_away():
+    """mmd_kv_stash / mmd_kv_unstash: a stash continues the context [0, from).  Unstash restores the tokens bit for bit when the arena stands at
+    `from`; a truncate below `from` or a stream reset invalidates the stash (unstash then fails instead of resurrecting stale KV)."""
+    import ctypes as C
+    from mmduet_amd._lib import lib, MmduetError
+    m, _, _ = hip_model('A', torch.float32)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 24, m.config.hidden_size, generator=g).cuda()
+    probe = torch.randn(1, 3, m.config.hidden_size, generator=g).cuda()
+    full = m(inputs_embeds=x)
+    want = m(inputs_embeds=probe, past_key_values=full.past_key_values).logits.clone()
+    base = m.cache_prefix(full.past_key_values, 24)
+    stash = m.kv_stash(base, 10)                                  # tokens [10, 24) set aside
+    other = m(inputs_embeds=probe * 2, past_key_values=m.cache_prefix(base, 10))      # something else uses slots 10..12
+    assert len(other.past_key_values) == 13
+    back = m.kv_unstash(stash)                                    # wrapper truncates to 10, the library restores [10, 24)
+    assert len(back) == 24
+    assert torch.equal(m(inputs_embeds=probe, past_key_values=back).logits, want)
+    arena = back.arena
+    # a stash whose context is truncated away is dropped
+    stash = m.kv_stash(m.cache_prefix(back, 24), 10)
+    arena.truncate(6)
+    with pytest.raises(MmduetError, match='stash'):
+        m.kv_unstash(stash)
+    # ... and so is one across a stream reset
+    h = m(inputs_embeds=x).past_key_values
+    st2 = m.kv_stash(h, 8)
+    assert lib().mmd_stream_reset(h.arena.h) == 0
+    with pytest.raises(MmduetError, match='stash'):
+        m.kv_unstash(st2)
+    # the arena must stand exactly at `from`: the raw entry point refuses otherwise
+    h = m(inputs_embeds=x).past_key_values
+    assert lib().mmd_kv_stash(h.arena.h, 12, 24) == 0
+    assert lib().mmd_kv_unstash(h.arena.h) != 0                   # len is 24, the stash continues 12

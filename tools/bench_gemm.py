@@ -48,7 +48,7 @@ if __name__ == '__main__':
     which = sys.argv[1] if len(sys.argv) > 1 else 'prod'
     if which == 'prod':
         rows = []
-        variants = [(0, 'auto'), (4, 'big'), (6, 'ring256'), (16, 'rx-8w'), (17, 'rx-4w'), (24, 'rx-8w-ns4'), (32, 'rx-8w-early'), (33, 'rx-4w-early'), (40, 'rx-8w-ns4-early'), (42, 'rx-8w-m32-ns4-early'), (160, 'rx-8w-early-defer'),
+        variants = [(0, 'auto'), (4, 'big'), (6, 'ring256'), (16, 'rx-8w'), (17, 'rx-4w'), (24, 'rx-8w-ns4'), (32, 'rx-8w-early'), (33, 'rx-4w-early'), (40, 'rx-8w-ns4-early'), (42, 'rx-8w-m32-ns4-early'), (93, 'rx-fine'),
                     (7, 'ring256-splitK'), (44, 'rx-8w-ns4-early-splitK'), (49, 'rx-4w-nostagger'), (65, 'rx-4w-early-nostagger'), (96, 'DBG-x-contig'), (97, 'DBG-no-x'), (98, 'DBG-no-dma'), (99, 'DBG-no-epilogue'), (95, 'DBG-stores-pending'), (94, 'DBG-convert-no-store')]
         if len(sys.argv) > 3: variants = [v for v in variants if v[1] in sys.argv[3].split(',')]
         for M, shapes in ((25515, VIT), (1274, LLM[:4]), (1323, LLM[:4])):
@@ -69,6 +69,29 @@ if __name__ == '__main__':
         if len(sys.argv) > 2:
             json.dump(dict(note='tools/bench_gemm.py prod: mmd_op_gemm_bench, random bf16 operands (X ~ 0.5 N(0,1), W ~ 0.02 N(0,1)), 10 iterations after 3 warm-ups, '
                                 'HIP events on the launch stream; frac = TF/s / 2500 (dense bf16 MFMA peak)', rows=rows), open(sys.argv[2], 'w'), indent=1)
+    if which == 'ab':
+        # interleaved A/B (guide rule 24): python tools/bench_gemm.py ab <variant,variant,...> [rounds] [out.json]; every round runs every variant on the same operands
+        import statistics
+        names = {0: 'auto', 4: 'big', 32: 'rx-8w-early', 33: 'rx-4w-early', 93: 'rx-fine', 99: 'DBG-no-epilogue', 98: 'DBG-no-dma', 7: 'ring-splitK', 48: 'rx-8w-early-splitK'}
+        vs = [int(v) for v in sys.argv[2].split(',')]
+        rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 7
+        shapes = [(25515, 'vit_qkv', 3456, 1152, 'none'), (25515, 'vit_o_none', 1152, 1152, 'none'), (25515, 'proj2', 3584, 3584, 'none'), (1274, 'gate_up_none', 37888, 3584, 'none'),
+                  (1274, 'qkv', 4608, 3584, 'none'), (4096, 'sq4096', 4096, 4096, 'none'), (8192, 'sq8192', 8192, 8192, 'none')]
+        if os.environ.get('AB_SHAPES'): shapes = [sh for sh in shapes if sh[1] in os.environ['AB_SHAPES'].split(',')]
+        rows = []
+        for M, name, N, K, epi in shapes:
+            t = {v: [] for v in vs}
+            for r in range(rounds):
+                for v in vs:
+                    try: t[v].append(run(ops, M, N, K, epi, v, iters=5))
+                    except Exception as e: t[v].append(float('nan'))
+            for v in vs:
+                med, mn = statistics.median(t[v]), min(t[v])
+                tf = 2 * M * N * K / med / 1e9
+                rows.append(dict(M=M, name=name, N=N, K=K, variant=names.get(v, str(v)), median_us=round(med * 1e3, 1), min_us=round(mn * 1e3, 1), tflops_median=round(tf, 1), frac=round(tf / 2500, 3)))
+                print(f'M={M:6d} {name:13s} N={N:6d} K={K:6d} {names.get(v, str(v)):18s} median {med*1e3:8.1f} us  min {mn*1e3:8.1f} us  {tf:7.1f} TF  {tf/2500:5.3f}', flush=True)
+        if len(sys.argv) > 4:
+            json.dump(dict(note=f'tools/bench_gemm.py ab: {rounds} interleaved rounds x 5 iterations per variant, random bf16 operands, same operands for every variant of a shape', rows=rows), open(sys.argv[4], 'w'), indent=1)
     if which in ('llm', 'all'):
         rows = []
         for M in (1, 16, 49, 64):

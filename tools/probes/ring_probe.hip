@@ -4,7 +4,10 @@
 #ifndef PROBE_EPI
 #define PROBE_EPI 0
 #endif
-#ifndef PROBE_DEFER
-#define PROBE_DEFER true
+#ifndef PROBE_DBG
+#define PROBE_DBG 0
 #endif
-template __global__ void gemm_ringx_kernel<PROBE_EPI, 4, false, 3, true, 0, PROBE_DEFER>(GemmP, int);
+#ifndef PROBE_DEFER
+#define PROBE_DEFER false
+#endif
+template __global__ void gemm_ringx_kernel<PROBE_EPI, 4, false, 3, true, PROBE_DBG>(GemmP, int);
