@@ -1287,7 +1287,18 @@ extern "C" int mmd_greedy_generate(mmd_ctx* c, mmd_stream* s, const void* prompt
     const mmd_config& g = c->cfg; hipStream_t st = c->stream; const int H = g.hidden_size; const size_t e = es(c);
     const bool pen = rep_penalty > 0.f;
     int np = (pen && n_prev) ? *n_prev : 0;
-    if (np > c->prev_cap) FAIL(c, MMD_ERANGE, "repetition-penalty list too long");
+    // The reference penalises EVERY id generated so far in the video (models/modeling_live.py:60-66; the list persists across turns): the device copy grows
+    // with it (doubling; a captured decode graph holds the old pointer and is dropped).  No cap.
+    if (pen && np + max_new > c->prev_cap) {
+        int ncap = c->prev_cap > 0 ? c->prev_cap : 16384;
+        while (ncap < np + max_new) ncap *= 2;
+        HIPCHK(c, hipStreamSynchronize(st));
+        if (c->dec_graph) { hipGraphExecDestroy(c->dec_graph); c->dec_graph = nullptr; }
+        if (c->dec_graph_src) { hipGraphDestroy(c->dec_graph_src); c->dec_graph_src = nullptr; }
+        dev_free(c, c->prev_dev); c->prev_dev = nullptr; c->prev_cap = 0;
+        int rc0 = dev_alloc(c, (void**)&c->prev_dev, (size_t)ncap * sizeof(int64_t)); if (rc0) return rc0;
+        c->prev_cap = ncap;
+    }
     if (np > 0) HIPCHK(c, hipMemcpyAsync(c->prev_dev, prev_ids_host, sizeof(int64_t) * np, hipMemcpyHostToDevice, st));
     int produced = 0;
     auto read_token = [&](int64_t* tok) -> int {

@@ -3,8 +3,9 @@
 Mirrors `LiveInferForDemo` (demo/liveinfer.py:60-105): `encode_given_query` (called from the Gradio handler thread,
 demo/app.py:84-85) and `input_one_frame` (called from the generator thread).  The reference shares
 `past_key_values` between those two threads without a lock; here both go through one re-entrant lock.
-`load_video` (demo/liveinfer.py:8-57, OpenCV decode + letterbox) is a host-side input producer and is not part of
-this package (cv2 is not available offline); feed uint8 [T,3,R,R] frames to `input_video_stream`.
+`load_video` (demo/liveinfer.py:8-57: OpenCV decode, time-based frame picking, letterbox to 384) lives in `mmduet_amd.video_input.load_video_frames`
+(sampling plan and letterbox geometry as the reference computes them, the resize / pad on the GPU) on top of `mmduet_amd.video_decode` (Motion-JPEG /
+uncompressed AVI; the image has no codec library); `input_video_stream` takes the resulting uint8 [T,3,R,R] frames.
 """
 import threading
 from .inference import LiveInferForBenchmark

@@ -147,6 +147,31 @@ def test_native_generate_equals_python_loop(f32, penalty):
     assert ids_a.cpu().tolist() == ids_c.tolist() and la == lc
 
 
+def test_penalty_list_is_unbounded(f32):
+    """models/modeling_live.py:60-66 penalises ALL ids generated so far in the video: a list beyond the device buffer's first 16 384 slots grows the buffer
+    (no clamp); native loop == Python loop == oracle."""
+    from mmduet_amd.modeling_live import fast_greedy_generate
+    tag, m, cfgd, w, ops = f32
+    x = ops['step0_in'][None].cuda()
+    V = cfgd['vocab_size']
+    base = [(7 * i + 3) % (V // 2) for i in range(20000)]            # 20 000 entries, half the vocabulary penalised
+    outs = []
+    for loop in (False, True):
+        out = torch.zeros(1, 6, dtype=torch.long, device='cuda'); seen = list(base)
+        m.python_generate_loop = loop
+        try:
+            ids, _, l = fast_greedy_generate(model=m, inputs_embeds=x, past_key_values=None, eos_token_id=-1, inplace_output_ids=out, repetition_penalty=1.3, generated_token_ids=seen)
+        finally:
+            m.python_generate_loop = False
+        assert len(l) == 20006
+        outs.append((ids.tolist(), l[-6:]))
+    assert outs[0] == outs[1]
+    om, _, _ = oracle_model(tag)
+    ids_c, _, lc = O.fast_greedy_generate(model=om, inputs_embeds=ops['step0_in'][None], past_key_values=None, eos_token_id=-1,
+                                          inplace_output_ids=torch.zeros(1, 6, dtype=torch.long), repetition_penalty=1.3, generated_token_ids=list(base))
+    assert outs[0][0] == ids_c.tolist()
+
+
 def test_eos_stops_generation_and_is_not_penalised(f32):
     from mmduet_amd.modeling_live import fast_greedy_generate
     tag, m, cfgd, w, ops = f32
