@@ -24,7 +24,7 @@ class MmdConfig(C.Structure):
                 ('vit_image', C.c_int32), ('vit_patch', C.c_int32), ('vit_ln_eps', C.c_float), ('vit_post_layernorm', C.c_int32),
                 ('pool_mode', C.c_int32), ('pool_stride', C.c_int32), ('frame_num_tokens', C.c_int32),
                 ('max_vit_batch', C.c_int32), ('max_step_tokens', C.c_int32), ('weight_dtype', C.c_int32),
-                ('vision_only', C.c_int32), ('vit_class_token', C.c_int32), ('vit_pre_layernorm', C.c_int32), ('vit_act', C.c_int32), ('vit_pool_head', C.c_int32)]
+                ('vision_only', C.c_int32), ('vit_class_token', C.c_int32), ('vit_pre_layernorm', C.c_int32), ('vit_act', C.c_int32), ('vit_pool_head', C.c_int32), ('tower_f16', C.c_int32)]
 
 
 class MmduetError(RuntimeError):

@@ -74,6 +74,7 @@ class LiveTestArguments(LiveTrainingArguments):
     evaluator_format: bool = False       # write debug_data in the shape test/evaluate.py reads (results.result_record)
     features_dir: Optional[str] = None   # entries of --test_fname that carry "features": "<file>" read a pre-extracted feature file from here (mmduet_amd/features.py)
     weight_dtype: Optional[str] = None   # 'fp8_e4m3': decoder linear layers stored as per-channel-scaled OCP e4m3 (bf16 activations, fp32 accumulate)
+    tower_dtype: Optional[str] = None    # 'fp16': the vision tower computes in IEEE half as under the reference's torch.cuda.amp.autocast() (models/modeling_live.py:28); None = model dtype
 
 
 def get_args_class(args_version: str):

@@ -674,7 +674,7 @@ static hipError_t launch_gqa128(AttnP& p, const AttnArgs& a, hipStream_t st) {
 // operand already has -- so no transposed copy of V is ever made.  128 query rows per block (4 waves x 2 row tiles),
 // 64-key tiles, next tile prefetched into registers during the MFMAs.
 // ------------------------------------------------------------------------------------------------------------------
-template <int NC, int DVT>      // NC = ceil(d/32) QK k-steps, DVT = max 16-wide output tiles
+template <int NC, int DVT, bool F16 = false>      // NC = ceil(d/32) QK k-steps, DVT = max 16-wide output tiles; F16: q / k / v / P / output are IEEE half (the fp16 tower)
 __global__ __launch_bounds__(256, 2) void attn_rowmajor_kernel(AttnP p) {
     constexpr int RT = 2, KT = 64, DQ = NC * 32, KLD = DQ + 8;
     constexpr int NCH = DQ / 8;                                 // 16-byte chunks per key row (incl. zero padding)
@@ -772,7 +772,7 @@ __global__ __launch_bounds__(256, 2) void attn_rowmajor_kernel(AttnP p) {
                 for (int c = 0; c < NC; ++c) {
                     bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + (h * 32 + t * 16 + lr) * KLD + c * 32 + lq * 8);
 #pragma unroll
-                    for (int rt = 0; rt < RT; ++rt) st[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[rt][c], st[rt][t], 0, 0, 0);
+                    for (int rt = 0; rt < RT; ++rt) st[rt][t] = mfma16<F16>(kf, qf[rt][c], st[rt][t]);
                 }
             bf16x8_t pf[RT];
 #pragma unroll
@@ -807,7 +807,7 @@ __global__ __launch_bounds__(256, 2) void attn_rowmajor_kernel(AttnP p) {
                 float psum = 0.f;
                 s16x8_t pk;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) { float pv = __builtin_amdgcn_exp2f(fmaf(sv[i], p.scale_log2, neg_m)); psum += pv; pk[i] = (short)f2bf(pv); }
+                for (int i = 0; i < 8; ++i) { float pv = __builtin_amdgcn_exp2f(fmaf(sv[i], p.scale_log2, neg_m)); psum += pv; pk[i] = (short)f2raw<F16>(pv); }
                 l_run[rt] += psum;
                 pf[rt] = __builtin_bit_cast(bf16x8_t, pk);
             }
@@ -821,7 +821,7 @@ __global__ __launch_bounds__(256, 2) void attn_rowmajor_kernel(AttnP p) {
                     s16x8_t vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                     bf16x8_t vfb = __builtin_bit_cast(bf16x8_t, vf);
 #pragma unroll
-                    for (int rt = 0; rt < RT; ++rt) oacc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfb, pf[rt], oacc[rt][t], 0, 0, 0);
+                    for (int rt = 0; rt < RT; ++rt) oacc[rt][t] = mfma16<F16>(vfb, pf[rt], oacc[rt][t]);
                 }
             }
         }
@@ -839,19 +839,20 @@ __global__ __launch_bounds__(256, 2) void attn_rowmajor_kernel(AttnP p) {
         for (int t = 0; t < DVT; ++t) {
             const int e = t * 16 + lq * 4;
             if (t < dvt && e + 4 <= d) {
-                s16x4_t o = {(short)f2bf(oacc[rt][t][0] * inv), (short)f2bf(oacc[rt][t][1] * inv), (short)f2bf(oacc[rt][t][2] * inv), (short)f2bf(oacc[rt][t][3] * inv)};
+                s16x4_t o = {(short)f2raw<F16>(oacc[rt][t][0] * inv), (short)f2raw<F16>(oacc[rt][t][1] * inv), (short)f2raw<F16>(oacc[rt][t][2] * inv), (short)f2raw<F16>(oacc[rt][t][3] * inv)};
                 *reinterpret_cast<s16x4_t*>(orow + e) = o;
             } else if (t < dvt) {
-                for (int r = 0; r < 4; ++r) if (e + r < d) orow[e + r] = f2bf(oacc[rt][t][r] * inv);
+                for (int r = 0; r < 4; ++r) if (e + r < d) orow[e + r] = f2raw<F16>(oacc[rt][t][r] * inv);
             }
         }
     }
 }
 
 template <int NC, int DVT>
-static hipError_t launch_rowmajor(AttnP& p, const AttnArgs& a, hipStream_t st) {
+static hipError_t launch_rowmajor(AttnP& p, const AttnArgs& a, hipStream_t st, bool f16 = false) {
     p.splits = 1; p.kv_per_split = 0;
-    hipLaunchKernelGGL((attn_rowmajor_kernel<NC, DVT>), dim3(cdiv(a.S, 128), a.nh, a.batch), dim3(256), 0, st, p);
+    if (f16) hipLaunchKernelGGL((attn_rowmajor_kernel<NC, DVT, true>), dim3(cdiv(a.S, 128), a.nh, a.batch), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((attn_rowmajor_kernel<NC, DVT>), dim3(cdiv(a.S, 128), a.nh, a.batch), dim3(256), 0, st, p);
     return hipGetLastError();
 }
 
@@ -894,7 +895,8 @@ hipError_t launch_attention(int dtype, const AttnArgs& a, hipStream_t st) {
     p.splits = 1; p.kv_per_split = 0; p.v_tr = a.v_transposed; p.dyn = a.dyn; p.layer = a.layer;
     p.scale_log2 = (1.0f / sqrtf((float)a.d)) * 1.4426950408889634f;
     p.slabs = a.qkv_slabs; p.n_slabs = a.n_slabs; p.qkv_bias = a.qkv_bias; p.rope_tab = (const float2*)a.rope_tab;
-    bool can_mfma = dtype == MMD_BF16 && (a.d % 8) == 0 && a.d <= 128 && (a.ldq % 8) == 0 && (a.k_ts % 8) == 0 && (a.v_ts % 8) == 0 &&
+    const bool f16 = dtype == MMD_F16;          // the fp16 vision tower: the row-major kernel only
+    bool can_mfma = (dtype == MMD_BF16 || f16) && (a.d % 8) == 0 && a.d <= 128 && (a.ldq % 8) == 0 && (a.k_ts % 8) == 0 && (a.v_ts % 8) == 0 &&
                     (a.k_hs % 8) == 0 && (a.v_hs % 8) == 0 && (a.kv_bstride % 8) == 0 && (a.q_bstride % 8) == 0;
     int variant = a.variant;
     const bool can_gqa128 = can_mfma && a.d == 128 && a.v_transposed && a.batch == 1 && a.k_ts == 128;
@@ -902,12 +904,13 @@ hipError_t launch_attention(int dtype, const AttnArgs& a, hipStream_t st) {
     const bool can_rowmajor = can_mfma && !a.v_transposed && a.n_ctx + a.S < (1 << 30) && (a.o_bstride % 4) == 0 && (a.ldo % 4) == 0;
     if (variant == 0) variant = can_gqa128 ? 3 : (can_rowmajor && a.S >= 64 ? 4 : (can_mfma ? 2 : 1));
     if (a.qkv_slabs && variant != 3) return hipErrorInvalidValue;
+    if (f16 && variant != 4) return hipErrorInvalidValue;
     if (variant == 4) {
         if (!can_rowmajor) return hipErrorInvalidValue;
-        if (a.d <= 32) return launch_rowmajor<1, 2>(p, a, st);
-        if (a.d <= 64) return launch_rowmajor<2, 4>(p, a, st);
-        if (a.d <= 96) return launch_rowmajor<3, 6>(p, a, st);
-        return launch_rowmajor<4, 8>(p, a, st);
+        if (a.d <= 32) return launch_rowmajor<1, 2>(p, a, st, f16);
+        if (a.d <= 64) return launch_rowmajor<2, 4>(p, a, st, f16);
+        if (a.d <= 96) return launch_rowmajor<3, 6>(p, a, st, f16);
+        return launch_rowmajor<4, 8>(p, a, st, f16);
     }
     if (variant == 2 && !can_mfma) return hipErrorInvalidValue;
     if (variant == 3) {

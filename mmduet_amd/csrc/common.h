@@ -23,12 +23,28 @@ __device__ __forceinline__ bf16_t f2bf(float f) {            // round-to-nearest
     __bf16 b = (__bf16)f;
     return __builtin_bit_cast(bf16_t, b);
 }
+// ---- fp16 storage of the vision tower (config tower_dtype = fp16: the reference runs the tower under torch.cuda.amp.autocast(), models/modeling_live.py:28) ----
+constexpr int MMD_F16 = 2;             // internal launcher dtype, never a context dtype: 2-byte IEEE half activations / weights, fp32 accumulate and statistics
+typedef _Float16 f16_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+__device__ __forceinline__ float h2f(uint16_t r) { return (float)__builtin_bit_cast(_Float16, r); }
+__device__ __forceinline__ uint16_t f2h(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }          // round-to-nearest-even (v_cvt_f16_f32)
+// raw 16-bit storage <-> float for kernels that move 2-byte elements as integer vectors
+template <bool F16> __device__ __forceinline__ float raw2f(uint16_t r) { if constexpr (F16) return h2f(r); else return __uint_as_float(((uint32_t)r) << 16); }
 template <typename T> __device__ __forceinline__ float to_f(T v);
 template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
 template <> __device__ __forceinline__ float to_f<bf16_t>(bf16_t v) { return bf2f(v); }
 template <typename T> __device__ __forceinline__ T from_f(float v);
 template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t from_f<bf16_t>(float v) { return f2bf(v); }
+template <> __device__ __forceinline__ float to_f<f16_t>(f16_t v) { return (float)v; }
+template <> __device__ __forceinline__ f16_t from_f<f16_t>(float v) { return (f16_t)v; }
+template <bool F16> __device__ __forceinline__ uint16_t f2raw(float f) { if constexpr (F16) return f2h(f); else return f2bf(f); }
+// one MFMA of the 2-byte GEMM / attention kernels: operands travel as raw 16-byte fragments, the instruction decides what the bits mean (same rate, same layouts)
+template <bool F16> __device__ __forceinline__ f32x4_t mfma16(const bf16x8_t& a, const bf16x8_t& b, const f32x4_t& c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
 // round a float through the storage type (the rounding points of eager bf16 execution)
 template <typename T> __device__ __forceinline__ float rnd(float v) { return to_f<T>(from_f<T>(v)); }
 
@@ -118,6 +134,7 @@ struct GemmArgs {
     int ring_max_blocks = 0;                    // > 0: cap on the persistent grid (co-residency experiments: leave CU resources to another stream)
     const GemvChain* chain = nullptr;           // gemv16 path only (M <= 16, packed bf16 / fp8 weights); see GemvChain
     int* plan_out = nullptr;                    // if set: int[4] = {kernel (GEMM_K_*), output tiles, K splits, blocks launched}
+    int f16 = 0;                                // operands, bias, residual and output are IEEE half (launch_gemm(MMD_F16, ...): the fp16 vision tower; ring / big kernels only)
 };
 // which kernel the dispatcher chose (mmd_op_gemm_last_plan; parity tests assert the production kernel really ran)
 enum { GEMM_K_TILE64 = 0, GEMM_K_TILE128 = 1, GEMM_K_SKINNY = 2, GEMM_K_GEMV16 = 3, GEMM_K_BIG64 = 4, GEMM_K_BIG128 = 5, GEMM_K_RING256 = 6, GEMM_K_RING128X2 = 7 };

@@ -747,7 +747,7 @@ static void launch_skinny_mt(const GemmP& p, const GemmArgs& a, hipStream_t st) 
 //     which makes the row-strided fragment reads bank-conflict-free.
 //   * rows beyond M are clamped on load and masked at the store; N % BN == 0 and K % 64 == 0 are dispatch conditions.
 // ------------------------------------------------------------------------------------------------------------------
-template <int BN, int EPI>
+template <int BN, int EPI, bool F16 = false>
 __global__ __launch_bounds__(256) void gemm_big_kernel(GemmP p, int KT) {
     constexpr int BM = 128, BK = 64;
     constexpr int TM = 4, TN = BN / 32;                      // 16x16 tiles per wave (wave tile 64 x BN/2)
@@ -829,7 +829,7 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(GemmP p, int KT) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) acc[i][j] = mfma16<F16>(wf[j], xf[i], acc[i][j]);
         }
         cur ^= 1;
     }
@@ -882,7 +882,7 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(GemmP p, int KT) {
 #pragma unroll
             for (int j = 0; j < TN; j += 2) {
                 const int nb = n0 + wn + j * 16;
-                const s16x8_t v = pair_to_row8(big_value_pre<EPI>(acc[i][j], has_sc, scq[j], has_bi, biq[j], rq[i][j]), big_value_pre<EPI>(acc[i][j + 1], has_sc, scq[j + 1], has_bi, biq[j + 1], rq[i][j + 1]));
+                const s16x8_t v = pair_to_row8(big_value_pre<EPI, F16>(acc[i][j], has_sc, scq[j], has_bi, biq[j], rq[i][j]), big_value_pre<EPI, F16>(acc[i][j + 1], has_sc, scq[j + 1], has_bi, biq[j + 1], rq[i][j + 1]));
                 if (m < p.M) *reinterpret_cast<s16x8_t*>((bf16_t*)p.Y + (long long)m * p.ldy + nb + (lq & 1) * 16 + (lq >> 1) * 8) = v;
             }
         }
@@ -893,13 +893,21 @@ template <int BN>
 static void launch_big(const GemmP& p, const GemmArgs& a, hipStream_t st) {
     const int tiles = (a.N / BN) * cdiv(a.M, 128);
     int splits = 1;
-    if (tiles < 320 && a.K >= 8192 && a.epi != EPI_SWIGLU && a.splitk_ws) {      // long K, under one block per CU (down_proj): split K
+    if (tiles < 320 && a.K >= 8192 && a.epi != EPI_SWIGLU && a.splitk_ws && !a.f16) {      // long K, under one block per CU (down_proj): split K
         splits = 3;                                                                // (measured: splitting K = 3584 GEMMs costs more than it fills)
         while (splits > 1 && (size_t)splits * a.M * a.N * sizeof(float) > a.splitk_ws_bytes) --splits;
     }
     dim3 grid(a.N / BN, cdiv(a.M, 128), splits);
     set_plan(a, BN == 128 ? GEMM_K_BIG128 : GEMM_K_BIG64, tiles, splits, tiles * splits);
     const int KT = a.K >> 5;
+    if (a.f16) {          // the fp16 vision tower: plain / GELU(tanh) / residual epilogues
+        switch (a.epi) {
+            case EPI_GELU_TANH: hipLaunchKernelGGL((gemm_big_kernel<BN, EPI_GELU_TANH, true>), grid, dim3(256), 0, st, p, KT); break;
+            case EPI_RESID: hipLaunchKernelGGL((gemm_big_kernel<BN, EPI_RESID, true>), grid, dim3(256), 0, st, p, KT); break;
+            default: hipLaunchKernelGGL((gemm_big_kernel<BN, EPI_NONE, true>), grid, dim3(256), 0, st, p, KT); break;
+        }
+        return;
+    }
     switch (a.epi) {
         case EPI_GELU_TANH: hipLaunchKernelGGL((gemm_big_kernel<BN, EPI_GELU_TANH>), grid, dim3(256), 0, st, p, KT); break;
         case EPI_GELU_ERF: hipLaunchKernelGGL((gemm_big_kernel<BN, EPI_GELU_ERF>), grid, dim3(256), 0, st, p, KT); break;
@@ -914,8 +922,9 @@ static void launch_big(const GemmP& p, const GemmArgs& a, hipStream_t st) {
 }
 
 
-template <int WN, bool M32, int NS, bool EARLY>
+template <int WN, bool M32, int NS, bool EARLY, bool F16 = false>
 static hipError_t launch_ringx_t(const GemmP& p, const GemmArgs& a, hipStream_t st, int splits, bool stagger = true) {
+    if (F16) splits = 1;
     while (splits > 1 && (a.epi == EPI_SWIGLU || !a.splitk_ws || (size_t)splits * a.M * a.N * sizeof(float) > a.splitk_ws_bytes)) --splits;
     constexpr int BN = 64 * WN;
     const int tiles = cdiv(a.N, BN) * cdiv(a.M, 256);
@@ -928,8 +937,9 @@ static hipError_t launch_ringx_t(const GemmP& p, const GemmArgs& a, hipStream_t 
     static bool attr_set[64] = {};          // per device (hipFuncSetAttribute applies to the current device's code object)
     int adev = 0; hipGetDevice(&adev);
     if (adev >= 0 && adev < 64 && !attr_set[adev]) {
-#define RX_ATTR(E) hipFuncSetAttribute((const void*)gemm_ringx_kernel<E, WN, M32, NS, EARLY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        RX_ATTR(EPI_NONE) RX_ATTR(EPI_GELU_TANH) RX_ATTR(EPI_GELU_ERF) RX_ATTR(EPI_RESID) RX_ATTR(EPI_SWIGLU)
+#define RX_ATTR(E) hipFuncSetAttribute((const void*)gemm_ringx_kernel<E, WN, M32, NS, EARLY, 0, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        RX_ATTR(EPI_NONE) RX_ATTR(EPI_GELU_TANH) RX_ATTR(EPI_RESID)
+        if constexpr (!F16) { RX_ATTR(EPI_GELU_ERF) RX_ATTR(EPI_SWIGLU) }
 #undef RX_ATTR
         attr_set[adev] = true;
     }
@@ -944,6 +954,14 @@ static hipError_t launch_ringx_t(const GemmP& p, const GemmArgs& a, hipStream_t 
     }
     // start-up stagger of the second-slot blocks in ~4 us units: about half a tile (K/32 steps of ~0.75 us) -- see the kernel
     q.kper = (!stagger || splits > 1) ? 0 : ((a.K / 32) * 10) / 100 + 1;
+    if constexpr (F16) {
+        switch (a.epi) {
+            case EPI_GELU_TANH: hipLaunchKernelGGL((gemm_ringx_kernel<EPI_GELU_TANH, WN, M32, NS, EARLY, 0, true>), grid, block, smem, st, q, KT); break;
+            case EPI_RESID: hipLaunchKernelGGL((gemm_ringx_kernel<EPI_RESID, WN, M32, NS, EARLY, 0, true>), grid, block, smem, st, q, KT); break;
+            case EPI_NONE: hipLaunchKernelGGL((gemm_ringx_kernel<EPI_NONE, WN, M32, NS, EARLY, 0, true>), grid, block, smem, st, q, KT); break;
+            default: return hipErrorInvalidValue;
+        }
+    } else
     switch (a.epi) {
         case EPI_GELU_TANH: hipLaunchKernelGGL((gemm_ringx_kernel<EPI_GELU_TANH, WN, M32, NS, EARLY>), grid, block, smem, st, q, KT); break;
         case EPI_GELU_ERF: hipLaunchKernelGGL((gemm_ringx_kernel<EPI_GELU_ERF, WN, M32, NS, EARLY>), grid, block, smem, st, q, KT); break;
@@ -972,6 +990,7 @@ static hipError_t launch_ringx_dbg(const GemmP& p, const GemmArgs& a, hipStream_
 // flags: bit 0 = 4-wave 256x128 blocks (two per CU), bit 1 = 32x32x16 MFMA, bit 3 = 4-slot ring, bit 4 = refill DMAs in the first rows of a step
 static hipError_t launch_ringx(int flags, const GemmP& p, const GemmArgs& a, hipStream_t st, int splits = 1) {
     const int f = flags & 27;
+    if (a.f16) return launch_ringx_t<4, false, 3, true, true>(p, a, st, 1);          // the fp16 tower runs the shipped instantiation
     if ((flags & 32) && f == 1) return launch_ringx_t<2, false, 3, false>(p, a, st, splits, false);
     if ((flags & 32) && f == 17) return launch_ringx_t<2, false, 3, true>(p, a, st, splits, false);
     switch (f) {
@@ -1026,7 +1045,7 @@ static hipError_t launch_t(const GemmArgs& a, hipStream_t st, int* kind_out) {
         // long K with under one block wave of 256^2 tiles (down_proj of a chunk): split K across grid.z so ~one block per CU runs a
         // long steady state (1.05 PF at M = 1274 against 0.84 PF for the 128-row kernel's 3-way split); K = 3584 shapes lose to it
         const bool ring_split_ok = big_packed_ok(MMD_BF16, a, 16) && (a.N % 32) == 0 && a.epi != EPI_SWIGLU && a.splitk_ws != nullptr && ring_size_ok(a);
-        if (variant == GEMM_RING256_SPLIT || (variant == GEMM_AUTO && a.M >= 512 && a.K >= 8192 && ring_split_ok && !getenv("MMDUET_NO_RING256"))) {
+        if (!a.f16 && (variant == GEMM_RING256_SPLIT || (variant == GEMM_AUTO && a.M >= 512 && a.K >= 8192 && ring_split_ok && !getenv("MMDUET_NO_RING256")))) {
             if (variant == GEMM_RING256_SPLIT && (!big_packed_ok(MMD_BF16, a, 16) || (a.N % 32) != 0 || !ring_size_ok(a))) return hipErrorInvalidValue;
             const int t256 = cdiv(a.M, 256) * cdiv(a.N, 256);
             int sp = 256 / t256; if (sp < 1) sp = 1;
@@ -1079,6 +1098,7 @@ static hipError_t launch_t(const GemmArgs& a, hipStream_t st, int* kind_out) {
             }
             if (variant == GEMM_BIG) return hipErrorInvalidValue;
         }
+        if (a.f16) return hipErrorInvalidValue;          // IEEE-half operands exist in the ring / big kernels only (the tower's shapes: M >= 65, N % 64 == 0, K % 64 == 0, packed weights)
         if (skinny && skinny_packed_ok(MMD_BF16, a)) {
             p.W = a.Wp;
             if (a.M <= 16 && !a.no_gemv) launch_gemv16(p, a, st);
@@ -1124,5 +1144,6 @@ static hipError_t launch_t(const GemmArgs& a, hipStream_t st, int* kind_out) {
 bool gemm_can_slab(int dtype, const GemmArgs& a) { return skinny_packed_ok(dtype, a) && a.splitk_ws != nullptr && a.epi != EPI_SWIGLU; }
 
 hipError_t launch_gemm(int dtype, const GemmArgs& a, hipStream_t st, int* kind_out) {
+    if (dtype == MMD_F16) { GemmArgs h = a; h.f16 = 1; return launch_t<bf16_t>(h, st, kind_out); }          // 2-byte storage either way; the kernels' F16 forms read the bits as IEEE half
     return dtype == MMD_F32 ? launch_t<float>(a, st, kind_out) : launch_t<bf16_t>(a, st, kind_out);
 }

@@ -45,7 +45,7 @@ __device__ __forceinline__ s16x4_t big_value(const GemmP& p, int m, int n, const
 }
 // the same value from operands the caller already holds: per-column weight scale / bias quads (one load per TILE, not per row) and the residual quad of
 // this row (prefetched one row ahead).  Same arithmetic, same rounding points.
-template <int EPI>
+template <int EPI, bool F16 = false>          // F16: bias, residual and result are IEEE half instead of bfloat16 (the fp16 vision tower); same rounding points
 __device__ __forceinline__ s16x4_t big_value_pre(const f32x4_t& a, bool has_scale, const f32x4_t& sc, bool has_bias, const s16x4_t& b, const s16x4_t& rr) {
     float v[4] = {a[0], a[1], a[2], a[3]};
     if (has_scale) {
@@ -54,19 +54,19 @@ __device__ __forceinline__ s16x4_t big_value_pre(const f32x4_t& a, bool has_scal
     }
     if (has_bias) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += bf2f((bf16_t)b[r]);
+        for (int r = 0; r < 4; ++r) v[r] += raw2f<F16>((uint16_t)b[r]);
     }
     if constexpr (EPI == EPI_GELU_TANH) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_fast(bf2f(f2bf(v[r])));
+        for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_fast(raw2f<F16>(f2raw<F16>(v[r])));
     } else if constexpr (EPI == EPI_GELU_ERF) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_erf_fast(bf2f(f2bf(v[r])));
+        for (int r = 0; r < 4; ++r) v[r] = gelu_erf_fast(raw2f<F16>(f2raw<F16>(v[r])));
     } else if constexpr (EPI == EPI_RESID) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = bf2f(f2bf(v[r])) + bf2f((bf16_t)rr[r]);
+        for (int r = 0; r < 4; ++r) v[r] = raw2f<F16>(f2raw<F16>(v[r])) + raw2f<F16>((uint16_t)rr[r]);
     }
-    return s16x4_t{(short)f2bf(v[0]), (short)f2bf(v[1]), (short)f2bf(v[2]), (short)f2bf(v[3])};
+    return s16x4_t{(short)f2raw<F16>(v[0]), (short)f2raw<F16>(v[1]), (short)f2raw<F16>(v[2]), (short)f2raw<F16>(v[3])};
 }
 template <int EPI>
 __device__ __forceinline__ void big_store(const GemmP& p, int m, int n, const f32x4_t& a) {
@@ -146,8 +146,9 @@ __device__ __forceinline__ s16x8_t halves_to_row8(const s16x4_t& q0, const s16x4
 }
 
 // DBG != 0: timing experiments only (results are WRONG): 1 = X pieces fetched as contiguous 1 KB runs, 2 = no X DMA, 3 = no DMA at all
-template <int EPI, int WN, bool M32, int NS, bool EARLY, int DBG = 0>
+template <int EPI, int WN, bool M32, int NS, bool EARLY, int DBG = 0, bool F16 = false>          // F16: IEEE-half operands / bias / residual / output (v_mfma_f32_16x16x32_f16: same rate, same layouts)
 __global__ __launch_bounds__(WN * 128, 2) void gemm_ringx_kernel(GemmP p, int KT) {
+    static_assert(!F16 || (!M32 && EPI != EPI_SWIGLU), "the fp16 form exists for the 16x16x32 schedule and the tower's epilogues");
     constexpr int BM = 256, BN = 64 * WN, BK = 32, NW = 2 * WN;
     constexpr int XE = BM * BK, WE = BN * BK, SE = XE + WE;    // elements per ring slot (32 KB / 24 KB)
     constexpr int XP = (BM / 16) / NW, WP = (BN / 16) / NW;    // X / W pieces (1 KB DMAs) per wave and slice: 2+2 (8 waves), 4+2 (4 waves)
@@ -272,19 +273,19 @@ __global__ __launch_bounds__(WN * 128, 2) void gemm_ringx_kernel(GemmP p, int KT
                 // matrix pipe's shadow of this wave's own previous MFMA.  Row i refills a[i-1] (dead since row i-1); a[7] travels in a7n from row 0.
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[0], a[i], acc[i][0], 0, 0, 0);
+                    acc[i][0] = mfma16<F16>(b[0], a[i], acc[i][0]);
                     __builtin_amdgcn_sched_barrier(0);
                     if (more) { if (i == 0) a7n = *reinterpret_cast<const bf16x8_t*>(nbase + aoff + 7 * 512); else a[i - 1] = *reinterpret_cast<const bf16x8_t*>(nbase + aoff + (i - 1) * 512); }
                     __builtin_amdgcn_sched_barrier(0);
-                    acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[1], a[i], acc[i][1], 0, 0, 0);
+                    acc[i][1] = mfma16<F16>(b[1], a[i], acc[i][1]);
                     __builtin_amdgcn_sched_barrier(0);
                     if (more && i < 4) bn[i] = *reinterpret_cast<const bf16x8_t*>(nbase + boff + i * 512);
                     __builtin_amdgcn_sched_barrier(0);
-                    acc[i][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[2], a[i], acc[i][2], 0, 0, 0);
+                    acc[i][2] = mfma16<F16>(b[2], a[i], acc[i][2]);
                     __builtin_amdgcn_sched_barrier(0);
                     if (refill && i < XP + WP) dma_k(slot, s + NS, i);
                     __builtin_amdgcn_sched_barrier(0);
-                    acc[i][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[3], a[i], acc[i][3], 0, 0, 0);
+                    acc[i][3] = mfma16<F16>(b[3], a[i], acc[i][3]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (more) a[7] = a7n;
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(WN * 128, 2) void gemm_ringx_kernel(GemmP p, int KT
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<F16>(b[j], a[i], acc[i][j]);
                 __builtin_amdgcn_sched_barrier(0);
                 if (more) {
                     if (i < 6) a[i] = *reinterpret_cast<const bf16x8_t*>(nbase + aoff + i * 512);
@@ -418,7 +419,7 @@ __global__ __launch_bounds__(WN * 128, 2) void gemm_ringx_kernel(GemmP p, int KT
 #pragma unroll
                     for (int j = 0; j < 4; j += 2) {
                         const int nb = en0 + wc * 64 + j * 16;
-                        const s16x8_t v = pair_to_row8(big_value_pre<EPI>(acc[i][j], has_sc, scq[j], has_bi, biq[j], rq[j]), big_value_pre<EPI>(acc[i][j + 1], has_sc, scq[j + 1], has_bi, biq[j + 1], rq[j + 1]));
+                        const s16x8_t v = pair_to_row8(big_value_pre<EPI, F16>(acc[i][j], has_sc, scq[j], has_bi, biq[j], rq[j]), big_value_pre<EPI, F16>(acc[i][j + 1], has_sc, scq[j + 1], has_bi, biq[j + 1], rq[j + 1]));
                         if constexpr (DBG == 6) { const u32x4_t w = __builtin_bit_cast(u32x4_t, v); asm volatile("" :: "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3])); }      // timing only: converted, not stored
                         else {
                             const bool ok = m < p.M && nb + 16 * (lq & 1) + 16 <= p.N;

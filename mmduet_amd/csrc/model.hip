@@ -185,6 +185,9 @@ extern "C" int mmd_create(const mmd_config* cfg, int device, mmd_ctx** out) {
     if (cfg->weight_dtype != MMD_W_DTYPE && (cfg->weight_dtype != MMD_W_FP8_E4M3 || cfg->dtype != MMD_BF16)) { g_create_error = "weight_dtype fp8_e4m3 needs a bf16 context"; return MMD_EINVAL; }
     if (!cfg->vision_only && (cfg->num_heads % cfg->num_kv_heads != 0 || cfg->head_dim % 2 != 0 || cfg->head_dim > 128)) { g_create_error = "unsupported head configuration"; return MMD_EINVAL; }
     if (cfg->vit_hidden % cfg->vit_heads != 0 || cfg->vit_hidden / cfg->vit_heads > 128) { g_create_error = "unsupported ViT head configuration"; return MMD_EINVAL; }
+    if (cfg->tower_f16 && (cfg->dtype != MMD_BF16 || cfg->vision_only || cfg->vit_class_token || cfg->vit_pre_layernorm || cfg->vit_act != 0 || cfg->vit_pool_head ||
+                           (cfg->vit_hidden % 64) != 0 || ((cfg->vit_hidden / cfg->vit_heads) % 8) != 0)) {
+        g_create_error = "tower_f16 needs a bf16 context and the LLaVA SigLIP tower form (no class token / pre-LN / pooling head, hidden % 64 == 0, head_dim % 8 == 0)"; return MMD_EINVAL; }
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) { g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e); return MMD_EHIP; }
     mmd_ctx* c = new mmd_ctx();
@@ -413,6 +416,12 @@ extern "C" int mmd_finalize_weights(mmd_ctx* c) {
     }
     }
     // vision tower
+    if (g.tower_f16) {
+        // the checkpoint's bf16 tower parameters become IEEE half, as autocast casts them per op (exact for every normal value: 8 mantissa bits into 11);
+        // padding / fusing / fragment packing below only move 2-byte elements
+        for (auto& kv : c->raw)
+            if (kv.first.rfind("vit.", 0) == 0) HIPCHK(c, launch_convert(kv.second.p, MMD_BF16, kv.second.p, MMD_F16, kv.second.numel, st));
+    }
     const int C = g.vit_hidden, CI = g.vit_intermediate, P = g.vit_patch, KP = 3 * P * P;
     {
         TAKE(w, "vit.embeddings.patch_embedding.weight", {C, 3, P, P});
@@ -551,10 +560,13 @@ static int connector_pool(mmd_ctx* c, const void* feats, int B, void* out);
 static int ensure_preprocess_tables(mmd_ctx* c, int T, int R);
 // the tower: patch-embed (+ class token, + pre-LN for CLIP) -> encoder layers -> optional post_layernorm; result [B * vit_seq, C] in c->v_h
 static int vit_tower(mmd_ctx* c, const void* px, int B, bool col_ready = false) {
-    const mmd_config& g = c->cfg; const int dt = g.dtype; hipStream_t st = c->stream;
+    const mmd_config& g = c->cfg; hipStream_t st = c->stream;
+    // tower_f16: every tower tensor is IEEE half (the reference's autocast); pixel_values arrive in the model dtype (bf16) and become half in the im2col pass,
+    // the tower's output is rounded to bf16 at the end (SigLipVisionTower returns hidden_states[-1].to(images.dtype) [3P-recalled])
+    const int dt = g.tower_f16 ? MMD_F16 : g.dtype;
     if (B > g.max_vit_batch) FAIL(c, MMD_ERANGE, "vit batch %d exceeds max_vit_batch %d", B, g.max_vit_batch);
     const int C = g.vit_hidden, T = c->vit_tokens, TS = c->vit_seq, M = B * TS, hd = C / g.vit_heads;
-    if (!col_ready) { ProfScope ps(c, MMD_K_OTHER, 0, 0); HIPCHK(c, launch_im2col(dt, px, B, g.vit_image, g.vit_patch, c->vit_grid, c->vit_kpad, c->v_col, st)); }
+    if (!col_ready) { ProfScope ps(c, MMD_K_OTHER, 0, 0); HIPCHK(c, launch_im2col(g.tower_f16 ? MMD_F16 + 1 : dt, px, B, g.vit_image, g.vit_patch, c->vit_grid, c->vit_kpad, c->v_col, st)); }
     void* patch_out = g.vit_class_token ? c->v_patch : c->v_h;
     int rc = gemm(c, c->v_col, c->vit_kpad, c->patch_w, c->vit_kpad, c->patch_b, nullptr, 0, patch_out, C, B * T, C, c->vit_kpad, EPI_NONE, 0, GEMM_AUTO, c->patch_w_p, true); if (rc) return rc;
     if (g.vit_class_token) {
@@ -588,6 +600,7 @@ static int vit_tower(mmd_ctx* c, const void* px, int B, bool col_ready = false) 
         rc = gemm(c, c->v_mlp, c->vit_ipad, L.w2, c->vit_ipad, L.b2, c->v_h, C, c->v_h, C, M, C, c->vit_ipad, EPI_RESID, 0, GEMM_AUTO, L.w2_p, true); if (rc) return rc;
     }
     if (g.vit_post_layernorm) { HIPCHK(c, launch_layernorm(dt, c->v_h, c->post_w, c->post_b, c->v_h, M, C, g.vit_ln_eps, st)); }
+    if (g.tower_f16) { ProfScope ps(c, MMD_K_OTHER, 0, 0); HIPCHK(c, launch_convert(c->v_h, MMD_F16, c->v_h, MMD_BF16, (int64_t)M * C, st)); }          // in place, elementwise
     c->last_vit_B = B;
     return MMD_OK;
 }
@@ -611,7 +624,7 @@ extern "C" int mmd_vit_encode_frames(mmd_ctx* c, const uint8_t* frames, int B, i
     if (B > c->cfg.max_vit_batch) FAIL(c, MMD_ERANGE, "vit batch %d exceeds max_vit_batch %d", B, c->cfg.max_vit_batch);
     int rc = ensure_preprocess_tables(c, B, R); if (rc) return rc;
     { ProfScope ps(c, MMD_K_OTHER, 0, 0);
-      HIPCHK(c, launch_preprocess_im2col(c->cfg.dtype, frames, B, R, c->cfg.vit_image, c->pp_coef, c->pp_bounds, c->pp_ksize, c->pp_tmp, c->cfg.vit_patch, c->vit_grid,
+      HIPCHK(c, launch_preprocess_im2col(c->cfg.tower_f16 ? MMD_F16 : c->cfg.dtype, frames, B, R, c->cfg.vit_image, c->pp_coef, c->pp_bounds, c->pp_ksize, c->pp_tmp, c->cfg.vit_patch, c->vit_grid,
                                          c->vit_kpad, c->v_col, c->stream)); }
     rc = vit_tower(c, nullptr, B, true); if (rc) return rc;
     return connector_pool(c, c->v_h, B, out);

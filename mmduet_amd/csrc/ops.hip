@@ -1,6 +1,7 @@
 // ops.hip -- the HBM-bound operators of the path: norms, RoPE + KV append, embedding gather, patch im2col, pooling,
 // response heads, greedy sampling, layout helpers.  wave64 shuffles for reductions, 16-byte vector accesses.
 #include "common.h"
+#include <type_traits>
 
 // ---------------------------------------------------------------------------------------------------------------
 // RMSNorm -- Qwen2RMSNorm.forward (transformers qwen2/modeling_qwen2.py:248-253): fp32 statistics,
@@ -59,6 +60,7 @@ __global__ void layernorm_kernel(const T* __restrict__ x, const T* __restrict__ 
     if (row >= M) return;
     const T* xr = x + (long long)row * H;
     T* yr = y + (long long)row * H;
+    [[maybe_unused]] constexpr bool F16 = std::is_same<T, f16_t>::value;
     if constexpr (sizeof(T) == 2) {
         if ((H & 7) == 0 && H <= 2048) {
             // one wave per row, 16-byte accesses, the row stays in registers between the statistics and the output pass
@@ -70,7 +72,7 @@ __global__ void layernorm_kernel(const T* __restrict__ x, const T* __restrict__ 
                 if (c < H) {
                     s16x8_t raw = *reinterpret_cast<const s16x8_t*>(xr + c);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { v[j][e] = bf2f((bf16_t)raw[e]); s += v[j][e]; }
+                    for (int e = 0; e < 8; ++e) { v[j][e] = raw2f<F16>((uint16_t)raw[e]); s += v[j][e]; }
                 }
             }
             const float mu = wave_sum(s) / (float)H;
@@ -90,7 +92,7 @@ __global__ void layernorm_kernel(const T* __restrict__ x, const T* __restrict__ 
                 if (c < H) {
                     s16x8_t g = *reinterpret_cast<const s16x8_t*>(w + c), bb = *reinterpret_cast<const s16x8_t*>(b + c), o;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = (short)f2bf((v[j][e] - mu) * inv * bf2f((bf16_t)g[e]) + bf2f((bf16_t)bb[e]));
+                    for (int e = 0; e < 8; ++e) o[e] = (short)f2raw<F16>((v[j][e] - mu) * inv * raw2f<F16>((uint16_t)g[e]) + raw2f<F16>((uint16_t)bb[e]));
                     *reinterpret_cast<s16x8_t*>(yr + c) = o;
                 }
             }
@@ -110,6 +112,7 @@ hipError_t launch_layernorm(int dtype, const void* x, const void* w, const void*
     if (M <= 0) return hipSuccess;
     dim3 grid(cdiv(M, 4)), block(256);
     if (dtype == MMD_F32) hipLaunchKernelGGL(layernorm_kernel<float>, grid, block, 0, st, (const float*)x, (const float*)w, (const float*)b, (float*)y, M, H, eps);
+    else if (dtype == MMD_F16) hipLaunchKernelGGL(layernorm_kernel<f16_t>, grid, block, 0, st, (const f16_t*)x, (const f16_t*)w, (const f16_t*)b, (f16_t*)y, M, H, eps);
     else hipLaunchKernelGGL(layernorm_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)y, M, H, eps);
     return hipGetLastError();
 }
@@ -252,6 +255,7 @@ hipError_t launch_add_rows(int dtype, void* x, const void* add, int M, int H, in
     if (total <= 0) return hipSuccess;
     dim3 grid(cdiv(total, 256)), block(256);
     if (dtype == MMD_F32) hipLaunchKernelGGL(add_rows_kernel<float>, grid, block, 0, st, (float*)x, (const float*)add, total, H, period);
+    else if (dtype == MMD_F16) hipLaunchKernelGGL(add_rows_kernel<f16_t>, grid, block, 0, st, (f16_t*)x, (const f16_t*)add, total, H, period);
     else hipLaunchKernelGGL(add_rows_kernel<bf16_t>, grid, block, 0, st, (bf16_t*)x, (const bf16_t*)add, total, H, period);
     return hipGetLastError();
 }
@@ -343,16 +347,17 @@ hipError_t launch_embed(int dtype, const void* table, const int64_t* ids, int k,
 // patch im2col -- SiglipVisionEmbeddings conv(k = stride = patch) as a GEMM operand (siglip/modeling_siglip.py:124-179):
 // row (b, gy, gx), column (c, ky, kx) in conv-weight flatten order, zero-padded to Kpad.
 // ---------------------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ void im2col_kernel(const T* __restrict__ px, int img, int patch, int grid, int Kpad, T* __restrict__ out) {
+template <typename T, typename TO = T>          // TO != T: bf16 pixel_values into the fp16 tower's patch matrix (exact: |x| <= 1 and 8 mantissa bits)
+__global__ void im2col_kernel(const T* __restrict__ px, int img, int patch, int grid, int Kpad, TO* __restrict__ out) {
     int row = blockIdx.x;                              // b*grid*grid + gy*grid + gx
     int b = row / (grid * grid), rem = row % (grid * grid), gy = rem / grid, gx = rem % grid;
     int K = 3 * patch * patch;
     for (int k = threadIdx.x; k < Kpad; k += blockDim.x) {
-        T v = 0;
+        TO v = 0;
         if (k < K) {
             int c = k / (patch * patch), r2 = k % (patch * patch), ky = r2 / patch, kx = r2 % patch;
-            v = px[(((long long)b * 3 + c) * img + gy * patch + ky) * img + gx * patch + kx];
+            const T s = px[(((long long)b * 3 + c) * img + gy * patch + ky) * img + gx * patch + kx];
+            if constexpr (std::is_same<T, TO>::value) v = s; else v = from_f<TO>(to_f<T>(s));
         }
         out[(long long)row * Kpad + k] = v;
     }
@@ -361,6 +366,8 @@ hipError_t launch_im2col(int dtype, const void* px, int B, int img, int patch, i
     int rows = B * grid * grid;
     if (rows <= 0) return hipSuccess;
     if (dtype == MMD_F32) hipLaunchKernelGGL(im2col_kernel<float>, dim3(rows), dim3(256), 0, st, (const float*)px, img, patch, grid, Kpad, (float*)out);
+    else if (dtype == MMD_F16) hipLaunchKernelGGL(im2col_kernel<f16_t>, dim3(rows), dim3(256), 0, st, (const f16_t*)px, img, patch, grid, Kpad, (f16_t*)out);
+    else if (dtype == MMD_F16 + 1) hipLaunchKernelGGL((im2col_kernel<bf16_t, f16_t>), dim3(rows), dim3(256), 0, st, (const bf16_t*)px, img, patch, grid, Kpad, (f16_t*)out);
     else hipLaunchKernelGGL(im2col_kernel<bf16_t>, dim3(rows), dim3(256), 0, st, (const bf16_t*)px, img, patch, grid, Kpad, (bf16_t*)out);
     return hipGetLastError();
 }
@@ -525,10 +532,14 @@ __global__ void convert_kernel(const S* __restrict__ s, D* __restrict__ d, long 
 hipError_t launch_convert(const void* src, int sdt, void* dst, int ddt, int64_t n, hipStream_t st) {
     if (n <= 0) return hipSuccess;
     int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    if (sdt == MMD_F32 && ddt == MMD_F32) hipLaunchKernelGGL((convert_kernel<float, float>), dim3(blocks), dim3(256), 0, st, (const float*)src, (float*)dst, (long long)n);
-    else if (sdt == MMD_F32) hipLaunchKernelGGL((convert_kernel<float, bf16_t>), dim3(blocks), dim3(256), 0, st, (const float*)src, (bf16_t*)dst, (long long)n);
-    else if (ddt == MMD_F32) hipLaunchKernelGGL((convert_kernel<bf16_t, float>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)src, (float*)dst, (long long)n);
-    else hipLaunchKernelGGL((convert_kernel<bf16_t, bf16_t>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, (long long)n);
+#define CV(S, D) hipLaunchKernelGGL((convert_kernel<S, D>), dim3(blocks), dim3(256), 0, st, (const S*)src, (D*)dst, (long long)n)
+    if (sdt == MMD_F16) { if (ddt == MMD_F32) CV(f16_t, float); else if (ddt == MMD_F16) CV(f16_t, f16_t); else CV(f16_t, bf16_t); }
+    else if (ddt == MMD_F16) { if (sdt == MMD_F32) CV(float, f16_t); else CV(bf16_t, f16_t); }
+    else if (sdt == MMD_F32 && ddt == MMD_F32) CV(float, float);
+    else if (sdt == MMD_F32) CV(float, bf16_t);
+    else if (ddt == MMD_F32) CV(bf16_t, float);
+    else CV(bf16_t, bf16_t);
+#undef CV
     return hipGetLastError();
 }
 
@@ -682,6 +693,7 @@ __global__ void resize_v_norm_im2col_kernel(const uint8_t* __restrict__ tmp, int
             }
             float f = (float)px * (1.0f / 255.0f);
             f = (f - 0.5f) / 0.5f;
+            if constexpr (std::is_same<T, f16_t>::value) f = bf2f(f2bf(f));          // the driver hands the tower bf16 pixel_values (test/inference.py:203); autocast then casts those to half
             v = from_f<T>(f);
         }
         out[(long long)row * Kpad + k] = v;
@@ -700,6 +712,7 @@ hipError_t launch_preprocess_im2col(int dtype, const uint8_t* frames, int T_, in
     }
     const int rows = T_ * grid * grid;
     if (dtype == MMD_F32) hipLaunchKernelGGL(resize_v_norm_im2col_kernel<float>, dim3(rows), dim3(256), 0, st, vsrc, R, size, coef, bounds, ksize, identity, patch, grid, Kpad, (float*)out);
+    else if (dtype == MMD_F16) hipLaunchKernelGGL(resize_v_norm_im2col_kernel<f16_t>, dim3(rows), dim3(256), 0, st, vsrc, R, size, coef, bounds, ksize, identity, patch, grid, Kpad, (f16_t*)out);
     else hipLaunchKernelGGL(resize_v_norm_im2col_kernel<bf16_t>, dim3(rows), dim3(256), 0, st, vsrc, R, size, coef, bounds, ksize, identity, patch, grid, Kpad, (bf16_t*)out);
     return hipGetLastError();
 }

@@ -242,6 +242,12 @@ class VideoHeadLiveLlavaQwenForCausalLM:
         if wd not in (None, 'bf16', 'model', 'fp8', 'fp8_e4m3'):
             raise ValueError(f'unknown weight_dtype {wd!r} (None | "fp8_e4m3")')
         c.weight_dtype = 1 if wd in ('fp8', 'fp8_e4m3') else 0
+        td = getattr(config, 'tower_dtype', None)
+        if td not in (None, 'model', 'bf16', 'fp16', 'float16'):
+            raise ValueError(f'unknown tower_dtype {td!r} (None | "fp16")')
+        c.tower_f16 = 1 if td in ('fp16', 'float16') else 0          # the reference's autocast tower (models/modeling_live.py:28): IEEE-half tower, bf16 everywhere else
+        if c.tower_f16 and torch_dtype != torch.bfloat16:
+            raise ValueError('tower_dtype=fp16 needs torch_dtype=bfloat16')
         if c.weight_dtype and torch_dtype != torch.bfloat16:
             raise ValueError('weight_dtype=fp8_e4m3 needs torch_dtype=bfloat16 (fp8 weights x bf16 activations, fp32 accumulate)')
         self._cfg_struct = c

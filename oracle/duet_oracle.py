@@ -227,6 +227,43 @@ def vit_forward(w, cfg: OracleConfig, pixel_values):
     return h.to(pixel_values.dtype)
 
 
+def vit_forward_autocast_fp16(w, cfg: OracleConfig, pixel_values):
+    """The tower as the reference's GPU path runs it: `with torch.cuda.amp.autocast(): frames = self.vision_encode(...)` (models/modeling_live.py:28).
+    Restated from the CUDA autocast op policy [3P, torch/csrc/autocast] applied to SigLipVisionTower / SiglipEncoderLayer [3P-recalled]:
+      * conv / linear / matmul run with fp16 inputs and weights (fp32 accumulate), result fp16; the bias add is inside the op;
+      * layer_norm and softmax are on the fp32 list: computed AND returned in fp32 (the next linear casts its input to fp16);
+      * `patch_embeds (fp16) + position_embedding (model dtype)` and every residual `hidden + sublayer_out (fp16)` promote to fp32: the residual stream is fp32;
+      * gelu_pytorch_tanh on an fp16 tensor: fp16 in, fp16 out;
+      * the tower returns `hidden_states[-1].to(images.dtype)`.
+    PARITY UNPINNED: `torch.cuda.amp.autocast` is a no-op without CUDA and CPU autocast follows a different op list, so the reference classes cannot be run
+    this way in the build container; the plain (non-autocast) tower restatement above IS pinned against them (tests/test_oracle_vs_golden.py)."""
+    h16 = lambda t: t.to(torch.float16)
+    B, C, Himg, Wimg = pixel_values.shape
+    P, g = cfg.vit_patch_size, cfg.vit_grid
+    x = pixel_values[:, :, :g * P, :g * P].reshape(B, C, g, P, g, P).permute(0, 2, 4, 1, 3, 5).reshape(B, g * g, C * P * P)
+    h = linear(h16(x), h16(w[VT + 'embeddings.patch_embedding.weight'].flatten(1)), h16(w[VT + 'embeddings.patch_embedding.bias']))
+    h = h.float() + w[VT + 'embeddings.position_embedding.weight'][None].float()
+    nh = cfg.vit_heads
+    for i in range(cfg.vit_layers):
+        p = VT + f'encoder.layers.{i}.'
+        r = h
+        x = layer_norm(h, w[p + 'layer_norm1.weight'], w[p + 'layer_norm1.bias'], cfg.vit_layer_norm_eps)          # fp32 in, fp32 out
+        N, Cw = x.shape[1], x.shape[2]
+        hd = Cw // nh
+        q, k, v = (linear(h16(x), h16(w[p + f'self_attn.{n}.weight']), h16(w[p + f'self_attn.{n}.bias'])).view(B, N, nh, hd).transpose(1, 2) for n in ('q_proj', 'k_proj', 'v_proj'))
+        s = torch.matmul(q, k.transpose(2, 3)) * (hd ** -0.5)                                                         # fp16
+        a = torch.softmax(s, dim=-1, dtype=torch.float32).to(q.dtype)
+        o = torch.matmul(a, v).transpose(1, 2).reshape(B, N, Cw)
+        h = r + linear(o, h16(w[p + 'self_attn.out_proj.weight']), h16(w[p + 'self_attn.out_proj.bias'])).float()
+        r = h
+        x = layer_norm(h, w[p + 'layer_norm2.weight'], w[p + 'layer_norm2.bias'], cfg.vit_layer_norm_eps)
+        x = gelu_tanh(linear(h16(x), h16(w[p + 'mlp.fc1.weight']), h16(w[p + 'mlp.fc1.bias'])))
+        h = r + linear(x, h16(w[p + 'mlp.fc2.weight']), h16(w[p + 'mlp.fc2.bias'])).float()
+    if cfg.vit_post_layernorm:
+        h = layer_norm(h, w[VT + 'post_layernorm.weight'], w[VT + 'post_layernorm.bias'], cfg.vit_layer_norm_eps)
+    return h.to(pixel_values.dtype)
+
+
 def connector(w, x):
     """models/live_llava/video_head_live_llava_qwen.py:90-91 -> mm_projector = Linear, GELU(erf), Linear [3P-recalled]."""
     h = gelu_erf(linear(x, w['model.mm_projector.0.weight'], w['model.mm_projector.0.bias']))
@@ -296,9 +333,9 @@ def adaptive_avg_pool_tokens(x, out_hw):
     return torch.stack(rows, 1).reshape(B, oh * ow, C).to(x.dtype)
 
 
-def visual_embed(w, cfg: OracleConfig, pixel_values):
-    """models/modeling_live.py:26-33: tower -> connector -> pooling -> flatten to [B*frame_num_tokens, hidden]."""
-    h = vit_forward(w, cfg, pixel_values)
+def visual_embed(w, cfg: OracleConfig, pixel_values, tower_autocast_fp16=False):
+    """models/modeling_live.py:26-33: tower (under autocast on the reference's GPU path, :28) -> connector -> pooling -> flatten to [B*frame_num_tokens, hidden]."""
+    h = vit_forward_autocast_fp16(w, cfg, pixel_values) if tower_autocast_fp16 else vit_forward(w, cfg, pixel_values)
     h = connector(w, h)
     h = post_projector_pooling(cfg, h)
     return h.reshape(-1, h.shape[-1])
@@ -461,8 +498,10 @@ class OracleModel:
     def get_input_embeddings(self):
         return self._embed
 
+    tower_autocast_fp16 = False          # True: the tower as under torch.cuda.amp.autocast() (vit_forward_autocast_fp16)
+
     def visual_embed(self, frames):
-        return visual_embed(self.w, self.cfg, frames.to(self.dtype))
+        return visual_embed(self.w, self.cfg, frames.to(self.dtype), tower_autocast_fp16=self.tower_autocast_fp16)
 
     def connector_pool(self, tower_features, out=None):
         """models/modeling_live.py:30-33 for pre-extracted tower features (no `vision_encode`): connector -> pooling -> flatten."""

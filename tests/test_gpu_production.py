@@ -26,7 +26,7 @@ def _record(key, **vals):
     try:
         d = os.path.join(ROOT, 'gpurun_out')
         os.makedirs(d, exist_ok=True)
-        path = os.path.join(d, 'parity_r02.json')
+        path = os.path.join(d, 'parity_r03.json')
         cur = json.load(open(path)) if os.path.exists(path) else {}
         cur[key] = RESULTS[key]
         json.dump(cur, open(path, 'w'), indent=1, sort_keys=True)
@@ -190,7 +190,7 @@ def test_chunk_attention_at_production_sizes(ops, S, n_ctx):
 
 
 # ---- true-width models ---------------------------------------------------------------------------------------------------------------
-def _build(llm_layers, vit_layers, dtype, vocab=2048, max_vit_batch=35, max_step_tokens=1536, seed=3):
+def _build(llm_layers, vit_layers, dtype, vocab=2048, max_vit_batch=35, max_step_tokens=1536, seed=3, tower_dtype=None):
     """(HIP model, oracle weights dict on the device in `dtype`-rounded fp32, oracle config)."""
     from mmduet_amd.configuration_live import VideoHeadLiveLlavaQwenConfig
     from mmduet_amd.modeling_live import VideoHeadLiveLlavaQwenForCausalLM
@@ -198,6 +198,8 @@ def _build(llm_layers, vit_layers, dtype, vocab=2048, max_vit_batch=35, max_step
     pcfg = VideoHeadLiveLlavaQwenConfig(vocab_size=vocab, num_hidden_layers=llm_layers, vit_num_hidden_layers=vit_layers + 1, vit_layers_removed=1,
                                         frame_num_tokens=49, frame_resolution=384, v_placeholder='<image>')
     ocfg = O.OracleConfig(vocab_size=vocab, num_hidden_layers=llm_layers, vit_layers=vit_layers)
+    if tower_dtype:
+        pcfg.tower_dtype = tower_dtype
     m = VideoHeadLiveLlavaQwenForCausalLM(pcfg, torch_dtype=dtype, max_vit_batch=max_vit_batch, max_step_tokens=max_step_tokens, kv_initial_tokens=4096)
     w = {}
     for name, t in synthetic_weights(pcfg, seed=seed, device=m.device, dtype=dtype, scale='unit'):
@@ -351,6 +353,77 @@ def test_full_depth_stream_prefix_measured_deltas():
         assert first > 0 or res['lm_logits']['fp32_top2_margin'] < 4 * res['lm_logits']['ours_vs_fp32'], res
     del m, w, o32, o16
     torch.cuda.empty_cache()
+
+
+# ---- the reference's autocast (fp16) tower --------------------------------------------------------------------------------------------------
+def _rms(a, b):
+    return (a.float() - b.float().to(a.device)).pow(2).mean().sqrt().item()
+
+
+def test_fp16_tower_true_width_error_against_fp32():
+    """config.tower_dtype = 'fp16' (models/modeling_live.py:28 runs the tower under torch.cuda.amp.autocast()): IEEE-half tower weights /
+    activations (v_mfma_f32_16x16x32_f16), fp32 LayerNorm / softmax statistics, bf16 features out.  True width, 4 tower layers, 8 frames, fused-preprocess and
+    pixel_values entry points.  Measured: rms error of the tower output against the fp32 oracle for the bf16 tower, the fp16 tower and the oracle's restatement of the
+    autocast path; the fp16 tower must cut the bf16 tower's error at least in half and stay within 3 x the autocast oracle's own error (+ 1e-3 x scale)."""
+    mb, w, ocfg = _build(1, 4, torch.bfloat16, max_vit_batch=8)
+    mh, _, _ = _build(1, 4, torch.bfloat16, max_vit_batch=8, tower_dtype='fp16')
+    dev = mb.device
+    g = torch.Generator(device=dev).manual_seed(21)
+    px = torch.randn(8, 3, 384, 384, generator=g, device=dev).to(torch.bfloat16)
+    w32 = {k: v.float() for k, v in w.items()}
+    t32 = O.vit_forward(w32, ocfg, px.float())
+    tac = O.vit_forward_autocast_fp16(w, ocfg, px)
+    tb16 = O.vit_forward(w, ocfg, px)
+    fb, fh = mb.tower_features(px), mh.tower_features(px)
+    assert fh.dtype == torch.bfloat16 and torch.isfinite(fh.float()).all()
+    scale = t32.abs().max().item()
+    res = dict(scale=scale, bf16_tower_rms=_rms(fb, t32), fp16_tower_rms=_rms(fh, t32), autocast_oracle_rms=_rms(tac, t32), bf16_oracle_rms=_rms(tb16, t32),
+               bf16_tower_max=maxerr(fb, t32), fp16_tower_max=maxerr(fh, t32), autocast_oracle_max=maxerr(tac, t32))
+    # after projector + pooling (what the LLM sees)
+    e32 = O.visual_embed(w32, ocfg, px.float())
+    eb, eh = mb.visual_embed(px), mh.visual_embed(px)
+    res.update(embed_scale=e32.abs().max().item(), bf16_tower_embed_rms=_rms(eb, e32), fp16_tower_embed_rms=_rms(eh, e32),
+               autocast_oracle_embed_rms=_rms(O.visual_embed(w, ocfg, px, tower_autocast_fp16=True), e32))
+    # the fused uint8 -> patch-matrix entry point gives the same tower as preprocess + visual_embed, bit for bit
+    fr = torch.randint(0, 256, (3, 3, 336, 336), dtype=torch.uint8, generator=torch.Generator().manual_seed(5)).to(dev)
+    pv = mh.get_vision_tower().image_processor.preprocess(fr)['pixel_values']
+    assert torch.equal(mh.visual_embed_frames(fr), mh.visual_embed(pv))
+    _record('fp16_tower_4_layers', **res)
+    assert res['fp16_tower_rms'] <= 0.5 * res['bf16_tower_rms'], res
+    assert res['fp16_tower_rms'] <= 3 * res['autocast_oracle_rms'] + 1e-3 * scale, res
+    assert res['fp16_tower_embed_rms'] <= 0.6 * res['bf16_tower_embed_rms'], res
+    del mb, mh, w, w32
+    torch.cuda.empty_cache()
+
+
+def test_fp16_tower_full_depth_head_logit_delta():
+    """The same at FULL depth (26 tower + 28 decoder layers): head logits of prompt + 3 frames end to end against the fp32 oracle, bf16 tower vs fp16 tower (the
+    decoder is identical).  Recorded for DESIGN.md section 2; the fp16 tower's end-to-end delta must not exceed the bf16 tower's by more than 1e-2."""
+    dev = torch.device('cuda', 0)
+    g = torch.Generator(device=dev).manual_seed(11)
+    px = torch.randn(3, 3, 384, 384, generator=g, device=dev).to(torch.bfloat16)
+    ids = torch.randint(0, 152064, (1, 40), generator=g, device=dev)
+    out = {}
+    ref = None
+    for name, td in (('bf16_tower', None), ('fp16_tower', 'fp16')):
+        m, w, ocfg = _build(28, 26, torch.bfloat16, vocab=152064, max_vit_batch=4, max_step_tokens=512, tower_dtype=td)
+        if ref is None:
+            o32 = _oracle(w, ocfg, torch.float32)
+            v32 = o32.visual_embed(px.float())
+            x = torch.cat([o32.get_input_embeddings()(ids), v32[None]], 1)
+            r = o32(inputs_embeds=x)
+            rows = [40 + 49 * (j + 1) - 1 for j in range(3)]
+            ref = (v32, torch.cat([r.informative_logits[0, rows], r.relevance_logits[0, rows]], -1).float().cpu(), rows)
+            del o32, r, x
+        ve = m.visual_embed(px)
+        o = m(inputs_embeds=torch.cat([m.get_input_embeddings()(ids), ve[None]], 1))
+        lg = torch.cat([o.informative_logits[0, ref[2]], o.relevance_logits[0, ref[2]]], -1).float().cpu()
+        out[name] = dict(visual_embed_rms=_rms(ve, ref[0]), visual_embed_max=maxerr(ve, ref[0]), head_logit_max_delta=maxerr(lg, ref[1]), embed_scale=ref[0].abs().max().item())
+        del m, w, o
+        torch.cuda.empty_cache()
+    _record('fp16_tower_full_depth', **out)
+    assert out['fp16_tower']['visual_embed_rms'] <= out['bf16_tower']['visual_embed_rms'], out
+    assert out['fp16_tower']['head_logit_max_delta'] <= out['bf16_tower']['head_logit_max_delta'] + 1e-2, out
 
 
 # ---- multi-GPU: collectives --------------------------------------------------------------------------------------------------------
