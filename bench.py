@@ -95,6 +95,7 @@ def parse(argv=None):
     p.add_argument('--multi-frames-per-forward', type=int, default=13)
     p.add_argument('--weights', choices=['bf16', 'fp8'], default=None, help='fp8 = e4m3 per-output-channel scaled LLM weights (BASELINE configs[4]); reported with dtype fp8, never the bf16 headline')
     p.add_argument('--phase', choices=['ab', 'b'], default='ab', help="'b': Phase B alone -- the frame embeddings come from a feature file written before the timed region (mmduet_amd/features.py); LLM-only frames/s, never the headline")
+    p.add_argument('--tower-dtype', choices=['auto', 'bf16', 'fp16'], default='auto', help="vision tower arithmetic: fp16 = the reference's torch.cuda.amp.autocast() tower (models/modeling_live.py:28), bf16 = the model dtype; auto = the product default")
     p.add_argument('--layers', type=int, default=None, help='debug: override LLM layer count (INVALID as a measurement)')
     a = p.parse_args(argv)
     c = CONFIGS[a.config]
@@ -145,6 +146,8 @@ def build(args, device):
             cfg.num_hidden_layers = args.layers
     if args.weights == 'fp8':
         cfg.weight_dtype = 'fp8_e4m3'
+    if getattr(args, 'tower_dtype', 'auto') != 'auto':
+        cfg.tower_dtype = args.tower_dtype
     k = max(1, args.frames_per_forward)
     step_tokens = max(256, max(1, args.streams_per_gpu) * (k * cfg.frame_num_tokens + 192))
     if getattr(args, 'multi_stream', 0):
@@ -506,7 +509,7 @@ def main():
                        'max_new_tokens': args.max_new_tokens, 'response_frames': forced, 'llm_forwards_per_step': fwd // max(1, args.steps),
                        'kv_tokens_end': kv_end, 'weights': ('random init N(0,0.02), true shapes' if not args.tiny else 'tiny') + ('' if args.weights == 'bf16' else ', LLM matrices quantised to fp8 e4m3 per output channel'),
                        'parallelism': f'dp{world} ({S} stream(s) per GPU, one RCCL all-gather of the [{world},{S},{T}+1,2] score block per step, issued by libmmduet_hip (mmd_gather_block))',
-                       'native_gather_check': native, 'tower_overlap': not args.no_overlap, 'phase': 'A+B' if args.phase == 'ab' else 'B only (frame embeddings pre-extracted to a feature file; LLM side alone)', 'layers_override': args.layers},
+                       'native_gather_check': native, 'tower_overlap': not args.no_overlap, 'tower_dtype': getattr(model, 'tower_dtype', None), 'phase': 'A+B' if args.phase == 'ab' else 'B only (frame embeddings pre-extracted to a feature file; LLM side alone)', 'layers_override': args.layers},
             'verified': verified, 'roofline': roof, 'roofline_secondary': roof2, 'cpu_baseline': cpu, 'multi_stream': multi,
         }
         import ctypes

@@ -87,6 +87,7 @@ struct mmd_ctx {
     float dec_pen = 0.f; int64_t dec_eos = 0; bool no_graph = false;
     int last_plan[4] = {-1, 0, 0, 0};   // kernel / tiles / splits / blocks of the most recent gemm() (mmd_op_gemm_last_plan)
     bool no_fuse = false;              // MMDUET_NO_FUSE=1: keep the unfused launch schedule (A/B and parity cross-check)
+    bool gemm_half = false;            // the GEMMs issued right now belong to the fp16 vision tower (cfg.tower_f16): IEEE-half operands
     int tower_ring_flags = -1, tower_ring_blocks = 0;   // MMDUET_TOWER_RING / MMDUET_TOWER_RING_BLOCKS: ring GEMM form of the tower (co-residency experiments)
     bool no_chain = false;             // MMDUET_NO_CHAIN=1: decode steps keep the separate reduce+residual+RMSNorm launches (A/B)
     void* rope_tab = 0;                // (cos, sin) of a decode step's positions (launch_rope_table), read by the attention kernel's fused q/k/v preparation
@@ -173,7 +174,7 @@ static int gemm(mmd_ctx* c, const void* X, int64_t ldx, const void* W, int64_t l
     double e = (double)es(c);
     double bytes = (double)M * K * e + (double)N * K * ((Wp8 && M <= 64) ? 1.0 : e) + (double)M * (epi == EPI_SWIGLU ? N / 2 : N) * (out_f32 ? 4.0 : e);
     ProfScope ps(c, kind, bytes, 2.0 * M * N * K);
-    HIPCHK(c, launch_gemm(c->cfg.dtype, a, c->stream, nullptr));
+    HIPCHK(c, launch_gemm(c->gemm_half ? MMD_F16 : c->cfg.dtype, a, c->stream, nullptr));          // gemm_half: inside the fp16 vision tower (vit_tower sets it)
     return MMD_OK;
 }
 
@@ -564,6 +565,7 @@ static int vit_tower(mmd_ctx* c, const void* px, int B, bool col_ready = false) 
     // tower_f16: every tower tensor is IEEE half (the reference's autocast); pixel_values arrive in the model dtype (bf16) and become half in the im2col pass,
     // the tower's output is rounded to bf16 at the end (SigLipVisionTower returns hidden_states[-1].to(images.dtype) [3P-recalled])
     const int dt = g.tower_f16 ? MMD_F16 : g.dtype;
+    struct HalfScope { mmd_ctx* c; HalfScope(mmd_ctx* c_, bool on) : c(c_) { c->gemm_half = on; } ~HalfScope() { c->gemm_half = false; } } half_scope(c, g.tower_f16 != 0);
     if (B > g.max_vit_batch) FAIL(c, MMD_ERANGE, "vit batch %d exceeds max_vit_batch %d", B, g.max_vit_batch);
     const int C = g.vit_hidden, T = c->vit_tokens, TS = c->vit_seq, M = B * TS, hd = C / g.vit_heads;
     if (!col_ready) { ProfScope ps(c, MMD_K_OTHER, 0, 0); HIPCHK(c, launch_im2col(g.tower_f16 ? MMD_F16 + 1 : dt, px, B, g.vit_image, g.vit_patch, c->vit_grid, c->vit_kpad, c->v_col, st)); }

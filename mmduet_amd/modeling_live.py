@@ -242,12 +242,19 @@ class VideoHeadLiveLlavaQwenForCausalLM:
         if wd not in (None, 'bf16', 'model', 'fp8', 'fp8_e4m3'):
             raise ValueError(f'unknown weight_dtype {wd!r} (None | "fp8_e4m3")')
         c.weight_dtype = 1 if wd in ('fp8', 'fp8_e4m3') else 0
+        # The reference runs the tower under torch.cuda.amp.autocast() (models/modeling_live.py:28): IEEE-half matmuls, fp32 LayerNorm / softmax, whatever the model
+        # dtype.  tower_dtype: None / 'auto' = do the same wherever the half forms of the kernels exist for the tower's shape (bf16 model, the LLaVA SigLIP form,
+        # hidden % 64 == 0, head_dim % 8 == 0, >= 65 tokens per frame -- every real tower; measured free: 340 frames/s either way), else the model dtype;
+        # 'fp16' = require it; 'bf16' / 'model' = tower in the model dtype (the round-2 behaviour).
         td = getattr(config, 'tower_dtype', None)
-        if td not in (None, 'model', 'bf16', 'fp16', 'float16'):
-            raise ValueError(f'unknown tower_dtype {td!r} (None | "fp16")')
-        c.tower_f16 = 1 if td in ('fp16', 'float16') else 0          # the reference's autocast tower (models/modeling_live.py:28): IEEE-half tower, bf16 everywhere else
-        if c.tower_f16 and torch_dtype != torch.bfloat16:
-            raise ValueError('tower_dtype=fp16 needs torch_dtype=bfloat16')
+        if td not in (None, 'auto', 'model', 'bf16', 'fp16', 'float16'):
+            raise ValueError(f'unknown tower_dtype {td!r} (None | "auto" | "fp16" | "bf16")')
+        half_ok = (torch_dtype == torch.bfloat16 and config.vit_hidden_size % 64 == 0 and (config.vit_hidden_size // config.vit_num_attention_heads) % 8 == 0 and
+                   config.vit_grid ** 2 >= 65)
+        if td in ('fp16', 'float16') and not half_ok:
+            raise ValueError('tower_dtype=fp16 needs torch_dtype=bfloat16 and a tower with hidden % 64 == 0, head_dim % 8 == 0 and at least 65 tokens per frame')
+        c.tower_f16 = 1 if (td in ('fp16', 'float16') or (td in (None, 'auto') and half_ok)) else 0
+        self.tower_dtype = 'fp16' if c.tower_f16 else ('bf16' if torch_dtype == torch.bfloat16 else 'fp32')
         if c.weight_dtype and torch_dtype != torch.bfloat16:
             raise ValueError('weight_dtype=fp8_e4m3 needs torch_dtype=bfloat16 (fp8 weights x bf16 activations, fp32 accumulate)')
         self._cfg_struct = c

@@ -365,8 +365,9 @@ def test_fp16_tower_true_width_error_against_fp32():
     activations (v_mfma_f32_16x16x32_f16), fp32 LayerNorm / softmax statistics, bf16 features out.  True width, 4 tower layers, 8 frames, fused-preprocess and
     pixel_values entry points.  Measured: rms error of the tower output against the fp32 oracle for the bf16 tower, the fp16 tower and the oracle's restatement of the
     autocast path; the fp16 tower must cut the bf16 tower's error at least in half and stay within 3 x the autocast oracle's own error (+ 1e-3 x scale)."""
-    mb, w, ocfg = _build(1, 4, torch.bfloat16, max_vit_batch=8)
-    mh, _, _ = _build(1, 4, torch.bfloat16, max_vit_batch=8, tower_dtype='fp16')
+    mb, w, ocfg = _build(1, 4, torch.bfloat16, max_vit_batch=8, tower_dtype='bf16')
+    mh, _, _ = _build(1, 4, torch.bfloat16, max_vit_batch=8)          # the default: half wherever the kernels exist
+    assert mb.tower_dtype == 'bf16' and mh.tower_dtype == 'fp16'
     dev = mb.device
     g = torch.Generator(device=dev).manual_seed(21)
     px = torch.randn(8, 3, 384, 384, generator=g, device=dev).to(torch.bfloat16)
@@ -405,7 +406,7 @@ def test_fp16_tower_full_depth_head_logit_delta():
     ids = torch.randint(0, 152064, (1, 40), generator=g, device=dev)
     out = {}
     ref = None
-    for name, td in (('bf16_tower', None), ('fp16_tower', 'fp16')):
+    for name, td in (('bf16_tower', 'bf16'), ('fp16_tower', 'fp16')):
         m, w, ocfg = _build(28, 26, torch.bfloat16, vocab=152064, max_vit_batch=4, max_step_tokens=512, tower_dtype=td)
         if ref is None:
             o32 = _oracle(w, ocfg, torch.float32)
