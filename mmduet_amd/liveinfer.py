@@ -20,10 +20,10 @@ class LiveInferForDemo(LiveInferForBenchmark):
     def encode_given_query(self, query):
         with self._step_lock:
             self.last_ids = chat_ids(self.tokenizer, [{'role': 'user', 'content': query}],
-                                     add_stream_query_prompt=self.last_role == 'stream', add_stream_prompt=True).to(self.device)
+                                     add_stream_query_prompt=self.last_role == 'stream', add_stream_prompt=True)
             outputs = self.model(inputs_embeds=self._embed(self.last_ids), past_key_values=self.past_key_values, use_cache=True, return_dict=True)
             self.past_key_values = outputs.past_key_values
-            self.last_ids = outputs.logits[:, -1:].argmax(dim=-1)
+            self.last_ids = outputs.logits[:, -1:].argmax(dim=-1).cpu()          # (ids live on the host in this driver)
             self.last_role = 'user'
 
     def input_one_frame(self):

@@ -148,11 +148,15 @@ class _Embedding:
     def __init__(self, model):
         self._m = model
 
-    def __call__(self, ids):
+    def __call__(self, ids, out=None):
+        """`out` (optional): a contiguous [k, hidden] slice of a caller's buffer to gather into (the stream driver's step buffer: no concatenation kernel)."""
         m = self._m
         ids = ids.to(device=m.device, dtype=torch.long).contiguous()
-        out = torch.empty(*ids.shape, m.config.hidden_size, dtype=m.dtype, device=m.device)
         k = ids.numel()
+        if out is None:
+            out = torch.empty(*ids.shape, m.config.hidden_size, dtype=m.dtype, device=m.device)
+        elif out.shape != (k, m.config.hidden_size) or out.dtype != m.dtype or not out.is_contiguous():
+            raise ValueError('embedding `out` must be a contiguous [k, hidden] tensor of the model dtype')
         if k:
             with m._lock:
                 m._bind_stream()

@@ -204,3 +204,65 @@ def test_youcook2_style_stream_on_fp8_weights(models):
     if t8 != to_:                                                                                # only a borderline running sum may move a response by a frame
         assert abs(len(t8) - len(to_)) <= 1
     assert len(t8) >= 1
+
+
+def test_fp8_model_at_7b_width_chunk_and_decode_rows():
+    """the fp8 build at the TRUE decoder width (hidden 3584, 28 / 4 heads of 128, intermediate 18 944; 2 layers, vocab 2048): a 26-frame
+    chunk (M = 1274 + prefix: bf16(q) tile kernels with the scale in the epilogue), per-frame steps (fp8-streaming skinny kernel) and single decode rows (fp8 GEMV,
+    decode chain, fused attention prologue) against the oracle on the DEQUANTISED weights in fp32 -- and the three regimes against each other.
+    tolerance: 6e-2 on O(1) head logits / 8e-2 on lm logits (the bf16 bound of the unquantised build at 2 layers, tests/test_gpu_production.py)."""
+    from mmduet_amd.configuration_live import VideoHeadLiveLlavaQwenConfig
+    from mmduet_amd.modeling_live import VideoHeadLiveLlavaQwenForCausalLM
+    from mmduet_amd.weights import synthetic_weights
+    pcfg = VideoHeadLiveLlavaQwenConfig(vocab_size=2048, num_hidden_layers=2, vit_num_hidden_layers=2, vit_layers_removed=1, frame_num_tokens=49, frame_resolution=384, v_placeholder='<image>')
+    pcfg.weight_dtype = 'fp8_e4m3'
+    ocfg = O.OracleConfig(vocab_size=2048, num_hidden_layers=2, vit_layers=1)
+    m = VideoHeadLiveLlavaQwenForCausalLM(pcfg, torch_dtype=torch.bfloat16, max_vit_batch=2, max_step_tokens=1536, kv_initial_tokens=4096)
+    w = {}
+    for name, t in synthetic_weights(pcfg, seed=3, device=m.device, dtype=torch.bfloat16, scale='unit'):
+        m.load_tensor(name, t); w[name] = t
+    m.finalize()
+    wd = {}
+    for k, v in w.items():
+        if k.startswith('model.layers.') and k.endswith('.weight') and any(f'.{l}.' in k for l in LIN):
+            q, sc = quantize_ref(v)
+            wd[k] = q.float() * sc[:, None]
+        else:
+            wd[k] = v.float()
+    o32 = O.OracleModel(ocfg, wd)
+    dev = m.device
+    g = torch.Generator(device=dev).manual_seed(2)
+    prompt = (torch.randn(1, 29, 3584, generator=g, device=dev) * 0.5).to(torch.bfloat16)
+    frames = [(torch.randn(49, 3584, generator=g, device=dev) * 0.5).to(torch.bfloat16) for _ in range(26)]
+    rows = [49 * (j + 1) - 1 for j in range(26)]
+    base = m(inputs_embeds=prompt).past_key_values
+    chunk, c_chunk = m.frame_step(torch.cat(frames)[None], m.cache_prefix(base, len(base)), rows)
+    per, cache = [], m.cache_prefix(base, len(base))
+    for f in frames:
+        sc, cache = m.frame_step(f[None], cache, [48]); per.append(sc[0])
+    per = torch.stack(per)
+    oc = o32(inputs_embeds=prompt.float()).past_key_values
+    ref = o32(inputs_embeds=torch.cat(frames)[None].float(), past_key_values=oc)
+    want = torch.cat([ref.informative_logits[0, rows], ref.relevance_logits[0, rows]], -1).cpu()
+    e_chunk, e_per, e_cp = (chunk - want).abs().max().item(), (per - want).abs().max().item(), (chunk - per).abs().max().item()
+    # decode rows: 6 single-token steps from the chunk's context, lm logits of each
+    toks = [(torch.randn(1, 1, 3584, generator=g, device=dev) * 0.5).to(torch.bfloat16) for _ in range(6)]
+    hc, ocache, e_dec, e_lm = c_chunk, ref.past_key_values, 0.0, 0.0
+    for t in toks:
+        out = m(inputs_embeds=t, past_key_values=hc); hc = out.past_key_values
+        r = o32(inputs_embeds=t.float(), past_key_values=ocache); ocache = r.past_key_values
+        e_dec = max(e_dec, (torch.cat([out.informative_logits[0, -1], out.relevance_logits[0, -1]]).cpu() - torch.cat([r.informative_logits[0, -1], r.relevance_logits[0, -1]]).cpu()).abs().max().item())
+        e_lm = max(e_lm, (out.logits[0, -1].float().cpu() - r.logits[0, -1].cpu()).abs().max().item())
+    assert len(hc) == 29 + 26 * 49 + 6
+    try:
+        import json, os
+        from conftest import ROOT
+        path = os.path.join(ROOT, 'gpurun_out', 'parity_r03.json')
+        cur = json.load(open(path)) if os.path.exists(path) else {}
+        cur['fp8_true_width_2_layers'] = dict(chunk_vs_fp32=e_chunk, per_frame_vs_fp32=e_per, chunk_vs_per_frame=e_cp, decode_rows_head_vs_fp32=e_dec, decode_rows_lm_vs_fp32=e_lm,
+                                              lm_scale=r.logits.abs().max().item())
+        json.dump(cur, open(path, 'w'), indent=1, sort_keys=True)
+    except Exception:
+        pass
+    assert e_chunk < 6e-2 and e_per < 6e-2 and e_cp < 6e-2 and e_dec < 6e-2, (e_chunk, e_per, e_cp, e_dec)
+    assert e_lm < 8e-2 * max(1.0, r.logits.abs().max().item()), e_lm
