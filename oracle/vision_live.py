@@ -20,7 +20,7 @@ OPENAI_CLIP_STD = [0.26862954, 0.26130258, 0.27577711]
 def normalize(frames, mean, std, rescale_factor=0.00392156862745098):
     """torchvision.transforms.functional.normalize(frames * rescale_factor, mean, std) -- models/vision_live.py:13,36"""
     x = frames * rescale_factor
-    mean = torch.as_tensor(mean, dtype=x.dtype).view(-1, 1, 1); std = torch.as_tensor(std, dtype=x.dtype).view(-1, 1, 1)
+    mean = torch.as_tensor(mean, dtype=x.dtype, device=x.device).view(-1, 1, 1); std = torch.as_tensor(std, dtype=x.dtype, device=x.device).view(-1, 1, 1)
     return (x - mean) / std
 
 

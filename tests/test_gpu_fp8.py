@@ -236,11 +236,11 @@ def test_fp8_model_at_7b_width_chunk_and_decode_rows():
     frames = [(torch.randn(49, 3584, generator=g, device=dev) * 0.5).to(torch.bfloat16) for _ in range(26)]
     rows = [49 * (j + 1) - 1 for j in range(26)]
     base = m(inputs_embeds=prompt).past_key_values
-    chunk, c_chunk = m.frame_step(torch.cat(frames)[None], m.cache_prefix(base, len(base)), rows)
     per, cache = [], m.cache_prefix(base, len(base))
     for f in frames:
         sc, cache = m.frame_step(f[None], cache, [48]); per.append(sc[0])
     per = torch.stack(per)
+    chunk, c_chunk = m.frame_step(torch.cat(frames)[None], m.cache_prefix(base, len(base)), rows)          # (same arena: rolls back to the prompt, then the 26 frames in one forward)
     oc = o32(inputs_embeds=prompt.float()).past_key_values
     ref = o32(inputs_embeds=torch.cat(frames)[None].float(), past_key_values=oc)
     want = torch.cat([ref.informative_logits[0, rows], ref.relevance_logits[0, rows]], -1).cpu()
