@@ -34,7 +34,7 @@ CONFIGS = {
     # name: (frames, responses, frames_per_forward, streams_per_gpu, workload text)
     'stream300': dict(frames=300, responses=4, k=26, streams=1, mode='response',
                       text='query at t=0, greedy per-frame response decision'),
-    'ground600': dict(frames=600, responses=0, k=26, streams=1, mode='grounding',
+    'ground600': dict(frames=600, responses=0, k=39, streams=1, mode='grounding',          # k re-swept for grounding mode in round 3 (profiles/r03_k_sweep_*.json): 39 > 26 by 1.6 %, flat beyond
                       text='grounding mode (threshold 1: scores only, no generation), KV grows to 29.4 k tokens'),
     'qvh': dict(frames=150, responses=0, k=30, streams=1, mode='grounding',
                 text='QVHighlights-style 150-frame grounding streams, scores all-gathered over RCCL'),
@@ -42,6 +42,11 @@ CONFIGS = {
     # ~5-10 min cooking videos), fp8 e4m3 weights.  Responses are pinned to 12 seeded frames (a YouCook2 video has ~8 annotated steps).
     'youcook2': dict(frames=600, responses=12, k=26, streams=1, mode='response', remove=True, weights='fp8',
                      text='YouCook2-style dense captioning: running-sum decision rule, assistant turns removed from the context, fp8 e4m3 LLM weights'),
+    # SURVEY.md section 8(d) "native-336 variant": the secondary encoder of models/vision_live.py:61 at its real shape (CLIP-L/14-336: 24 layers, width 1024, 577 tokens),
+    # 336-px frames with no resize, pooled to 6x6 (+CLS) tokens -- the offline feature-extraction path (data/utils.py:99-117).  Vision side only; reported separately,
+    # never mixed with the 384 path
+    'native336': dict(frames=300, responses=0, k=1, streams=1, mode='vision',
+                      text='CLIP-L/14-336 secondary encoder (models/vision_live.py:34-64), native 336-px frames, adaptive pooling to 6x6 + CLS tokens; vision encode only (feature extraction)'),
 }
 
 
@@ -297,8 +302,69 @@ def cpu_baseline():
     return out
 
 
+def bench_native336(args):
+    """--config native336: frames/s of the CLIP-L/14-336 encoder (LiveVisionEncoder) over a 300-frame 336-px stream in batches of 32, random-init weights at the true shape."""
+    import ctypes as C
+    from mmduet_amd.vision_live import LiveVisionEncoder, KNOWN
+    from mmduet_amd import _lib
+    device = torch.device('cuda', 0)
+    torch.cuda.set_device(device)
+    kind, vc = KNOWN['openai/clip-vit-large-patch14-336']
+    Cw, CI, P, L = vc['hidden_size'], vc['intermediate_size'], vc['patch_size'], vc['num_hidden_layers']
+    n_tok = (vc['image_size'] // P) ** 2 + 1
+    g = torch.Generator(device=device).manual_seed(0)
+    rn = lambda *sh: (torch.randn(*sh, generator=g, device=device) * 0.02).to(torch.bfloat16)
+    sd = {'embeddings.patch_embedding.weight': rn(Cw, 3, P, P), 'embeddings.position_embedding.weight': rn(n_tok, Cw), 'embeddings.class_embedding': rn(Cw),
+          'pre_layrnorm.weight': torch.ones(Cw, device=device, dtype=torch.bfloat16), 'pre_layrnorm.bias': torch.zeros(Cw, device=device, dtype=torch.bfloat16)}
+    for i in range(L):
+        p = f'encoder.layers.{i}.'
+        for ln in ('layer_norm1', 'layer_norm2'):
+            sd[p + ln + '.weight'] = torch.ones(Cw, device=device, dtype=torch.bfloat16); sd[p + ln + '.bias'] = torch.zeros(Cw, device=device, dtype=torch.bfloat16)
+        for lin in ('q_proj', 'k_proj', 'v_proj', 'out_proj'):
+            sd[p + f'self_attn.{lin}.weight'] = rn(Cw, Cw); sd[p + f'self_attn.{lin}.bias'] = torch.zeros(Cw, device=device, dtype=torch.bfloat16)
+        sd[p + 'mlp.fc1.weight'] = rn(CI, Cw); sd[p + 'mlp.fc1.bias'] = torch.zeros(CI, device=device, dtype=torch.bfloat16)
+        sd[p + 'mlp.fc2.weight'] = rn(Cw, CI); sd[p + 'mlp.fc2.bias'] = torch.zeros(Cw, device=device, dtype=torch.bfloat16)
+    enc = LiveVisionEncoder.from_state_dict(kind, vc, sd, torch_dtype=torch.bfloat16, frame_token_cls=True, frame_token_pooled=(6, 6), max_batch=32)
+    frames = torch.randint(0, 256, (args.frames, 3, 336, 336), dtype=torch.uint8, generator=torch.Generator().manual_seed(1)).to(device)
+    L_ = _lib.lib()
+    n = len(_lib.K_NAMES)
+
+    def prof(on):
+        if on:
+            _lib.check(L_.mmd_prof_reset(enc._ctx), enc._ctx); _lib.check(L_.mmd_prof_set_stride(enc._ctx, 1), enc._ctx)
+        _lib.check(L_.mmd_prof_enable(enc._ctx, (1 << n) - 1 if on else 0), enc._ctx)
+
+    for _ in range(max(1, args.warmup)):
+        out = enc(frames)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = enc(frames)
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    assert out.shape == (args.frames, 37, Cw) and bool(torch.isfinite(out.float()).all())
+    prof(True); enc(frames); torch.cuda.synchronize(device); prof(False)
+    ms, cnt, by, fl = (C.c_double * n)(), (C.c_int64 * n)(), (C.c_double * n)(), (C.c_double * n)()
+    _lib.check(L_.mmd_prof_read(enc._ctx, ms, cnt, by, fl), enc._ctx)
+    i = _lib.K_NAMES.index('gemm_tile')
+    ach = fl[i] / max(1, cnt[i]) / (ms[i] / max(1, cnt[i]) * 1e-3) / 1e12
+    roof = dict(bound='mfma', kernel='gemm_tile', achieved=round(ach, 2), peak=MFMA_BF16_PEAK_TF, unit='TFLOP/s', frac=round(ach / MFMA_BF16_PEAK_TF, 4), traffic=None,
+                avg_launch_us=round(ms[i] / max(1, cnt[i]) * 1e3, 2), launches_timed=int(cnt[i]), per_class_ms_untimed_pass={k: round(ms[j], 1) for j, k in enumerate(_lib.K_NAMES)},
+                source='one more pass of the same workload, every launch bracketed with HIP events (untimed)')
+    gf = 2 * 577 * (4 * Cw * Cw + 2 * Cw * CI) * L + 2 * 576 * 588 * Cw + 4 * 577 * 577 * Cw * L          # per frame: encoder GEMMs + patch embed + attention
+    line = {'metric': 'video frames/sec (vision encode only, native 336 px, CLIP-L/14-336 secondary encoder)', 'value': round(args.steps * args.frames / dt, 2), 'unit': 'frames/s',
+            'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 2), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': f'{args.frames}-frame 336px stream, ' + CONFIGS['native336']['text'], 'name': 'native336', 'tower_batch': 32, 'tokens_per_frame_out': 37,
+                       'algorithmic_gflop_per_frame': round(gf / 1e9, 1), 'weights': 'random init N(0,0.02), true shape (24 layers)', 'note': 'a separate configuration: never mixed with the 384-px LLaVA path'},
+            'roofline': roof, 'cpu_baseline': None}
+    print(json.dumps(line), flush=True)
+
+
 def main():
     args = parse()
+    if args.mode == 'vision':
+        return bench_native336(args)
     launch_ranks_if_needed(args)
     torch.set_num_threads(max(1, effective_cpus() // max(1, int(os.environ.get('WORLD_SIZE', '1')))))   # host-side torch ops (and the CPU baseline) use the cores this process really has
     from mmduet_amd.distributed import init_distributed, gather_scores, NativeScoreGather
