@@ -82,7 +82,7 @@ def _build_product(weights, frames):
     cfg = VideoHeadLiveLlavaQwenConfig(frame_num_tokens=49, frame_resolution=384, v_placeholder='<image>')
     if weights == 'fp8':
         cfg.weight_dtype = 'fp8_e4m3'
-    model = VideoHeadLiveLlavaQwenForCausalLM(cfg, torch_dtype=torch.bfloat16, device=dev, max_vit_batch=35, max_step_tokens=26 * 49 + 192,
+    model = VideoHeadLiveLlavaQwenForCausalLM(cfg, torch_dtype=torch.bfloat16, device=dev, max_vit_batch=35, max_step_tokens=39 * 49 + 192,
                                               kv_initial_tokens=frames * 49 + 4096)
     tok = build_live_tokenizer_and_update_config('synthetic:bench', cfg)
     w = {}
