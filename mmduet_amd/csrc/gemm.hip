@@ -1058,6 +1058,15 @@ static hipError_t launch_t(const GemmArgs& a, hipStream_t st, int* kind_out) {
             }
         }
 #ifdef MMDUET_DEBUG_VARIANTS          // timing experiments of tools/bench_gemm.py (most give WRONG results): `make DEBUG_VARIANTS=1`; never in the shipped library
+        if (variant == 92) {          // DBG 8 on the 4-slot ring
+            if (!big_packed_ok(MMD_BF16, a, 16) || (a.N % 32) != 0) return hipErrorInvalidValue; p.W = a.Wp;
+            const int tiles = cdiv(a.N, 256) * cdiv(a.M, 256);
+            const size_t smem = 4 * (256 * 32 + 256 * 32) * sizeof(bf16_t);
+            hipFuncSetAttribute((const void*)gemm_ringx_kernel<EPI_NONE, 4, false, 4, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            hipLaunchKernelGGL((gemm_ringx_kernel<EPI_NONE, 4, false, 4, true, 8>), dim3(tiles <= 256 ? tiles : 256), dim3(512), smem, st, p, a.K >> 5);
+            set_plan(a, GEMM_K_RING256, tiles, 1, tiles <= 256 ? tiles : 256);
+            return hipGetLastError();
+        }
         if (variant == 93) { if (!big_packed_ok(MMD_BF16, a, 16) || (a.N % 32) != 0) return hipErrorInvalidValue; p.W = a.Wp; return launch_ringx_dbg<7>(p, a, st); }
         if (variant == 94) { if (!big_packed_ok(MMD_BF16, a, 16) || (a.N % 32) != 0) return hipErrorInvalidValue; p.W = a.Wp; return launch_ringx_dbg<6>(p, a, st); }
         if (variant == 95) { if (!big_packed_ok(MMD_BF16, a, 16) || (a.N % 32) != 0) return hipErrorInvalidValue; p.W = a.Wp; return launch_ringx_dbg<5>(p, a, st); }

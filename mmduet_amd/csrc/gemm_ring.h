@@ -262,7 +262,7 @@ __global__ __launch_bounds__(WN * 128, 2) void gemm_ringx_kernel(GemmP p, int KT
             else if (STEADY || s + NS - 1 < nsteps) RINGX_WAIT((NS - 2) * NDMA);
             else if (NS == 4 && s + 2 < nsteps) RINGX_WAIT(NDMA);
             else RINGX_WAIT(0);
-            MMD_BAR();
+            if (!(DBG == 8 && (s & 1))) MMD_BAR();          // DBG 8 (timing only, RACY): the barrier of every other slice left out -- what would a barrier per TWO slices buy?
             const bool refill = STEADY || s + NS < nsteps;
             const bool more = STEADY || s + 1 < nsteps;
             const bf16_t* nbase = lds + (slot == NS - 1 ? 0 : slot + 1) * SE;

@@ -72,7 +72,7 @@ if __name__ == '__main__':
     if which == 'ab':
         # interleaved A/B (guide rule 24): python tools/bench_gemm.py ab <variant,variant,...> [rounds] [out.json]; every round runs every variant on the same operands
         import statistics
-        names = {0: 'auto', 4: 'big', 32: 'rx-8w-early', 33: 'rx-4w-early', 93: 'rx-fine', 99: 'DBG-no-epilogue', 98: 'DBG-no-dma', 7: 'ring-splitK', 48: 'rx-8w-early-splitK'}
+        names = {0: 'auto', 4: 'big', 32: 'rx-8w-early', 33: 'rx-4w-early', 40: 'rx-8w-ns4-early', 92: 'DBG-ns4-half-barriers', 93: 'rx-fine', 99: 'DBG-no-epilogue', 98: 'DBG-no-dma', 7: 'ring-splitK', 48: 'rx-8w-early-splitK'}
         vs = [int(v) for v in sys.argv[2].split(',')]
         rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 7
         shapes = [(25515, 'vit_qkv', 3456, 1152, 'none'), (25515, 'vit_o_none', 1152, 1152, 'none'), (25515, 'proj2', 3584, 3584, 'none'), (1274, 'gate_up_none', 37888, 3584, 'none'),
