@@ -28,7 +28,7 @@ import torch
 
 HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_BF16_PEAK_TF = 2500.0      # dense bf16 MFMA peak
-PMC_TRAFFIC = ('profiles/r02_pmc_traffic.json', 'profiles/r01_pmc_traffic.json')      # newest first
+PMC_TRAFFIC = ('profiles/r03_pmc_traffic.json', 'profiles/r02_pmc_traffic.json', 'profiles/r01_pmc_traffic.json')      # newest first
 
 CONFIGS = {
     # name: (frames, responses, frames_per_forward, streams_per_gpu, workload text)

@@ -16,11 +16,18 @@ $B --config ground600 --steps 2 --warmup 1 --multi-stream 0 --no-cpu-baseline > 
 for s in 1 2 4 8; do
   $B --config qvh --streams-per-gpu $s --steps 2 --warmup 1 --multi-stream 0 --no-cpu-baseline > $O/${tag}_bench_qvh_s$s.json 2>> $O/${tag}_bench.err
 done
+$B --config youcook2 --steps 2 --warmup 1 --multi-stream 0 --no-cpu-baseline > $O/${tag}_bench_youcook2_fp8.json 2>> $O/${tag}_bench.err
+$B --config youcook2 --weights bf16 --steps 2 --warmup 1 --multi-stream 0 --no-cpu-baseline > $O/${tag}_bench_youcook2_bf16ref.json 2>> $O/${tag}_bench.err
+$B --weights fp8 --steps 3 --warmup 1 --multi-stream 0 --no-cpu-baseline > $O/${tag}_bench_stream300_fp8.json 2>> $O/${tag}_bench.err
+$B --phase b --steps 3 --warmup 1 --multi-stream 0 --no-cpu-baseline > $O/${tag}_bench_phase_b.json 2>> $O/${tag}_bench.err
+$B --tower-dtype bf16 --steps 3 --warmup 1 --multi-stream 0 --no-cpu-baseline > $O/${tag}_bench_tower_bf16.json 2>> $O/${tag}_bench.err
+$B --config native336 --steps 3 > $O/${tag}_bench_native336.json 2>> $O/${tag}_bench.err
 P="python3 $R/bench.py --steps 1 --warmup 0 --no-prof --no-overlap --multi-stream 0 --no-cpu-baseline"
 rm -rf $O/prof_$tag
 rocprofv3 --kernel-trace -d $O/prof_$tag -o trace -- $P > $O/${tag}_prof.log 2>&1
 db=$(ls $O/prof_$tag/*.db 2>/dev/null | head -1)
 [ -n "$db" ] && python3 $R/tools/rocpd_stats.py $db 45 > $O/${tag}_rocprofv3_kernel_stats.txt
+[ -n "$db" ] && python3 $R/tools/rocpd_window.py $db > $O/${tag}_stream_window_kernels.txt
 rm -rf $O/prof_$tag
 for pass in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
   t=$(echo $pass | cut -d' ' -f1)
