@@ -895,6 +895,12 @@ static void launch_big(const GemmP& p, const GemmArgs& a, hipStream_t st) {
     int splits = 1;
     if (tiles < 320 && a.K >= 8192 && a.epi != EPI_SWIGLU && a.splitk_ws && !a.f16) {      // long K, under one block per CU (down_proj): split K
         splits = 3;                                                                // (measured: splitting K = 3584 GEMMs costs more than it fills)
+        if (tiles <= 64) splits = 4;
+        while (splits > 1 && (size_t)splits * a.M * a.N * sizeof(float) > a.splitk_ws_bytes) --splits;
+    } else if (tiles < 128 && a.K >= 2048 && a.epi != EPI_SWIGLU && a.splitk_ws && !a.f16) {
+        // a handful of rows (65 <= M <= ~256: a few frames per forward, several streams' decode rows): 56-72 tiles cannot pull the weights out of HBM (a CU streams ~25 GB/s);
+        // split K so that ~one block per CU streams.  round 3, 15 k context: an M = 98 step 8.5 -> see profiles/r03_decode_experiments.md
+        splits = 256 / tiles; if (splits > 4) splits = 4; if (splits < 1) splits = 1;
         while (splits > 1 && (size_t)splits * a.M * a.N * sizeof(float) > a.splitk_ws_bytes) --splits;
     }
     dim3 grid(a.N / BN, cdiv(a.M, 128), splits);
