@@ -283,10 +283,14 @@ __global__ void attn_combine_kernel(AttnP p, int nrows_total_all) {
 //   * masking work only on tiles that cross the causal diagonal / the end of the key range.
 //   * long contexts: grid.z splits the keys (flash-decoding); attn_combine128_kernel merges the fp32 partials.
 // ------------------------------------------------------------------------------------------------------------------
-template <int RT>
-__global__ __launch_bounds__(256, 2) void attn_gqa128_kernel(AttnP p) {
+//   * NSLOT = 4 (decode: one query block per kv head, <= 256 blocks, ONE per CU): a four-slot ring in 128 KB of LDS, three tiles in flight beyond the one being
+//     consumed, counted vmcnt per tile, nt policy on the K / V stream (every byte is read once by one CU).  A 4-tile split at 15 k keys then pays ONE load
+//     latency instead of four; the q prologue (slab sum + RoPE) loads are issued before the DMAs and finished under them.
+template <int RT, int NSLOT = 2>
+__global__ __launch_bounds__(256, NSLOT == 2 ? 2 : 1) void attn_gqa128_kernel(AttnP p) {
     constexpr int D = 128, KT = 64, TILE = KT * D;              // one K tile = one V^T tile = 8192 elements = 16 KB, contiguous in the arena
-    __shared__ __attribute__((aligned(16))) bf16_t kv[2 * 2 * TILE];   // two slots of (K tile, V^T tile): 64 KB
+    constexpr int PF = NSLOT - 1;                                // tiles in flight beyond the one being consumed
+    extern __shared__ __attribute__((aligned(16))) bf16_t kv[];        // NSLOT slots of (K tile, V^T tile): 64 / 128 KB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4;
     int bx, by, bz; xcd_block_id(bx, by, bz);
@@ -351,13 +355,14 @@ __global__ __launch_bounds__(256, 2) void attn_gqa128_kernel(AttnP p) {
             const int pc = wave + 4 * j;
             const int key = pc * 4 + (lane >> 4);
             const bf16_t* src = Kg + (k0 + key) * p.k_ts + (((lane & 15) ^ ((((key >> 3) & 3) << 2) | (key & 3))) * 8);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(ks + pc * 512), 16, 0, 0);
             const int dim = pc * 8 + (lane >> 3);
             const bf16_t* vsrc = Vg + ((blk * D + dim) << 6) + (((lane & 7) ^ ((dim >> 1) & 7)) * 8);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(ks + pc * 512), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)vsrc, (__attribute__((address_space(3))) void*)(vt + pc * 512), 16, 0, 0);
         }
     };
     const int vsw = (lr >> 1) & 7;
+    const int ntile = kbeg < kend ? (int)((kend - kbeg + KT - 1) >> 6) : 0;
 
     if (RT == 1 && p.slabs) {
         // the new tokens' K rows / V columns: written by the block (query block 0 of this kv head) whose key range holds the position, BEFORE it stages
@@ -369,7 +374,7 @@ __global__ __launch_bounds__(256, 2) void attn_gqa128_kernel(AttnP p) {
             for (int tok = 0; tok < p.S; ++tok) {
                 const long long pos = n_ctx + tok;
                 if (pos < kbeg || pos >= kbeg + kv_per_split) continue;
-                in_first_tile |= pos < kbeg + KT;
+                in_first_tile |= pos < kbeg + (long long)PF * KT;               // ... the tiles staged before the loop
                 const bf16_t* bias = (const bf16_t*)p.qkv_bias;
                 if (tid < 64) {                       // k: pair (i, i + 64)
                     const int i = tid, col = (p.nh + kvh) * D;
@@ -397,7 +402,44 @@ __global__ __launch_bounds__(256, 2) void attn_gqa128_kernel(AttnP p) {
             if (in_first_tile) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }       // block-uniform
         }
     }
-    if (kbeg < kend) stage(0, kbeg);
+    // NSLOT == 4 (decode, <= 16 rows: wave 0 is the only one with rows): waves 1-3 are LOADERS -- they stage every tile (32 pieces dealt 11 / 11 / 10) and own the
+    // counted waits; wave 0 issues no DMA at all, so the compiler's vmcnt(0) in front of its q prologue (slab sum + RoPE) covers the q loads only and the
+    // prologue runs under the ring's first three tiles.  (A plain VGPR load next to LDS-DMAs in ONE wave always gets vmcnt(0) from hipcc.)
+    const int ldr = wave - 1;
+    auto stage3 = [&](int slot, long long k0) {
+        bf16_t* ks = kv + slot * 2 * TILE;
+        bf16_t* vt = ks + TILE;
+        const long long blk = k0 >> 6;
+#pragma unroll
+        for (int j = 0; j < 11; ++j) {
+            const int pp = ldr + 3 * j;
+            if (pp < 16) {
+                const int key = pp * 4 + (lane >> 4);
+                const bf16_t* src = Kg + (k0 + key) * p.k_ts + (((lane & 15) ^ ((((key >> 3) & 3) << 2) | (key & 3))) * 8);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(ks + pp * 512), 16, 0, 2);
+            } else if (pp < 32) {
+                const int pc = pp - 16, dim = pc * 8 + (lane >> 3);
+                const bf16_t* vsrc = Vg + ((blk * D + dim) << 6) + (((lane & 7) ^ ((dim >> 1) & 7)) * 8);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)vsrc, (__attribute__((address_space(3))) void*)(vt + pc * 512), 16, 0, 2);
+            }
+        }
+    };
+    if constexpr (NSLOT == 4) {
+        if (wave != 0) {               // the loaders' whole life: one raw barrier per tile, matched by wave 0's below
+#pragma unroll
+            for (int t = 0; t < PF; ++t) if (t < ntile) stage3(t, kbeg + (long long)t * KT);
+            for (int ti = 0; ti < ntile; ++ti) {
+                // tile ti has landed once at most the younger tiles' DMAs (11 per tile from this wave, the third loader 10) are outstanding
+                const int younger = min(PF - 1, ntile - 1 - ti);
+                if (younger >= 2) { if (ldr < 2) asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); }
+                else if (younger == 1) { if (ldr < 2) asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (ti + PF < ntile) stage3((ti + PF) & (NSLOT - 1), kbeg + (long long)(ti + PF) * KT);       // the slot tile ti - 1 left: wave 0 is past it
+            }
+            return;
+        }
+    } else if (kbeg < kend) stage(0, kbeg);
     // q fragments AFTER the first tile's DMAs are in flight (their latency covers the q loads / the slab reduction + RoPE)
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
@@ -439,11 +481,16 @@ __global__ __launch_bounds__(256, 2) void attn_gqa128_kernel(AttnP p) {
             }
         }
     }
-    int slot = 0;
-    for (long long k0 = kbeg; k0 < kend; k0 += KT, slot ^= 1) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (k0 + KT < kend) stage(slot ^ 1, k0 + KT);
+    int slot = 0, ti = 0;
+    for (long long k0 = kbeg; k0 < kend; k0 += KT, slot = (slot + 1) & (NSLOT - 1), ++ti) {
+            if constexpr (NSLOT == 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (k0 + KT < kend) stage(slot ^ 1, k0 + KT);
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (wave 0 only: its reads of the previous tile are done before the loaders may refill that slot)
+            __builtin_amdgcn_s_barrier();
+        }
         const bf16_t* Ks = kv + slot * 2 * TILE;
         const bf16_t* Vt = Ks + TILE;
         if (!wave_active) continue;
@@ -658,7 +705,19 @@ static hipError_t launch_gqa128(AttnP& p, const AttnArgs& a, hipStream_t st) {
     const int nrows_all = a.nkv * rows_total;
     p.ws_o = a.ws;
     p.ws_ml = a.ws ? a.ws + (size_t)splits * nrows_all * 128 : nullptr;
-    hipLaunchKernelGGL((attn_gqa128_kernel<RT>), dim3(qblocks, a.nkv, splits), dim3(256), 0, st, p);
+    // decode geometry (one query block per kv head, at most one block per CU): the four-slot ring; MMDUET_ATTN_DECODE_RING=0 keeps the two-slot form (A/B switch)
+    static const bool ring_off = getenv("MMDUET_ATTN_DECODE_RING") && atoi(getenv("MMDUET_ATTN_DECODE_RING")) == 0;
+    if (RT == 1 && qblocks == 1 && a.nkv * splits <= 256 && rows_total <= 16 && !ring_off) {
+        static bool attr_set[64] = {};
+        int dev = 0; hipGetDevice(&dev);
+        if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+            hipError_t e = hipFuncSetAttribute((const void*)attn_gqa128_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
+            if (e != hipSuccess) return e;
+            attr_set[dev] = true;
+        }
+        hipLaunchKernelGGL((attn_gqa128_kernel<1, 4>), dim3(qblocks, a.nkv, splits), dim3(256), 4 * 32768, st, p);
+    } else
+        hipLaunchKernelGGL((attn_gqa128_kernel<RT>), dim3(qblocks, a.nkv, splits), dim3(256), 2 * 32768, st, p);
     if (splits > 1) {
         if (nrows_all <= 64 && splits <= 64) hipLaunchKernelGGL(attn_combine128_rows_kernel, dim3(nrows_all), dim3(256), 0, st, p, nrows_all);
         else hipLaunchKernelGGL(attn_combine128_kernel, dim3(cdiv(nrows_all, 4)), dim3(256), 0, st, p, nrows_all);

@@ -1015,6 +1015,9 @@ static hipError_t launch_ringx(int flags, const GemmP& p, const GemmArgs& a, hip
 
 // the ring GEMM addresses its operands as uniform base + 32-bit byte offset
 static bool ring_size_ok(const GemmArgs& a) { return (long long)a.M * a.ldx * 2 < (1ll << 32) && (long long)a.N * a.K * 2 < (1ll << 32); }
+// enough 256^2 tiles for the persistent ring: >= 400 (1.6 block waves of the 256 CUs), or close to whole waves from 0.75 of one up (4096^2: 256 tiles = one
+// wave, 1.36 PF against 0.94 for the 128-row kernel; 300 tiles would leave the second wave at 17 % and stay with the 128-row kernel)
+static bool ring_tiles_ok(long long t) { return t >= 400 || (t >= 192 && (double)t / (double)(cdiv((int)t, 256) * 256) >= 0.9); }
 static bool big_packed_ok(int dtype, const GemmArgs& a, int BN) {
     return dtype == MMD_BF16 && a.Wp != nullptr && a.M > 64 && (a.N % BN) == 0 && (a.K % 64) == 0 && (a.ldx % 8) == 0 &&
            ((uintptr_t)a.X % 16) == 0 && !a.out_f32 && (a.ldy % 4) == 0 && ((uintptr_t)a.Y % 8) == 0 &&
@@ -1042,7 +1045,7 @@ static hipError_t launch_t(const GemmArgs& a, hipStream_t st, int* kind_out) {
     if constexpr (sizeof(T) == 2) {
         // 256^2 tiles pay once there are ~1.5 block waves of them (every ViT / projector GEMM, gate_up of a >= 600-row chunk)
         if (variant == GEMM_RING256 || (variant == GEMM_AUTO && a.M >= 512 && (a.N % 32) == 0 && big_packed_ok(MMD_BF16, a, 16) && ring_size_ok(a) &&
-                                        (long long)cdiv(a.M, 256) * cdiv(a.N, 256) >= 400 && !getenv("MMDUET_NO_RING256"))) {
+                                        ring_tiles_ok((long long)cdiv(a.M, 256) * cdiv(a.N, 256)) && !getenv("MMDUET_NO_RING256"))) {
             if (!big_packed_ok(MMD_BF16, a, 16) || (a.N % 32) != 0 || !ring_size_ok(a)) return hipErrorInvalidValue;
             p.W = a.Wp;
             if (kind_out) *kind_out = MMD_K_GEMM_TILE;
@@ -1105,6 +1108,21 @@ static hipError_t launch_t(const GemmArgs& a, hipStream_t st, int* kind_out) {
             const long long t128 = (long long)cdiv(a.M, 128) * (a.N / 128);
             if (big_packed_ok(MMD_BF16, a, 128) && (t128 >= 400 || (a.K >= 8192 && t128 >= 224))) bn = 128;
             else if (big_packed_ok(MMD_BF16, a, 64)) bn = 64;
+            // mid-M (a chunk's qkv / o_proj): once some CU would carry three or more 128-row blocks, one 256x128 ring tile per CU (4-wave ring, flags 17) is the
+            // shorter schedule.  Per-CU cost in units of one 128x64 block at two per CU (17.5 us at K = 3584), fitted to tools/probes/midm_ring4w_sweep.py:
+            // n blocks of 128x64 cost max(1.83, n), of 128x128 max(2.29, 1.77 n), a 256x128 ring tile 2.95 (M = 1323 qkv 75 -> 51 us, M = 1911 o 63 -> 58 us)
+            static const bool no_r4 = getenv("MMDUET_NO_RING4W") != nullptr;
+            if (bn && variant == GEMM_AUTO && !a.f16 && !no_r4 && a.M >= 512 && a.K >= 1024 && (a.N % 128) == 0 && big_packed_ok(MMD_BF16, a, 16) && ring_size_ok(a)) {
+                const long long mt128 = cdiv(a.M, 128);
+                const double nb = bn == 64 ? (double)cdiv(mt128 * (a.N / 64), 256) : (double)cdiv(t128, 256);
+                const double cbig = bn == 64 ? (nb > 1.83 ? nb : 1.83) : (1.77 * nb > 2.29 ? 1.77 * nb : 2.29);
+                const double cr4 = 2.95 * (double)cdiv((long long)cdiv(a.M, 256) * (a.N / 128), 256);
+                if (cr4 < cbig) {
+                    p.W = a.Wp;
+                    if (kind_out) *kind_out = MMD_K_GEMM_TILE;
+                    return launch_ringx(17, p, a, st);
+                }
+            }
             if (bn) {
                 p.W = a.Wp;
                 if (kind_out) *kind_out = MMD_K_GEMM_TILE;

@@ -92,6 +92,31 @@ if __name__ == '__main__':
                 print(f'M={M:6d} {name:13s} N={N:6d} K={K:6d} {names.get(v, str(v)):18s} median {med*1e3:8.1f} us  min {mn*1e3:8.1f} us  {tf:7.1f} TF  {tf/2500:5.3f}', flush=True)
         if len(sys.argv) > 4:
             json.dump(dict(note=f'tools/bench_gemm.py ab: {rounds} interleaved rounds x 5 iterations per variant, random bf16 operands, same operands for every variant of a shape', rows=rows), open(sys.argv[4], 'w'), indent=1)
+    if which == 'lib':
+        # reference point only (never on the product path): the ROCm library GEMM (torch.mm -> hipBLASLt / rocBLAS) on the same operands, interleaved with the dispatcher's kernel
+        import statistics
+        rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 7
+        shapes = [(25515, n, N, K) for n, N, K, _ in VIT] + [(1274, n, N, K) for n, N, K, _ in LLM[:4]] + [(4096, 'sq4096', 4096, 4096), (8192, 'sq8192', 8192, 8192)]
+        rows = []
+        for M, name, N, K in shapes:
+            X, W = operands(ops, M, N, K)
+            Wt = W.t()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for _ in range(3): torch.mm(X, Wt)
+            t_lib, t_us = [], []
+            for r in range(rounds):
+                torch.cuda.synchronize(); e0.record()
+                for _ in range(5): Y = torch.mm(X, Wt)
+                e1.record(); torch.cuda.synchronize()
+                t_lib.append(e0.elapsed_time(e1) / 5)
+                t_us.append(run(ops, M, N, K, 'none', 0, iters=5))
+            a, b = statistics.median(t_lib), statistics.median(t_us)
+            rows.append(dict(M=M, name=name, N=N, K=K, library_us=round(a * 1e3, 1), ours_us=round(b * 1e3, 1), library_tflops=round(2 * M * N * K / a / 1e9, 1), ours_tflops=round(2 * M * N * K / b / 1e9, 1), ours_kernel=run.plan['kernel']))
+            print(rows[-1], flush=True)
+            del X, W, Wt
+        if len(sys.argv) > 3:
+            json.dump(dict(note=f'tools/bench_gemm.py lib: torch.mm (ROCm library GEMM, row-major X[M,K] x W[N,K]^T, bf16) beside mmd_op_gemm_bench variant 0 (epilogue none), {rounds} interleaved rounds x 5 iterations, random operands; '
+                                'ours runs on different random operands of the same distribution (the bench entry draws its own W)', rows=rows), open(sys.argv[3], 'w'), indent=1)
     if which in ('llm', 'all'):
         rows = []
         for M in (1, 16, 49, 64):
