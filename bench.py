@@ -78,6 +78,24 @@ def cpu_model():
     return 'unknown'
 
 
+def thread_cpu_times():
+    """{tid: (comm, cpu seconds)} of this process's threads (/proc/self/task): which host thread burns the cores a rank is granted."""
+    out = {}
+    tick = os.sysconf('SC_CLK_TCK')
+    try:
+        for tid in os.listdir('/proc/self/task'):
+            try:
+                st = open(f'/proc/self/task/{tid}/stat').read()
+                comm = st[st.index('(') + 1:st.rindex(')')]
+                f_ = st[st.rindex(')') + 2:].split()
+                out[int(tid)] = (comm, (int(f_[11]) + int(f_[12])) / tick)
+            except Exception:
+                pass
+    except Exception:
+        pass
+    return out
+
+
 def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
@@ -101,6 +119,7 @@ def parse(argv=None):
     p.add_argument('--weights', choices=['bf16', 'fp8'], default=None, help='fp8 = e4m3 per-output-channel scaled LLM weights (BASELINE configs[4]); reported with dtype fp8, never the bf16 headline')
     p.add_argument('--phase', choices=['ab', 'b'], default='ab', help="'b': Phase B alone -- the frame embeddings come from a feature file written before the timed region (mmduet_amd/features.py); LLM-only frames/s, never the headline")
     p.add_argument('--tower-dtype', choices=['auto', 'bf16', 'fp16'], default='auto', help="vision tower arithmetic: fp16 = the reference's torch.cuda.amp.autocast() tower (models/modeling_live.py:28), bf16 = the model dtype; auto = the product default")
+    p.add_argument('--host-sync', choices=['auto', 'spin', 'yield', 'blocking'], default='auto', help='how this rank waits for the GPU (hipSetDeviceFlags before the first HIP call): blocking frees the host core a spinning wait burns -- matters when 8 ranks share 16 cores')
     p.add_argument('--layers', type=int, default=None, help='debug: override LLM layer count (INVALID as a measurement)')
     a = p.parse_args(argv)
     c = CONFIGS[a.config]
@@ -367,6 +386,14 @@ def main():
         return bench_native336(args)
     launch_ranks_if_needed(args)
     torch.set_num_threads(max(1, effective_cpus() // max(1, int(os.environ.get('WORLD_SIZE', '1')))))   # host-side torch ops (and the CPU baseline) use the cores this process really has
+    if args.host_sync != 'auto':                            # must precede the first HIP call of the process (so before init_distributed, which initialises the device for RCCL)
+        import ctypes
+        hip = ctypes.CDLL('libamdhip64.so')
+        flag = {'spin': 1, 'yield': 2, 'blocking': 4}[args.host_sync]          # hipDeviceScheduleSpin / Yield / BlockingSync
+        hip.hipSetDevice(int(os.environ.get('LOCAL_RANK', '0')))
+        rc = hip.hipSetDeviceFlags(flag)
+        if rc != 0:
+            raise SystemExit(f'bench.py: hipSetDeviceFlags({flag}) failed with {rc}')
     from mmduet_amd.distributed import init_distributed, gather_scores, NativeScoreGather
     import torch.distributed as dist
     rank, world, local = init_distributed()
@@ -462,7 +489,7 @@ def main():
     model.prof_enable([dom] + ([second] if second else []) if prof_on else False)        # only the dominant class(es) are bracketed inside the timed region
     sync()
     t0 = time.perf_counter()
-    cpu0 = time.process_time()
+    cpu0 = time.process_time(); thr0 = thread_cpu_times()
     fwd = 0
     step_blocks = []
     for _ in range(args.steps):
@@ -472,6 +499,8 @@ def main():
         fwd += driver.forward_calls if multi_runner is None else multi_runner.ms.rounds
     sync()
     dt = time.perf_counter() - t0
+    thr1 = thread_cpu_times()
+    host_threads = sorted(((round((c - thr0.get(t, (n, 0.0))[1]) / max(1, args.steps), 3), n, 'main' if t == os.getpid() else 'tid') for t, (n, c) in thr1.items()), reverse=True)[:5]
     host_cpu_s = time.process_time() - cpu0                                # user + system CPU seconds of this rank's process (all its threads) inside the timed region
     model.prof_enable(False)
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -567,7 +596,7 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 2),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16' if args.weights == 'bf16' else 'fp8_e4m3 weights x bf16 activations',
             'data': 'synthetic', 'rccl_ranks': rccl_ranks,
-            'host_cpu_s_per_step': round(host_cpu_s / max(1, args.steps), 3), 'nproc_granted': effective_cpus(), 'nproc_visible': os.cpu_count(),
+            'host_cpu_s_per_step': round(host_cpu_s / max(1, args.steps), 3), 'host_sync': args.host_sync, 'host_threads_cpu_s_per_step': [dict(comm=n, cpu_s=c, thread=w) for c, n, w in host_threads if c > 0.005], 'nproc_granted': effective_cpus(), 'nproc_visible': os.cpu_count(),
             'torch_threads': torch.get_num_threads(), 'gpu_idle_frac': gpu_idle,
             'config': {'workload': ('tiny-plumbing' if args.tiny else 'llava-onevision-qwen2-7b + siglip-so400m-384') +
                        f', {args.frames}-frame 1fps {R}px stream{"s" if S > 1 else ""} ({S} per GPU), ' + CONFIGS[args.config]['text'],
