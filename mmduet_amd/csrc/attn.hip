@@ -481,6 +481,8 @@ __global__ __launch_bounds__(256, NSLOT == 2 ? 2 : 1) void attn_gqa128_kernel(At
             }
         }
     }
+    // (ring form: wave 0 wrote the new token's K row above and never counts vmcnt again -- drain it here, before the first barrier lets a loader stage that row's tile)
+    if constexpr (NSLOT == 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     int slot = 0, ti = 0;
     for (long long k0 = kbeg; k0 < kend; k0 += KT, slot = (slot + 1) & (NSLOT - 1), ++ti) {
             if constexpr (NSLOT == 2) {

@@ -180,6 +180,12 @@ def test_attention_mfma_kernels(ops_bf16, S, nh, nkv, d, n_ctx, causal, variant)
     _attention(ops_bf16, S, nh, nkv, d, n_ctx, causal, variant)
 
 
+# decode geometry (<= 16 rows per kv head): the loader / compute ring of attn_gqa128_kernel<1, 4> -- 1..5+ tiles per split, ring refills, partial last tiles, empty context
+@pytest.mark.parametrize('S,n_ctx', [(s, n) for s in (1, 2) for n in (0, 1, 62, 63, 64, 127, 191, 255, 256, 1000, 4100, 16383, 16400, 33000, 70001)])
+def test_decode_attention_ring_contexts(ops_bf16, S, n_ctx):
+    _attention(ops_bf16, S, 28, 4, 128, n_ctx, True, 3)
+
+
 def _attention(ops, S, nh, nkv, d, n_ctx, causal, variant):
     g = torch.Generator().manual_seed(S * 13 + d)
     cap = (n_ctx + S + 37 + 63) // 64 * 64

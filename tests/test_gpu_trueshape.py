@@ -164,6 +164,12 @@ print("RES " + json.dumps(res))
     long_ctx = ','.join(['120'] * 125 + ['3', '1', '4', '2', '1'])
     got = run(long_ctx, MMDUET_NO_FUSE='0', MMD_KV_TOKENS='16384')
     assert got[-5:] == run(long_ctx, MMDUET_NO_FUSE='0', MMDUET_NO_ROPE_FUSE='1', MMD_KV_TOKENS='16384')[-5:]
+    # the decode attention's four-slot loader / compute ring against its two-slot form: same tiles, same per-tile arithmetic, same split ranges -> same bits
+    # (edge: 1-5 tiles per split, empty splits, positions on tile boundaries; long: 4 tiles per split of 15 k keys, the ring refilled once)
+    assert run(edge, MMDUET_NO_FUSE='0') == run(edge, MMDUET_NO_FUSE='0', MMDUET_ATTN_DECODE_RING='0')
+    assert got[-5:] == run(long_ctx, MMDUET_NO_FUSE='0', MMDUET_ATTN_DECODE_RING='0', MMD_KV_TOKENS='16384')[-5:]
+    mid = ','.join(['100'] * 4 + ['1', '2', '1'] + ['128'] * 3 + ['1', '1', '2'] + ['128'] * 40 + ['1', '2'])          # contexts 400 / 790 / 5.9 k: 1 / 1 / 2 tiles per split
+    assert run(mid, MMDUET_NO_FUSE='0', MMD_KV_TOKENS='8192') == run(mid, MMDUET_NO_FUSE='0', MMDUET_ATTN_DECODE_RING='0', MMD_KV_TOKENS='8192')
     ref = run(long_ctx, MMDUET_NO_FUSE='1', MMD_KV_TOKENS='16384')          # unfused launch schedule throughout
     for ra, rb in zip(got[-5:], ref[-5:]):
         assert ra == pytest.approx(rb, abs=3e-2, rel=3e-2)
