@@ -269,6 +269,29 @@ __global__ void attn_combine_kernel(AttnP p, int nrows_total_all) {
     }
 }
 
+#ifdef MMDUET_ATTN_GRP_LSB
+#define ATTN_GRP(w) ((w) & 1)
+#else
+#define ATTN_GRP(w) ((w) >> 2)
+#endif
+#ifdef MMDUET_ATTN_TIMING
+// debug build only (`make ATTN_TIMING=1`, tools/attn_timing.py; never shipped): per-wave issue-time stamps of the chunk kernel's loop segments, summed over all
+// waves of all launches since the last reset: [0] wait + barrier + next tile's DMA issue, [1] score MFMAs (+ K fragment reads), [2] softmax, [3] P.V MFMAs (+ V reads), [4] tiles, [5] whole kernel
+__device__ unsigned long long g_attn_t[8];
+extern "C" int mmd_debug_attn_timing(unsigned long long* out8, int reset) {
+    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_attn_t), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_attn_t), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#define ATS_DECL unsigned long long ats_[6] = {0, 0, 0, 0, 0, 0}, ats_t_ = __builtin_readcyclecounter(), ats_k_ = ats_t_
+#define ATS(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); ats_[i] += n_ - ats_t_; ats_t_ = n_; } while (0)
+#define ATS_FLUSH do { ats_[5] = __builtin_readcyclecounter() - ats_k_; if ((threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 6; ++i_) atomicAdd(&g_attn_t[i_], ats_[i_]); } while (0)
+#else
+#define ATS_DECL
+#define ATS(i)
+#define ATS_FLUSH
+#endif
+
 // ------------------------------------------------------------------------------------------------------------------
 // attn_gqa128_kernel: the LLM attention of the streaming loop (head_dim 128, bf16, K arena [kvh][cap][128], V arena
 // transposed in 64-token blocks).  One block = 4 waves x RT row-tiles of 16 "rows" (row = tok*G + g: the G query heads
@@ -286,17 +309,24 @@ __global__ void attn_combine_kernel(AttnP p, int nrows_total_all) {
 //   * NSLOT = 4 (decode: one query block per kv head, <= 256 blocks, ONE per CU): a four-slot ring in 128 KB of LDS, three tiles in flight beyond the one being
 //     consumed, counted vmcnt per tile, nt policy on the K / V stream (every byte is read once by one CU).  A 4-tile split at 15 k keys then pays ONE load
 //     latency instead of four; the q prologue (slab sum + RoPE) loads are issued before the DMAs and finished under them.
-template <int RT, int NSLOT = 2>
-__global__ __launch_bounds__(256, NSLOT == 2 ? 2 : 1) void attn_gqa128_kernel(AttnP p) {
+//   * WAVES = 8 (chunks of >= 1024 rows per kv head): 256 query rows per block, ONE block per CU, the four-slot ring fed by all eight waves (4 DMA pieces per
+//     wave and tile, counted vmcnt, raw barrier).  The 128-row form is bound by its K / V stream, not by MFMA or VALU: each block re-reads the whole key range
+//     of its kv head from L2 with one 32 KB tile in flight (tools/attn_timing.py: 43-59 % of every wave's cycles sit in the per-tile wait + barrier; 2.1 GB per
+//     launch at 15 k keys = 5.7 TB/s).  256 rows halve that traffic per flop and three tiles in flight cover the L2 latency.
+template <int RT, int NSLOT = 2, int WAVES = 4>
+__global__ __launch_bounds__(WAVES * 64, (NSLOT == 2 && WAVES == 4) ? 2 : 1) void attn_gqa128_kernel(AttnP p) {
     constexpr int D = 128, KT = 64, TILE = KT * D;              // one K tile = one V^T tile = 8192 elements = 16 KB, contiguous in the arena
     constexpr int PF = NSLOT - 1;                                // tiles in flight beyond the one being consumed
+    constexpr int BR = WAVES * 16 * RT;                          // query rows per block
+    constexpr int NPC = 16 / WAVES;                              // (K piece, V^T piece) pairs per wave and tile
+    constexpr bool ALLRING = NSLOT == 4 && WAVES == 8;           // every wave stages and computes; NSLOT == 4 && WAVES == 4 is the decode form (loaders + one compute wave)
     extern __shared__ __attribute__((aligned(16))) bf16_t kv[];        // NSLOT slots of (K tile, V^T tile): 64 / 128 KB
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // (a scalar: LDS-DMA destinations and the role split need no per-tile readfirstlane)
     const int lr = lane & 15, lq = lane >> 4;
     int bx, by, bz; xcd_block_id(bx, by, bz);
     const int G = p.nh / p.nkv, kvh = by;
     const int rows_total = p.S * G;
-    const int row_base = bx * (64 * RT) + wave * (16 * RT);
+    const int row_base = bx * BR + wave * (16 * RT);
     long long n_ctx = p.n_ctx, k_hs = p.k_hs, v_hs = p.v_hs;
     const bf16_t* Kb = (const bf16_t*)p.K; const bf16_t* Vb = (const bf16_t*)p.V;
     int kv_per_split = p.kv_per_split;
@@ -324,8 +354,8 @@ __global__ __launch_bounds__(256, NSLOT == 2 ? 2 : 1) void attn_gqa128_kernel(At
     }
     const bool wave_active = row_base < rows_total;                 // wave-uniform
     // key range of this block / split (multiples of 64 except at the very end)
-    const int blk_first_row = bx * (64 * RT);
-    const int blk_last_row = min(blk_first_row + 64 * RT - 1, rows_total - 1);
+    const int blk_first_row = bx * BR;
+    const int blk_last_row = min(blk_first_row + BR - 1, rows_total - 1);
     const long long blk_limit = p.causal ? min(n_tot, n_ctx + (long long)(blk_last_row / G) + 1) : n_tot;
     const long long blk_min_limit = p.causal ? n_ctx + (long long)(blk_first_row / G) + 1 : n_tot;   // keys below this are visible to every row
     const long long kbeg = (long long)bz * kv_per_split;
@@ -346,19 +376,29 @@ __global__ __launch_bounds__(256, NSLOT == 2 ? 2 : 1) void attn_gqa128_kernel(At
     // position q ^ f(key), f = ((key >> 3) & 3) * 4 + (key & 3), chunk q of V^T row `dim` at q ^ ((dim >> 1) & 7) -- conflict-free for the
     // b128 fragment reads.  MFMA row i of S^T tile t is key (i >> 2) * 8 + t * 4 + (i & 3) of the 32-key half (not t * 16 + i): a lane's
     // eight P values then belong to eight CONSECUTIVE keys, so its V^T operand is one 16-byte read instead of two 8-byte reads + repack.
+    // The per-lane part of a DMA address (row / swizzle of this wave's four K and four V^T pieces) is fixed for the whole kernel: eight 32-bit byte offsets;
+    // per tile only a scalar base moves (was: eight 64-bit address computations + eight readfirstlanes per tile, ~40 VALU of a VALU-bound loop).
+    unsigned koff[NPC], voff[NPC];
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) {
+        const int pc = wave + WAVES * j;
+        const int key = pc * 4 + (lane >> 4);
+        koff[j] = (unsigned)((key * (int)p.k_ts + (((lane & 15) ^ ((((key >> 3) & 3) << 2) | (key & 3))) * 8)) * 2);
+        const int dim = pc * 8 + (lane >> 3);
+        voff[j] = (unsigned)(((dim << 6) + (((lane & 7) ^ ((dim >> 1) & 7)) * 8)) * 2);
+    }
     auto stage = [&](int slot, long long k0) {
         bf16_t* ks = kv + slot * 2 * TILE;
         bf16_t* vt = ks + TILE;
-        const long long blk = k0 >> 6;
+        const char* kb = (const char*)(Kg + k0 * p.k_ts);
+        const char* vb = (const char*)(Vg + (((k0 >> 6) * D) << 6));
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int pc = wave + 4 * j;
-            const int key = pc * 4 + (lane >> 4);
-            const bf16_t* src = Kg + (k0 + key) * p.k_ts + (((lane & 15) ^ ((((key >> 3) & 3) << 2) | (key & 3))) * 8);
-            const int dim = pc * 8 + (lane >> 3);
-            const bf16_t* vsrc = Vg + ((blk * D + dim) << 6) + (((lane & 7) ^ ((dim >> 1) & 7)) * 8);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(ks + pc * 512), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)vsrc, (__attribute__((address_space(3))) void*)(vt + pc * 512), 16, 0, 0);
+        for (int j = 0; j < NPC; ++j) {
+            const int pc = wave + WAVES * j;
+            unsigned ko = koff[j], vo = voff[j];
+            asm volatile("" : "+v"(ko), "+v"(vo));          // (keeps the zero-extension next to the load: scalar base + 32-bit VGPR offset addressing, no 64-bit offset pairs carried through the loop)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kb + ko), (__attribute__((address_space(3))) void*)(ks + pc * 512), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vb + vo), (__attribute__((address_space(3))) void*)(vt + pc * 512), 16, 0, 0);
         }
     };
     const int vsw = (lr >> 1) & 7;
@@ -424,7 +464,10 @@ __global__ __launch_bounds__(256, NSLOT == 2 ? 2 : 1) void attn_gqa128_kernel(At
             }
         }
     };
-    if constexpr (NSLOT == 4) {
+    if constexpr (ALLRING) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) if (t < ntile && t < 2 + ATTN_GRP(wave)) stage(t, kbeg + (long long)t * KT);          // (group 0: tiles 0, 1; group 1: 0, 1, 2 -- see the phase loop)
+    } else if constexpr (NSLOT == 4) {
         if (wave != 0) {               // the loaders' whole life: one raw barrier per tile, matched by wave 0's below
 #pragma unroll
             for (int t = 0; t < PF; ++t) if (t < ntile) stage3(t, kbeg + (long long)t * KT);
@@ -482,13 +525,205 @@ __global__ __launch_bounds__(256, NSLOT == 2 ? 2 : 1) void attn_gqa128_kernel(At
         }
     }
     // (ring form: wave 0 wrote the new token's K row above and never counts vmcnt again -- drain it here, before the first barrier lets a loader stage that row's tile)
-    if constexpr (NSLOT == 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (NSLOT == 4 && !ALLRING) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ATS_DECL;
+    if constexpr (ALLRING) {
+        // Phase-split loop.  Left to itself every wave runs score MFMAs -> softmax -> P.V MFMAs in the same order behind the same per-tile barrier, so the two waves
+        // of a SIMD want the matrix pipe together and the VALU together (tools/attn_timing.py: ~6400 cycles per wave and tile for 1024 cycles of MFMA).  Here a
+        // wave's tile i is two SEGMENTS separated by block barriers,
+        //     A_i = P.V of tile i-1  +  scores of tile i   (64 MFMAs, 32 LDS fragment reads)        B_i = softmax of tile i   (VALU only),
+        // and waves 4-7 (the second wave of every SIMD: a block's waves are dealt to the SIMDs cyclically) run one segment behind waves 0-3: whenever one wave of a
+        // SIMD is in an A segment its partner is in a B segment.  Global segment s: group g runs local segment u = s - g; u = 2i is A_i, u = 2i + 1 is B_i.
+        // Ring: tile i's K is read during s = 2i, 2i + 1 and its V during 2i + 2, 2i + 3; tile j is staged behind barrier 2j - 4 into the slot tile j - 4 left after
+        // s = 2j - 5, and every wave waits for its own pieces of tile i (counted: tile i + 1 may stay in flight) before barrier 2i.
+#ifdef MMDUET_ATTN_GRP_LSB
+        const int grp = wave & 1;               // (experiment: pairs the waves that do NOT share a SIMD)
+#else
+        const int grp = wave >> 2;
+#endif
+        f32x4_t st[RT][2][2];
+        bf16x8_t pf[RT][2];
+        static_assert(!ALLRING || NPC == 2, "counted waits below assume 4 DMAs per wave and tile");
+        // start of global segment sg: (even sg) this wave's pieces of tile sg / 2 have landed -- tile sg / 2 + 1 may stay in flight --, every LDS read of the
+        // previous segment is done, block barrier, then (even sg) tile sg / 2 + 2 goes out
+        // The DMAs go out at the END of a wave's softmax segments (a DMA issued beside bare MFMAs or at a barrier release costs the wave 60-185 cycles, in a
+        // VALU stretch 25-60): group 0 issues tile i + 2 behind B_i (global segment 2i + 1; its slot, tile i - 2's, is free since 2i - 1), group 1 tile i + 3 behind
+        // B_i (global 2i + 2; tile i - 1's slot is free since 2i + 1); before the loop group 0 has tiles 0, 1 in flight and group 1 tiles 0, 1, 2.
+        auto seg_start = [&](int sg) {
+            if ((sg & 1) == 0 && (sg >> 1) < ntile) {
+                const int i = sg >> 1;
+                const int issued = (grp == 1 && i == 0) ? 2 : i + 1;                 // newest tile this wave has issued by now
+                const int younger = min(issued, ntile - 1) - i;
+                if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            ATS(0);
+        };
+        auto stage_after_softmax = [&](int i) { const int j = i + 2 + grp; if (j < ntile) stage(j & (NSLOT - 1), kbeg + (long long)j * KT); };
+        auto do_pv = [&](int i) {               // O += P(i) V(i)
+            const bf16_t* Vt = kv + (i & (NSLOT - 1)) * 2 * TILE + TILE;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const bf16x8_t vfb = *reinterpret_cast<const bf16x8_t*>(Vt + (t * 16 + lr) * KT + (((h * 4 + lq) ^ vsw) * 8));
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) oacc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfb, pf[rt][h], oacc[rt][t], 0, 0, 0);
+                    if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);          // (4 fragment reads + 8 MFMAs per group: bounds the fragments in flight and with them the register count)
+                }
+        };
+        auto do_qk = [&](int i) {               // S(i) = K(i) Q^T
+            const bf16_t* Ks = kv + (i & (NSLOT - 1)) * 2 * TILE;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + (h * 32 + (lr >> 2) * 8 + t * 4 + (lr & 3)) * D + (((c * 4 + lq) ^ lr) * 8));
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt)
+                            st[rt][h][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[rt][c], c == 0 ? f32x4_t{0, 0, 0, 0} : st[rt][h][t], 0, 0, 0);
+                        if (c == 3) __builtin_amdgcn_sched_barrier(0);
+                    }
+        };
+        // A_i, software-pipelined by hand: eight groups of 4 fragment reads + 8 MFMAs (P.V: half h, output tiles 4q..4q+3; scores: half h, key sub-tile t, the four
+        // 32-dim steps); group g + 1's reads are issued before group g's MFMAs and sched_barriers pin that order -- left alone the compiler hoists all 32 reads
+        // (registers), fenced per group it exposes every LDS latency (measured: 2150 cycles for 1024 cycles of MFMA)
+        auto a_load = [&](auto G, bf16x8_t (&fr)[4], const bf16_t* Vt, const bf16_t* Ks) {
+            constexpr int g = decltype(G)::value;
+            if constexpr (g < 4) {
+                constexpr int h = g >> 1, tq = (g & 1) * 4;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) fr[u] = *reinterpret_cast<const bf16x8_t*>(Vt + ((tq + u) * 16 + lr) * KT + (((h * 4 + lq) ^ vsw) * 8));
+            } else {
+                constexpr int h = (g - 4) >> 1, t = (g - 4) & 1;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) fr[c] = *reinterpret_cast<const bf16x8_t*>(Ks + (h * 32 + (lr >> 2) * 8 + t * 4 + (lr & 3)) * D + (((c * 4 + lq) ^ lr) * 8));
+            }
+        };
+        auto a_mma = [&](auto G, const bf16x8_t (&fr)[4]) {
+            constexpr int g = decltype(G)::value;
+            if constexpr (g < 4) {
+                constexpr int h = g >> 1, tq = (g & 1) * 4;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) oacc[rt][tq + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[u], pf[rt][h], oacc[rt][tq + u], 0, 0, 0);
+            } else {
+                constexpr int h = (g - 4) >> 1, t = (g - 4) & 1;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt)
+                        st[rt][h][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[c], qf[rt][c], c == 0 ? f32x4_t{0, 0, 0, 0} : st[rt][h][t], 0, 0, 0);
+            }
+        };
+        auto do_a = [&](int i) {                // P.V of tile i - 1, scores of tile i
+            const bf16_t* Vt = kv + ((i - 1) & (NSLOT - 1)) * 2 * TILE + TILE;
+            const bf16_t* Ks = kv + (i & (NSLOT - 1)) * 2 * TILE;
+            bf16x8_t fa[4], fb[4];
+#define A_STEP(g, cur, nxt) do { if constexpr ((g) + 1 < 8) a_load(std::integral_constant<int, ((g) + 1 < 8 ? (g) + 1 : 7)>{}, nxt, Vt, Ks); __builtin_amdgcn_sched_barrier(0); \
+                                 a_mma(std::integral_constant<int, (g)>{}, cur); __builtin_amdgcn_sched_barrier(0); } while (0)
+            a_load(std::integral_constant<int, 0>{}, fa, Vt, Ks);
+            A_STEP(0, fa, fb); A_STEP(1, fb, fa); A_STEP(2, fa, fb); A_STEP(3, fb, fa); A_STEP(4, fa, fb); A_STEP(5, fb, fa); A_STEP(6, fa, fb); A_STEP(7, fb, fa);
+#undef A_STEP
+        };
+        const int lim0[RT] = {(int)((my_limit[0] < kend ? my_limit[0] : kend) - kbeg), (int)((my_limit[RT - 1] < kend ? my_limit[RT - 1] : kend) - kbeg)};      // (a split's key range fits 31 bits)
+        auto do_softmax = [&](int i) {          // P(i) from S(i).  ONE running-max decision per row and 64-key tile (both halves' P wait for their P.V in the next segment: a
+                                                // rescale between them would miss the first half), otherwise the arithmetic of the two-slot loop below
+            const int t0 = i * KT;                                           // tile-relative to kbeg
+            const bool need_mask = (kbeg + t0 + KT > blk_min_limit) || (kbeg + t0 + KT > kend);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const int lim = lim0[rt] - t0;
+                const int rel = (lim < 0 ? 0 : (lim > KT ? KT : lim)) - lq * 8;
+#define SV(h, t, r) st[rt][h][t][r]
+                if (need_mask) {                  // (in place: the scores are dead after this segment, and a copy would cost a move per element on the unmasked path)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (!(h * 32 + t * 4 + r < rel)) SV(h, t, r) = -INFINITY;
+                }
+                float mx = fmaxf(fmaxf(fmaxf(fmaxf(SV(0, 0, 0), SV(0, 0, 1)), fmaxf(SV(0, 0, 2), SV(0, 0, 3))), fmaxf(fmaxf(SV(0, 1, 0), SV(0, 1, 1)), fmaxf(SV(0, 1, 2), SV(0, 1, 3)))),
+                                 fmaxf(fmaxf(fmaxf(SV(1, 0, 0), SV(1, 0, 1)), fmaxf(SV(1, 0, 2), SV(1, 0, 3))), fmaxf(fmaxf(SV(1, 1, 0), SV(1, 1, 1)), fmaxf(SV(1, 1, 2), SV(1, 1, 3)))));
+                mx = quad_lanes_max(mx);
+                mx *= p.scale_log2;
+                if (mx > m_run[rt] + ATTN_DEFER) {
+                    const float alpha = __builtin_amdgcn_exp2f(m_run[rt] - mx);
+                    l_run[rt] *= alpha;
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) oacc[rt][t] *= alpha;
+                    m_run[rt] = mx;
+                }
+                const float neg_m = m_run[rt] == -INFINITY ? 0.f : -m_run[rt];
+                float psum = 0.f;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    s16x8_t pk;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { float pv = __builtin_amdgcn_exp2f(fmaf(SV(h, e >> 2, e & 3), p.scale_log2, neg_m)); psum += pv; pk[e] = (short)f2bf(pv); }
+                    pf[rt][h] = __builtin_bit_cast(bf16x8_t, pk);
+                }
+#undef SV
+                l_run[rt] += psum;
+            }
+        };
+        if (ntile > 0) {
+            // this wave's segments, in order: A_0 = scores(0); B_0; A_1 = PV(0) + scores(1); B_1; ...; A_n = PV(n - 1).  Group 1 opens with one idle global segment,
+            // group 0 closes with one: both run 2 n + 2 barriers
+            int sg = 0;
+            if (grp == 1) seg_start(sg++);
+            seg_start(sg++);
+            if (wave_active) do_qk(0);
+            ATS(1);
+            seg_start(sg++);
+            if (wave_active) do_softmax(0);
+            stage_after_softmax(0);
+            ATS(2);
+            for (int i = 1; i < ntile; ++i) {
+                seg_start(sg++);
+#if defined(MMDUET_ATTN_PRIO_A)
+                __builtin_amdgcn_s_setprio(MMDUET_ATTN_PRIO_A);
+#endif
+                if (wave_active) do_a(i);
+#if defined(MMDUET_ATTN_PRIO_A)
+                __builtin_amdgcn_s_setprio(0);
+#endif
+                ATS(1);
+                seg_start(sg++);
+#if defined(MMDUET_ATTN_PRIO_B)
+                __builtin_amdgcn_s_setprio(MMDUET_ATTN_PRIO_B);
+#endif
+                if (wave_active) do_softmax(i);
+#if defined(MMDUET_ATTN_PRIO_B)
+                __builtin_amdgcn_s_setprio(0);
+#endif
+                stage_after_softmax(i);
+                ATS(2);
+#ifdef MMDUET_ATTN_TIMING
+                ats_[4] += 1;
+#endif
+            }
+            seg_start(sg++);
+            if (wave_active) do_pv(ntile - 1);
+            ATS(3);
+            if (grp == 0) seg_start(sg++);
+        }
+    } else {
     int slot = 0, ti = 0;
     for (long long k0 = kbeg; k0 < kend; k0 += KT, slot = (slot + 1) & (NSLOT - 1), ++ti) {
-            if constexpr (NSLOT == 2) {
+        if constexpr (NSLOT == 2) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (k0 + KT < kend) stage(slot ^ 1, k0 + KT);
+            ATS(0);
         } else {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (wave 0 only: its reads of the previous tile are done before the loaders may refill that slot)
             __builtin_amdgcn_s_barrier();
@@ -517,6 +752,7 @@ __global__ __launch_bounds__(256, NSLOT == 2 ? 2 : 1) void attn_gqa128_kernel(At
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt) st[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[rt][c], st[rt][t], 0, 0, 0);
                 }
+            ATS(1);
             bf16x8_t pf[RT];
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
@@ -553,14 +789,21 @@ __global__ __launch_bounds__(256, NSLOT == 2 ? 2 : 1) void attn_gqa128_kernel(At
                 l_run[rt] += psum;
                 pf[rt] = __builtin_bit_cast(bf16x8_t, pk);
             }
+            ATS(2);
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
                 const bf16x8_t vfb = *reinterpret_cast<const bf16x8_t*>(Vt + (t * 16 + lr) * KT + (((h * 4 + lq) ^ vsw) * 8));
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) oacc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfb, pf[rt], oacc[rt][t], 0, 0, 0);
             }
+            ATS(3);
         }
+#ifdef MMDUET_ATTN_TIMING
+        ats_[4] += 1;
+#endif
     }
+    }
+    if constexpr (RT == 2) { ATS_FLUSH; }
 
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
@@ -676,7 +919,12 @@ __global__ __launch_bounds__(256) void attn_combine128_rows_kernel(AttnP p, int 
 template <int RT>
 static hipError_t launch_gqa128(AttnP& p, const AttnArgs& a, hipStream_t st) {
     const int G = a.nh / a.nkv, rows_total = a.S * G;
-    const int qblocks = cdiv(rows_total, 64 * RT);
+    // chunks (>= 1024 rows per kv head): 256-row blocks, one per CU, four-slot ring; MMDUET_ATTN_CHUNK8=0 keeps the 128-row form (A/B switch)
+    static const bool chunk8_off = getenv("MMDUET_ATTN_CHUNK8") && atoi(getenv("MMDUET_ATTN_CHUNK8")) == 0;
+    const bool chunk8 = RT == 2 && rows_total >= 1024 && !chunk8_off;
+    const int qblocks = cdiv(rows_total, chunk8 ? 256 : 64 * RT);
+    const int resident = chunk8 ? 256 : 512;                       // blocks the chip holds at once
+    static const double chunk8_unit = getenv("MMDUET_ATTN_CHUNK8_UNIT") ? atof(getenv("MMDUET_ATTN_CHUNK8_UNIT")) : 1.6;
     const long long n_tot = a.n_ctx + a.S;
     const int blocks = qblocks * a.nkv;
     const int tiles = cdiv(n_tot, 64);
@@ -696,7 +944,7 @@ static hipError_t launch_gqa128(AttnP& p, const AttnArgs& a, hipStream_t st) {
         while (maxs > 1 && (size_t)maxs * a.nkv * rows_total * (128 + 2) * sizeof(float) > a.ws_bytes) --maxs;
         double best = 1e30;
         for (int sp = 1; sp <= maxs; ++sp) {
-            const double rounds = (double)cdiv((long long)blocks * sp, 512);
+            const double rounds = (double)cdiv((long long)blocks * sp, resident) * (chunk8 ? chunk8_unit : 1.0);          // (a 256-row block's tile in units of the 128-row form's)
             const double cost = rounds * ((double)cdiv(tiles, sp) + 2.0) + (sp > 1 ? sp * rows_all * 6.7e-5 + 1.5 : 0.0);
             if (cost < best - 1e-9) { best = cost; splits = sp; }
         }
@@ -718,6 +966,15 @@ static hipError_t launch_gqa128(AttnP& p, const AttnArgs& a, hipStream_t st) {
             attr_set[dev] = true;
         }
         hipLaunchKernelGGL((attn_gqa128_kernel<1, 4>), dim3(qblocks, a.nkv, splits), dim3(256), 4 * 32768, st, p);
+    } else if (chunk8) {
+        static bool attr8_set[64] = {};
+        int dev = 0; hipGetDevice(&dev);
+        if (dev >= 0 && dev < 64 && !attr8_set[dev]) {
+            hipError_t e = hipFuncSetAttribute((const void*)attn_gqa128_kernel<2, 4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
+            if (e != hipSuccess) return e;
+            attr8_set[dev] = true;
+        }
+        hipLaunchKernelGGL((attn_gqa128_kernel<2, 4, 8>), dim3(qblocks, a.nkv, splits), dim3(512), 4 * 32768, st, p);
     } else
         hipLaunchKernelGGL((attn_gqa128_kernel<RT>), dim3(qblocks, a.nkv, splits), dim3(256), 2 * 32768, st, p);
     if (splits > 1) {
@@ -787,31 +1044,40 @@ __global__ __launch_bounds__(256, 2) void attn_rowmajor_kernel(AttnP p) {
         for (int t = 0; t < DVT; ++t) oacc[rt][t] = f32x4_t{0, 0, 0, 0};
     }
 
+    // this thread's pieces of a tile -- (key, 16-byte chunk) pairs, KT * nch of them dealt round-robin -- are fixed for the whole kernel: source column, LDS
+    // offsets and validity are computed once.  Loads are UNCONDITIONAL (a lane without a piece re-reads the last one, a key past the end reads the last valid
+    // row: its scores are masked and its P is 0, any finite V row will do), so no per-tile zero fill of the staging registers and no branch around a load.
     s16x8_t pk_[PRE], pv_[PRE];
-    auto prefetch = [&](int k0) {
+    int pkey[PRE], pcol[PRE], lk[PRE], lv[PRE]; bool pok[PRE];
+    {
+        const int pieces = KT * nch;
 #pragma unroll
         for (int j = 0; j < PRE; ++j) {
             const int i = tid + 256 * j;
-            const int key = i / NCH, c = i % NCH;
-            s16x8_t kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (i < KT * NCH && c < nch && k0 + key < kend) {
-                kv = *reinterpret_cast<const s16x8_t*>(Kg + (long long)(k0 + key) * p.k_ts + c * 8);
-                vv = *reinterpret_cast<const s16x8_t*>(Vg + (long long)(k0 + key) * p.v_ts + c * 8);
-            }
-            pk_[j] = kv; pv_[j] = vv;
+            pok[j] = i < pieces;
+            const int ii = pok[j] ? i : pieces - 1;
+            const int key = ii / nch, c = ii - key * nch;
+            pkey[j] = key; pcol[j] = c * 8;
+            lk[j] = key * KLD + c * 8;
+            lv[j] = (((c >> 1) * 16 + (key >> 2)) * 4 + (key & 3)) * 16 + (c & 1) * 8;          // V image: block (dtile = c>>1, quad = key>>2), row key&3, cols (c&1)*8..
+        }
+    }
+    const int kts = (int)p.k_ts, vts = (int)p.v_ts;
+    auto prefetch = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < PRE; ++j) {
+            const int row = min(k0 + pkey[j], kend - 1);
+            pk_[j] = *reinterpret_cast<const s16x8_t*>(Kg + (unsigned)(row * kts + pcol[j]));          // (32-bit element offsets: launch_attention checks n_tot * stride < 2^31)
+            pv_[j] = *reinterpret_cast<const s16x8_t*>(Vg + (unsigned)(row * vts + pcol[j]));
         }
     };
     auto commit = [&]() {
 #pragma unroll
-        for (int j = 0; j < PRE; ++j) {
-            const int i = tid + 256 * j;
-            const int key = i / NCH, c = i % NCH;
-            if (i < KT * NCH && c < nch) {
-                *reinterpret_cast<s16x8_t*>(Ks + key * KLD + c * 8) = pk_[j];
-                // V image: block (dtile = c>>1, quad = key>>2), row key&3, cols (c&1)*8..
-                *reinterpret_cast<s16x8_t*>(Vs + (((c >> 1) * 16 + (key >> 2)) * 4 + (key & 3)) * 16 + (c & 1) * 8) = pv_[j];
+        for (int j = 0; j < PRE; ++j)
+            if (pok[j]) {
+                *reinterpret_cast<s16x8_t*>(Ks + lk[j]) = pk_[j];
+                *reinterpret_cast<s16x8_t*>(Vs + lv[j]) = pv_[j];
             }
-        }
     };
 
     if (0 < kend) prefetch(0);
@@ -842,19 +1108,19 @@ __global__ __launch_bounds__(256, 2) void attn_rowmajor_kernel(AttnP p) {
                 // maximum is only moved (O and l rescaled) when it grows by more than 2^DEFER -- P then ranges up to 2^DEFER
                 // instead of 1, which bf16 P / fp32 O and l absorb; saves ~30 VALU per 16 MFMAs in a VALU-bound loop
                 float sv[8];
-                float mx = -INFINITY;
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float v = st[rt][t][r];
-                        if (need_mask) {
-                            const int key = k0 + h * 32 + t * 16 + lq * 4 + r;
-                            if (!(key < my_limit[rt] && key < kend)) v = -INFINITY;
-                        }
-                        sv[t * 4 + r] = v;
-                        mx = fmaxf(mx, v);
-                    }
+                    for (int r = 0; r < 4; ++r) sv[t * 4 + r] = st[rt][t][r];
+                if (need_mask) {                  // wave-uniform BRANCH: only the tile at the end of the keys (and, causal, on the diagonal) pays the compares / selects
+                    const int lim = min(my_limit[rt], kend) - (k0 + h * 32 + lq * 4);          // element (t, r) is visible iff t*16 + r < lim
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (!(t * 16 + r < lim)) sv[t * 4 + r] = -INFINITY;
+                }
+                float mx = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
                 mx = quad_lanes_max(mx);
                 mx *= p.scale_log2;                                   // scale > 0: max commutes with it
                 if (mx > m_run[rt] + ATTN_DEFER) {                    // (first tile: m_run = -inf -> always)
@@ -962,7 +1228,8 @@ hipError_t launch_attention(int dtype, const AttnArgs& a, hipStream_t st) {
     int variant = a.variant;
     const bool can_gqa128 = can_mfma && a.d == 128 && a.v_transposed && a.batch == 1 && a.k_ts == 128;
     // token-major K/V rows (ViT fused qkv): the transpose-read kernel; it keeps a whole sequence per (head, batch) block
-    const bool can_rowmajor = can_mfma && !a.v_transposed && a.n_ctx + a.S < (1 << 30) && (a.o_bstride % 4) == 0 && (a.ldo % 4) == 0;
+    const bool can_rowmajor = can_mfma && !a.v_transposed && a.n_ctx + a.S < (1 << 30) && (a.o_bstride % 4) == 0 && (a.ldo % 4) == 0 &&
+                              (a.n_ctx + a.S) * (a.k_ts > a.v_ts ? a.k_ts : a.v_ts) < (1ll << 31);          // (its staging loads address a sequence with 32-bit element offsets)
     if (variant == 0) variant = can_gqa128 ? 3 : (can_rowmajor && a.S >= 64 ? 4 : (can_mfma ? 2 : 1));
     if (a.qkv_slabs && variant != 3) return hipErrorInvalidValue;
     if (f16 && variant != 4) return hipErrorInvalidValue;
