@@ -466,7 +466,7 @@ __global__ __launch_bounds__(WAVES * 64, (NSLOT == 2 && WAVES == 4) ? 2 : 1) voi
     };
     if constexpr (ALLRING) {
 #pragma unroll
-        for (int t = 0; t < 3; ++t) if (t < ntile && t < 2 + ATTN_GRP(wave)) stage(t, kbeg + (long long)t * KT);          // (group 0: tiles 0, 1; group 1: 0, 1, 2 -- see the phase loop)
+        for (int t = 0; t < 2; ++t) if (t < ntile) stage(t, kbeg + (long long)t * KT);          // (tile j >= 2 goes out during interval j - 2, see the phase loop)
     } else if constexpr (NSLOT == 4) {
         if (wave != 0) {               // the loaders' whole life: one raw barrier per tile, matched by wave 0's below
 #pragma unroll
@@ -530,12 +530,9 @@ __global__ __launch_bounds__(WAVES * 64, (NSLOT == 2 && WAVES == 4) ? 2 : 1) voi
     if constexpr (ALLRING) {
         // Phase-split loop.  Left to itself every wave runs score MFMAs -> softmax -> P.V MFMAs in the same order behind the same per-tile barrier, so the two waves
         // of a SIMD want the matrix pipe together and the VALU together (tools/attn_timing.py: ~6400 cycles per wave and tile for 1024 cycles of MFMA).  Here a
-        // wave's tile i is two SEGMENTS separated by block barriers,
+        // wave's tile i is two SEGMENTS,
         //     A_i = P.V of tile i-1  +  scores of tile i   (64 MFMAs, 32 LDS fragment reads)        B_i = softmax of tile i   (VALU only),
-        // and waves 4-7 (the second wave of every SIMD: a block's waves are dealt to the SIMDs cyclically) run one segment behind waves 0-3: whenever one wave of a
-        // SIMD is in an A segment its partner is in a B segment.  Global segment s: group g runs local segment u = s - g; u = 2i is A_i, u = 2i + 1 is B_i.
-        // Ring: tile i's K is read during s = 2i, 2i + 1 and its V during 2i + 2, 2i + 3; tile j is staged behind barrier 2j - 4 into the slot tile j - 4 left after
-        // s = 2j - 5, and every wave waits for its own pieces of tile i (counted: tile i + 1 may stay in flight) before barrier 2i.
+        // and waves 4-7 (the second wave of every SIMD: a block's waves are dealt to the SIMDs cyclically) run half a tile out of step with waves 0-3.
 #ifdef MMDUET_ATTN_GRP_LSB
         const int grp = wave & 1;               // (experiment: pairs the waves that do NOT share a SIMD)
 #else
@@ -546,23 +543,21 @@ __global__ __launch_bounds__(WAVES * 64, (NSLOT == 2 && WAVES == 4) ? 2 : 1) voi
         static_assert(!ALLRING || NPC == 2, "counted waits below assume 4 DMAs per wave and tile");
         // start of global segment sg: (even sg) this wave's pieces of tile sg / 2 have landed -- tile sg / 2 + 1 may stay in flight --, every LDS read of the
         // previous segment is done, block barrier, then (even sg) tile sg / 2 + 2 goes out
-        // The DMAs go out at the END of a wave's softmax segments (a DMA issued beside bare MFMAs or at a barrier release costs the wave 60-185 cycles, in a
-        // VALU stretch 25-60): group 0 issues tile i + 2 behind B_i (global segment 2i + 1; its slot, tile i - 2's, is free since 2i - 1), group 1 tile i + 3 behind
-        // B_i (global 2i + 2; tile i - 1's slot is free since 2i + 1); before the loop group 0 has tiles 0, 1 in flight and group 1 tiles 0, 1, 2.
-        auto seg_start = [&](int sg) {
-            if ((sg & 1) == 0 && (sg >> 1) < ntile) {
-                const int i = sg >> 1;
-                const int issued = (grp == 1 && i == 0) ? 2 : i + 1;                 // newest tile this wave has issued by now
-                const int younger = min(issued, ntile - 1) - i;
-                if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
+        // ONE barrier per tile.  Every wave runs the same sequence A_0 B_0 A_1 B_1 ... A_n; group 0 (waves 0-3) has barrier i in front of A_i, group 1 (waves 4-7) in
+        // front of B_(i-1): between barriers i and i + 1 group 0 runs [A_i, B_i] and group 1 [B_(i-1), A_i] -- on every SIMD one wave is in its MFMA segment while the
+        // partner is in its softmax segment, both do the same work per interval (no waiting for the longer of A / B), and both read tile i's K and tile i - 1's V in
+        // interval i.  Ring: tile j is staged during interval j - 2 (group 1 right behind barrier j - 2, where its VALU segment starts; group 0 behind its softmax)
+        // into the slot of tile j - 4, whose V was last read in interval j - 3; every wave waits for its own pieces of tile i -- tile i + 1 may stay in flight --
+        // before barrier i.  A DMA issued beside bare MFMAs costs the wave 60-185 cycles, in a VALU stretch 25-60.
+        auto seg_barrier = [&](int k) {
+            if (k < ntile) { if (k + 1 < ntile) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            ATS(3);                                  // (debug build: [3] = the DMA wait alone, [0] = barrier + DMA issue)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
+            if (grp == 1 && k + 2 < ntile) stage((k + 2) & (NSLOT - 1), kbeg + (long long)(k + 2) * KT);
             ATS(0);
         };
-        auto stage_after_softmax = [&](int i) { const int j = i + 2 + grp; if (j < ntile) stage(j & (NSLOT - 1), kbeg + (long long)j * KT); };
+        auto stage_after_softmax = [&](int i) { if (grp == 0 && i + 2 < ntile) stage((i + 2) & (NSLOT - 1), kbeg + (long long)(i + 2) * KT); };
         auto do_pv = [&](int i) {               // O += P(i) V(i)
             const bf16_t* Vt = kv + (i & (NSLOT - 1)) * 2 * TILE + TILE;
 #pragma unroll
@@ -590,8 +585,8 @@ __global__ __launch_bounds__(WAVES * 64, (NSLOT == 2 && WAVES == 4) ? 2 : 1) voi
                         if (c == 3) __builtin_amdgcn_sched_barrier(0);
                     }
         };
-        // A_i, software-pipelined by hand: eight groups of 4 fragment reads + 8 MFMAs (P.V: half h, output tiles 4q..4q+3; scores: half h, key sub-tile t, the four
-        // 32-dim steps); group g + 1's reads are issued before group g's MFMAs and sched_barriers pin that order -- left alone the compiler hoists all 32 reads
+        // A_i, software-pipelined by hand: eight groups of 4 fragment reads + 8 MFMAs (P.V: half h, output tiles 4q..4q+3; scores: half h, two 32-dim steps x both
+        // key sub-tiles); group g + 1's reads are issued before group g's MFMAs and sched_barriers pin that order -- left alone the compiler hoists all 32 reads
         // (registers), fenced per group it exposes every LDS latency (measured: 2150 cycles for 1024 cycles of MFMA)
         auto a_load = [&](auto G, bf16x8_t (&fr)[4], const bf16_t* Vt, const bf16_t* Ks) {
             constexpr int g = decltype(G)::value;
@@ -600,9 +595,10 @@ __global__ __launch_bounds__(WAVES * 64, (NSLOT == 2 && WAVES == 4) ? 2 : 1) voi
 #pragma unroll
                 for (int u = 0; u < 4; ++u) fr[u] = *reinterpret_cast<const bf16x8_t*>(Vt + ((tq + u) * 16 + lr) * KT + (((h * 4 + lq) ^ vsw) * 8));
             } else {
-                constexpr int h = (g - 4) >> 1, t = (g - 4) & 1;
+                constexpr int h = (g - 4) >> 1, c0 = ((g - 4) & 1) * 2;          // scores: half h, 32-dim steps c0, c0 + 1, both key sub-tiles -- fr[(c - c0) * 2 + t]
 #pragma unroll
-                for (int c = 0; c < 4; ++c) fr[c] = *reinterpret_cast<const bf16x8_t*>(Ks + (h * 32 + (lr >> 2) * 8 + t * 4 + (lr & 3)) * D + (((c * 4 + lq) ^ lr) * 8));
+                for (int u = 0; u < 4; ++u)
+                    fr[u] = *reinterpret_cast<const bf16x8_t*>(Ks + (h * 32 + (lr >> 2) * 8 + (u & 1) * 4 + (lr & 3)) * D + ((((c0 + (u >> 1)) * 4 + lq) ^ lr) * 8));
             }
         };
         auto a_mma = [&](auto G, const bf16x8_t (&fr)[4]) {
@@ -614,12 +610,14 @@ __global__ __launch_bounds__(WAVES * 64, (NSLOT == 2 && WAVES == 4) ? 2 : 1) voi
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt) oacc[rt][tq + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[u], pf[rt][h], oacc[rt][tq + u], 0, 0, 0);
             } else {
-                constexpr int h = (g - 4) >> 1, t = (g - 4) & 1;
+                constexpr int h = (g - 4) >> 1, c0 = ((g - 4) & 1) * 2;          // four independent accumulation chains (rt x t) interleaved: a dependent MFMA is four issues behind its producer
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
+                for (int u = 0; u < 4; ++u)
 #pragma unroll
-                    for (int rt = 0; rt < RT; ++rt)
-                        st[rt][h][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[c], qf[rt][c], c == 0 ? f32x4_t{0, 0, 0, 0} : st[rt][h][t], 0, 0, 0);
+                    for (int rt = 0; rt < RT; ++rt) {
+                        const int c = c0 + (u >> 1), t = u & 1;
+                        st[rt][h][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[u], qf[rt][c], c == 0 ? f32x4_t{0, 0, 0, 0} : st[rt][h][t], 0, 0, 0);
+                    }
             }
         };
         auto do_a = [&](int i) {                // P.V of tile i - 1, scores of tile i
@@ -634,7 +632,8 @@ __global__ __launch_bounds__(WAVES * 64, (NSLOT == 2 && WAVES == 4) ? 2 : 1) voi
         };
         const int lim0[RT] = {(int)((my_limit[0] < kend ? my_limit[0] : kend) - kbeg), (int)((my_limit[RT - 1] < kend ? my_limit[RT - 1] : kend) - kbeg)};      // (a split's key range fits 31 bits)
         auto do_softmax = [&](int i) {          // P(i) from S(i).  ONE running-max decision per row and 64-key tile (both halves' P wait for their P.V in the next segment: a
-                                                // rescale between them would miss the first half), otherwise the arithmetic of the two-slot loop below
+                                                // rescale between them would miss the first half), otherwise the arithmetic of the two-slot loop below.  (Both row tiles'
+                                                // maxima first, one rescale branch, then all 32 exponentials -- more parallel on paper -- measured +10 %: kept row tile by row tile)
             const int t0 = i * KT;                                           // tile-relative to kbeg
             const bool need_mask = (kbeg + t0 + KT > blk_min_limit) || (kbeg + t0 + KT > kend);
 #pragma unroll
@@ -676,45 +675,29 @@ __global__ __launch_bounds__(WAVES * 64, (NSLOT == 2 && WAVES == 4) ? 2 : 1) voi
             }
         };
         if (ntile > 0) {
-            // this wave's segments, in order: A_0 = scores(0); B_0; A_1 = PV(0) + scores(1); B_1; ...; A_n = PV(n - 1).  Group 1 opens with one idle global segment,
-            // group 0 closes with one: both run 2 n + 2 barriers
-            int sg = 0;
-            if (grp == 1) seg_start(sg++);
-            seg_start(sg++);
-            if (wave_active) do_qk(0);
+            if (grp == 1) seg_barrier(0);
+            if (grp == 0) seg_barrier(0);
+            if (wave_active) do_qk(0);                          // A_0
             ATS(1);
-            seg_start(sg++);
-            if (wave_active) do_softmax(0);
+            if (grp == 1) seg_barrier(1);
+            if (wave_active) do_softmax(0);                     // B_0
             stage_after_softmax(0);
             ATS(2);
             for (int i = 1; i < ntile; ++i) {
-                seg_start(sg++);
-#if defined(MMDUET_ATTN_PRIO_A)
-                __builtin_amdgcn_s_setprio(MMDUET_ATTN_PRIO_A);
-#endif
-                if (wave_active) do_a(i);
-#if defined(MMDUET_ATTN_PRIO_A)
-                __builtin_amdgcn_s_setprio(0);
-#endif
+                if (grp == 0) seg_barrier(i);
+                if (wave_active) do_a(i);                       // A_i = P.V(i - 1) + scores(i)
                 ATS(1);
-                seg_start(sg++);
-#if defined(MMDUET_ATTN_PRIO_B)
-                __builtin_amdgcn_s_setprio(MMDUET_ATTN_PRIO_B);
-#endif
-                if (wave_active) do_softmax(i);
-#if defined(MMDUET_ATTN_PRIO_B)
-                __builtin_amdgcn_s_setprio(0);
-#endif
+                if (grp == 1) seg_barrier(i + 1);
+                if (wave_active) do_softmax(i);                 // B_i
                 stage_after_softmax(i);
                 ATS(2);
 #ifdef MMDUET_ATTN_TIMING
                 ats_[4] += 1;
 #endif
             }
-            seg_start(sg++);
-            if (wave_active) do_pv(ntile - 1);
+            if (grp == 0) seg_barrier(ntile);
+            if (wave_active) do_pv(ntile - 1);                  // A_n
             ATS(3);
-            if (grp == 0) seg_start(sg++);
         }
     } else {
     int slot = 0, ti = 0;

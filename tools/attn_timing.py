@@ -21,7 +21,7 @@ for n_chunks in range(12):
     if n_chunks in (0, 3, 7, 11) and t[4]:
         seg = t[0] + t[1] + t[2] + t[3]
         out[n_chunks * 1274] = dict(tiles_per_wave_total=t[4], cycles_per_wave_tile=round(seg / t[4]), wait_barrier_stage=round(t[0] / seg, 3), score_mfma=round(t[1] / seg, 3), softmax=round(t[2] / seg, 3),
-                                    pv_mfma=round(t[3] / seg, 3), loop_share_of_kernel=round(seg / max(1, t[5]), 3))
+                                    pv_mfma_or_dma_wait=round(t[3] / seg, 3), loop_share_of_kernel=round(seg / max(1, t[5]), 3))
         print(n_chunks * 1274, out[n_chunks * 1274], flush=True)
 os.makedirs(os.path.join(R, 'gpurun_out'), exist_ok=True)
 json.dump(out, open(os.path.join(R, 'gpurun_out', 'attn_timing.json'), 'w'), indent=1)
