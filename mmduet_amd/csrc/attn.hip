@@ -907,7 +907,7 @@ static hipError_t launch_gqa128(AttnP& p, const AttnArgs& a, hipStream_t st) {
     const bool chunk8 = RT == 2 && rows_total >= 1024 && !chunk8_off;
     const int qblocks = cdiv(rows_total, chunk8 ? 256 : 64 * RT);
     const int resident = chunk8 ? 256 : 512;                       // blocks the chip holds at once
-    static const double chunk8_unit = getenv("MMDUET_ATTN_CHUNK8_UNIT") ? atof(getenv("MMDUET_ATTN_CHUNK8_UNIT")) : 1.6;
+    static const double chunk8_unit = getenv("MMDUET_ATTN_CHUNK8_UNIT") ? atof(getenv("MMDUET_ATTN_CHUNK8_UNIT")) : 1.0;          // (swept 1.0 .. 2.6 at 0 / 3.8 k / 8.9 k / 14 k keys: flat up to 2.0, 1.0 best at 3.8 k)
     const long long n_tot = a.n_ctx + a.S;
     const int blocks = qblocks * a.nkv;
     const int tiles = cdiv(n_tot, 64);
