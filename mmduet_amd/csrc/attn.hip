@@ -975,7 +975,7 @@ static hipError_t launch_gqa128(AttnP& p, const AttnArgs& a, hipStream_t st) {
 // operand already has -- so no transposed copy of V is ever made.  128 query rows per block (4 waves x 2 row tiles),
 // 64-key tiles, next tile prefetched into registers during the MFMAs.
 // ------------------------------------------------------------------------------------------------------------------
-template <int NC, int DVT, bool F16 = false>      // NC = ceil(d/32) QK k-steps, DVT = max 16-wide output tiles; F16: q / k / v / P / output are IEEE half (the fp16 tower)
+template <int NC, int DVT, bool F16 = false, bool EXACT = false>      // NC = ceil(d/32) QK k-steps, DVT = max 16-wide output tiles (EXACT: ceil(d/16) == DVT, no per-tile `t < dvt` branches); F16: q / k / v / P / output are IEEE half (the fp16 tower)
 __global__ __launch_bounds__(256, 2) void attn_rowmajor_kernel(AttnP p) {
     constexpr int RT = 2, KT = 64, DQ = NC * 32, KLD = DQ + 8;
     constexpr int NCH = DQ / 8;                                 // 16-byte chunks per key row (incl. zero padding)
@@ -984,7 +984,7 @@ __global__ __launch_bounds__(256, 2) void attn_rowmajor_kernel(AttnP p) {
     __shared__ __attribute__((aligned(16))) bf16_t Vs[DVT * 16 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4;
-    const int d = p.d, dvt = (d + 15) >> 4, nch = d >> 3;
+    const int d = p.d, dvt = EXACT ? DVT : (d + 15) >> 4, nch = d >> 3;
     const int G = p.nh / p.nkv;
     int bx, by, bz; xcd_block_id(bx, by, bz);
     const int head = by, kvh = head / G, b = bz;
@@ -1158,11 +1158,11 @@ __global__ __launch_bounds__(256, 2) void attn_rowmajor_kernel(AttnP p) {
     }
 }
 
-template <int NC, int DVT>
+template <int NC, int DVT, bool EXACT = false>
 static hipError_t launch_rowmajor(AttnP& p, const AttnArgs& a, hipStream_t st, bool f16 = false) {
     p.splits = 1; p.kv_per_split = 0;
-    if (f16) hipLaunchKernelGGL((attn_rowmajor_kernel<NC, DVT, true>), dim3(cdiv(a.S, 128), a.nh, a.batch), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((attn_rowmajor_kernel<NC, DVT>), dim3(cdiv(a.S, 128), a.nh, a.batch), dim3(256), 0, st, p);
+    if (f16) hipLaunchKernelGGL((attn_rowmajor_kernel<NC, DVT, true, EXACT>), dim3(cdiv(a.S, 128), a.nh, a.batch), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((attn_rowmajor_kernel<NC, DVT, false, EXACT>), dim3(cdiv(a.S, 128), a.nh, a.batch), dim3(256), 0, st, p);
     return hipGetLastError();
 }
 
@@ -1220,6 +1220,7 @@ hipError_t launch_attention(int dtype, const AttnArgs& a, hipStream_t st) {
         if (!can_rowmajor) return hipErrorInvalidValue;
         if (a.d <= 32) return launch_rowmajor<1, 2>(p, a, st, f16);
         if (a.d <= 64) return launch_rowmajor<2, 4>(p, a, st, f16);
+        if (a.d > 64 && a.d <= 80) return launch_rowmajor<3, 5, true>(p, a, st, f16);          // SigLIP-so400m: 72 -> five 16-wide output tiles, known at compile time
         if (a.d <= 96) return launch_rowmajor<3, 6>(p, a, st, f16);
         return launch_rowmajor<4, 8>(p, a, st, f16);
     }
