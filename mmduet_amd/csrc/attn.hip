@@ -528,6 +528,12 @@ __global__ __launch_bounds__(WAVES * 64, (NSLOT == 2 && WAVES == 4) ? 2 : 1) voi
     if constexpr (NSLOT == 4 && !ALLRING) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     ATS_DECL;
     if constexpr (ALLRING) {
+        // The q fragments come from ordinary global loads; their first use sits behind a branch (wave_active), so hipcc would place its wait for them -- a full vmcnt(0),
+        // which also drains the ring's DMAs -- at the score MFMAs INSIDE the tile loop, every tile.  Touch them here: the wait happens once, before the loop.
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) asm volatile("" :: "v"(qf[rt][c]));
         // Phase-split loop.  Left to itself every wave runs score MFMAs -> softmax -> P.V MFMAs in the same order behind the same per-tile barrier, so the two waves
         // of a SIMD want the matrix pipe together and the VALU together (tools/attn_timing.py: ~6400 cycles per wave and tile for 1024 cycles of MFMA).  Here a
         // wave's tile i is two SEGMENTS,

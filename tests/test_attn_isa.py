@@ -1,0 +1,70 @@
+"""ISA audit of the ring forms of the LLM attention kernel (attn_gqa128_kernel<2, 4, 8> chunks, <1, 4> decode): their K / V tiles arrive by LDS-DMA three tiles deep and are
+waited for with COUNTED `s_waitcnt vmcnt(N)`.  Two silent compiler-side regressions would undo that without failing a parity test: a register spill inside the tile loop
+(scratch reloads are VMEM: hipcc puts `vmcnt(0)` behind each one and drains the ring) and a compiler-inserted `vmcnt(0)` in the loop (an ordinary global load or a second
+LDS object next to the DMAs).  Cross-compiles attn.hip for gfx950 with the Makefile's flags (no GPU needed) and reads the ISA."""
+import os, re, shutil, subprocess, tempfile
+import pytest
+from conftest import ROOT
+
+HIPCC = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason='needs hipcc')
+
+
+@pytest.fixture(scope='module')
+def attn_isa():
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, 'attn.s')
+        r = subprocess.run([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-fno-honor-nans', '-Wno-unused-result', '-Wno-unused-value',
+                            '--cuda-device-only', '-S', '-o', out, os.path.join(ROOT, 'mmduet_amd', 'csrc', 'attn.hip')], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return open(out).read()
+
+
+def _kernel(s, mangled):
+    m = re.search(r'^' + re.escape(mangled) + r':', s, re.M)
+    assert m, f'{mangled} not in the ISA'
+    body = s[m.start():]
+    end = body.index('s_endpgm')
+    meta = body[end:end + 8000]
+    return body[:end].split('\n'), meta
+
+
+def _loop(lines):
+    inl = [i for i, l in enumerate(lines) if re.search(r'in Loop: Header=BB\d+_\d+ Depth=1', l)]
+    assert inl
+    return lines[min(inl) - 1:max(inl) + 2]
+
+
+def test_chunk_ring_kernel_has_no_spills_and_only_counted_waits(attn_isa):
+    lines, meta = _kernel(attn_isa, '_Z18attn_gqa128_kernelILi2ELi4ELi8EEv5AttnP')
+    assert not any('scratch_' in l for l in lines), 'the chunk attention spills'
+    assert re.search(r'; ScratchSize: 0\b', meta)
+    vg = int(re.search(r'; NumVgprs: (\d+)', meta).group(1))
+    assert vg <= 256                                            # 8 waves per CU
+    loop = _loop(lines)
+    assert sum('s_barrier' in l for l in loop) == 1             # one barrier per tile
+    assert sum('v_mfma_f32_16x16x32_bf16' in l for l in loop) == 64
+    assert sum('global_load_lds_dwordx4' in l for l in loop) == 8          # this wave's 4 pieces, once for either group's issue point
+    # every vmcnt wait in the loop is one of seg_barrier's hand-written ones (inside an inline-asm block: vmcnt(4) with a tile in flight, vmcnt(0) at the end of the
+    # keys); hipcc's own would sit outside ASMSTART / ASMEND (it once put `vmcnt(0) lgkmcnt(0)` in front of the score MFMAs for the q fragments' loads: every tile)
+    waits = [(i, l.strip()) for i, l in enumerate(loop) if 'vmcnt' in l]
+    assert len(waits) >= 2
+    for i, w in waits:
+        assert w in ('s_waitcnt vmcnt(0)', 's_waitcnt vmcnt(4)'), w
+        assert 'ASMSTART' in loop[i - 1], (w, loop[i - 1])
+    assert not any(re.match(r'\s*global_load_dword', l) for l in loop), 'an ordinary global load inside the ring loop'
+
+
+def test_decode_ring_kernel_loaders_use_counted_waits(attn_isa):
+    lines, meta = _kernel(attn_isa, '_Z18attn_gqa128_kernelILi1ELi4ELi4EEv5AttnP')
+    assert not any('scratch_' in l for l in lines), 'the decode attention spills'
+    text = '\n'.join(lines)
+    for n in (22, 20, 11, 10):                                  # loaders: 11 / 11 / 10 DMA pieces per tile, one or two younger tiles in flight
+        assert re.search(rf's_waitcnt vmcnt\({n}\)', text), n
+    assert len(re.findall(r'global_load_lds_dwordx4 .* nt', text)) >= 11          # K / V stream with the nt policy
+
+
+def test_two_slot_forms_unchanged(attn_isa):
+    for name in ('_Z18attn_gqa128_kernelILi2ELi2ELi4EEv5AttnP', '_Z18attn_gqa128_kernelILi1ELi2ELi4EEv5AttnP'):
+        lines, meta = _kernel(attn_isa, name)
+        assert not any('scratch_' in l for l in lines), name
