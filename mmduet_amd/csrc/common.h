@@ -128,6 +128,8 @@ struct GemmArgs {
     int variant;
     float* splitk_ws; size_t splitk_ws_bytes;   // fp32 partial slabs
     int no_gemv = 0;                            // A/B switch: use the LDS-staged skinny kernel also for M <= 16
+    int* ring_slabs_out = nullptr;              // if set: a split-K tile GEMM (ring / 128-row) leaves its [splits][M][N] fp32 slabs in splitk_ws and reports the count here
+                                                // (0 = the GEMM ran unsplit and applied its epilogue itself); the caller consumes them with launch_slab_resid_rmsnorm
     int* slabs_out = nullptr;                   // if set (packed skinny path only): leave [splits][M][N] fp32 slabs in splitk_ws, no
                                                 // epilogue, and return the split count here; a fused consumer kernel reduces them
     int ring_flags = 16;                        // ring GEMM instantiation the auto dispatch uses (launch_ringx flags; 16 = 8 waves, 256 x 256, early refill)

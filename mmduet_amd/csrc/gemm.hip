@@ -922,6 +922,7 @@ static void launch_big(const GemmP& p, const GemmArgs& a, hipStream_t st) {
         default: hipLaunchKernelGGL((gemm_big_kernel<BN, EPI_NONE>), grid, dim3(256), 0, st, p, KT); break;
     }
     if (splits > 1) {
+        if (a.ring_slabs_out) { *a.ring_slabs_out = splits; return; }          // the caller folds the slabs itself (reduce + residual + RMSNorm in one pass)
         long long work = (long long)a.M * ((a.N + 3) / 4);
         hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), dim3(cdiv(work, 256)), dim3(256), 0, st, p, splits);
     }
@@ -976,6 +977,7 @@ static hipError_t launch_ringx_t(const GemmP& p, const GemmArgs& a, hipStream_t 
         default: hipLaunchKernelGGL((gemm_ringx_kernel<EPI_NONE, WN, M32, NS, EARLY>), grid, block, smem, st, q, KT); break;
     }
     if (splits > 1) {
+        if (a.ring_slabs_out) { *a.ring_slabs_out = splits; return hipGetLastError(); }
         long long work = (long long)a.M * ((a.N + 3) / 4);
         hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), dim3(cdiv(work, 256)), dim3(256), 0, st, p, splits);
     }
@@ -1037,6 +1039,7 @@ static hipError_t launch_t(const GemmArgs& a, hipStream_t st, int* kind_out) {
     p.ldx = a.ldx; p.ldw = a.ldw; p.ldr = a.ldr; p.ldy = a.ldy;
     p.M = a.M; p.N = a.N; p.K = a.K; p.epi = a.epi; p.out_f32 = a.out_f32; p.slabs = a.slabs_out ? 1 : 0; p.dump = nullptr;
     p.vec = (sizeof(T) == 2 && (a.ldx % 8) == 0 && (a.ldw % 8) == 0 && ((uintptr_t)a.X % 16) == 0 && ((uintptr_t)a.W % 16) == 0) ? 1 : 0;
+    if (a.ring_slabs_out) *a.ring_slabs_out = 0;
     if (a.M <= 0 || a.N <= 0) return hipSuccess;
     int variant = a.variant;
     bool skinny = (variant == GEMM_SKINNY) || (variant == GEMM_AUTO && a.M <= 64);

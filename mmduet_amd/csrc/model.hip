@@ -89,6 +89,7 @@ struct mmd_ctx {
     bool no_fuse = false;              // MMDUET_NO_FUSE=1: keep the unfused launch schedule (A/B and parity cross-check)
     bool gemm_half = false;            // the GEMMs issued right now belong to the fp16 vision tower (cfg.tower_f16): IEEE-half operands
     int tower_ring_flags = -1, tower_ring_blocks = 0;   // MMDUET_TOWER_RING / MMDUET_TOWER_RING_BLOCKS: ring GEMM form of the tower (co-residency experiments)
+    bool no_slab_norm = false;         // MMDUET_NO_SLAB_NORM=1: a chunk's split-K down_proj keeps splitk_reduce + a separate RMSNorm launch (A/B)
     bool no_chain = false;             // MMDUET_NO_CHAIN=1: decode steps keep the separate reduce+residual+RMSNorm launches (A/B)
     void* rope_tab = 0;                // (cos, sin) of a decode step's positions (launch_rope_table), read by the attention kernel's fused q/k/v preparation
     bool no_rope_fuse = false;         // MMDUET_NO_ROPE_FUSE=1: decode steps keep the slab_rope_append launch (A/B)
@@ -163,8 +164,8 @@ static void prof_drain(mmd_ctx* c) {
 // ---- GEMM wrapper --------------------------------------------------------------------------------------------------
 static int gemm(mmd_ctx* c, const void* X, int64_t ldx, const void* W, int64_t ldw, const void* bias, const void* R, int64_t ldr, void* Y,
                 int64_t ldy, int M, int N, int K, int epi, int out_f32 = 0, int variant = GEMM_AUTO, const void* Wp = nullptr, bool tower = false,
-                const void* Wp8 = nullptr, const float* wscale = nullptr, const GemvChain* chain = nullptr) {
-    GemmArgs a; a.chain = chain;
+                const void* Wp8 = nullptr, const float* wscale = nullptr, const GemvChain* chain = nullptr, int* ring_slabs_out = nullptr) {
+    GemmArgs a; a.chain = chain; a.ring_slabs_out = ring_slabs_out;
     a.X = X; a.ldx = ldx; a.W = W; a.ldw = ldw; a.Wp = Wp; a.bias = bias; a.R = R; a.ldr = ldr; a.Y = Y; a.ldy = ldy;
     a.M = M; a.N = N; a.K = K; a.epi = epi; a.out_f32 = out_f32; a.variant = variant; a.Wp8 = Wp8; a.wscale = wscale;
     a.splitk_ws = tower ? c->v_splitk_ws : c->splitk_ws; a.splitk_ws_bytes = tower ? c->v_splitk_bytes : c->splitk_bytes;
@@ -204,6 +205,7 @@ extern "C" int mmd_create(const mmd_config* cfg, int device, mmd_ctx** out) {
     c->qkv_w = cfg->vision_only ? 0 : (cfg->num_heads + 2 * cfg->num_kv_heads) * cfg->head_dim;
     { const char* nf = getenv("MMDUET_NO_FUSE"); c->no_fuse = nf && nf[0] == '1'; }
     { const char* nf = getenv("MMDUET_NO_CHAIN"); c->no_chain = nf && nf[0] == '1'; }
+    { const char* nf = getenv("MMDUET_NO_SLAB_NORM"); c->no_slab_norm = nf && nf[0] == '1'; }
     { const char* nf = getenv("MMDUET_NO_ROPE_FUSE"); c->no_rope_fuse = nf && nf[0] == '1'; }
     { const char* e = getenv("MMDUET_TOWER_RING"); if (e) c->tower_ring_flags = atoi(e); e = getenv("MMDUET_TOWER_RING_BLOCKS"); if (e) c->tower_ring_blocks = atoi(e); }
     // graph replay of the decode step is opt-in (MMDUET_GRAPH=1): measured on MI355X it is not faster than eager launches
@@ -1123,6 +1125,7 @@ static int llm_step_segs(mmd_ctx* c, const StepSeg* segs, int nseg, const void* 
     // rows <= 4, head_dim 128: the attention kernel prepares q / k / v from the qkv slabs itself (AttnArgs::qkv_slabs)
     const bool rope_fused = chain && d == 128 && !c->no_rope_fuse;
     if (rope_fused) HIPCHK(c, launch_rope_table(c->rope_tab, S, 64, c->inv_freq, n, st, dyn));
+    bool xn_ready = false;             // the previous layer's fused slab consumer already left this layer's normalised input in l_xn
     for (int i = 0; i < g.num_layers; ++i) {
         LlmLayer& L = c->L[i];
         void* Kl = (char*)s->K + (size_t)i * layer_elems * e;
@@ -1136,7 +1139,8 @@ static int llm_step_segs(mmd_ctx* c, const StepSeg* segs, int nseg, const void* 
                 HIPCHK(c, launch_slab_rope_append(c->splitk_ws, splits, L.bqkv, S, nh, nkv, d, c->inv_freq, n, c->l_q, Kl, Vl, s->cap, st, dyn, i));
             }
         } else {
-            { ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * S * H * e, 0); HIPCHK(c, launch_rmsnorm(dt, c->l_h, L.ln1, c->l_xn, S, H, g.rms_norm_eps, st)); }
+            if (!xn_ready) { ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * S * H * e, 0); HIPCHK(c, launch_rmsnorm(dt, c->l_h, L.ln1, c->l_xn, S, H, g.rms_norm_eps, st)); }
+            xn_ready = false;
             rc = gemm(c, c->l_xn, H, L.wqkv, H, L.bqkv, nullptr, 0, c->l_qkv, c->qkv_w, S, c->qkv_w, H, EPI_NONE, 0, GEMM_AUTO, L.wqkv_p, false, L.wqkv_8, L.sqkv); if (rc) return rc;
             ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * S * c->qkv_w * e, 0);
             for (int j = 0; j < nseg; ++j) {
@@ -1188,10 +1192,19 @@ static int llm_step_segs(mmd_ctx* c, const StepSeg* segs, int nseg, const void* 
             rc = gemm(c, c->l_attn, (int64_t)nh * d, L.wo, (int64_t)nh * d, nullptr, c->l_h, H, c->l_h, H, S, H, nh * d, EPI_RESID, 0, GEMM_AUTO, L.wo_p, false, L.wo_8, L.so); if (rc) return rc;
             { ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * S * H * e, 0); HIPCHK(c, launch_rmsnorm(dt, c->l_h, L.ln2, c->l_xn, S, H, g.rms_norm_eps, st)); }
             rc = gemm(c, c->l_xn, H, L.wgu, H, nullptr, nullptr, 0, c->l_act, I, S, 2 * I, H, EPI_SWIGLU, 0, GEMM_AUTO, L.wgu_p, false, L.wgu_8, L.sgu); if (rc) return rc;
-            rc = gemm(c, c->l_act, I, L.wdown, I, nullptr, c->l_h, H, c->l_h, H, S, H, I, EPI_RESID, 0, GEMM_AUTO, L.wdown_p, false, L.wdown_8, L.sdown); if (rc) return rc;
+            // a split-K down_proj (long K, under one block wave of tiles: every chunk) leaves its fp32 slabs; ONE pass then sums them, adds the residual stream, and
+            // normalises for the next layer (or the final norm) -- instead of splitk_reduce (+ residual) followed by a separate RMSNorm launch re-reading the row
+            int rs = 0;
+            rc = gemm(c, c->l_act, I, L.wdown, I, nullptr, c->l_h, H, c->l_h, H, S, H, I, EPI_RESID, 0, GEMM_AUTO, L.wdown_p, false, L.wdown_8, L.sdown, nullptr,
+                      (dt == MMD_BF16 && H <= 4096 && (H & 3) == 0 && !c->no_fuse && !c->no_slab_norm && L.sdown == nullptr) ? &rs : nullptr); if (rc) return rc;          // (fp8 matrices: the per-channel scale lives in the reduce's epilogue)
+            if (rs > 1) {
+                ProfScope ps(c, MMD_K_NORM_ROPE, 4.0 * S * H * e + 4.0 * rs * S * H, 0);
+                HIPCHK(c, launch_slab_resid_rmsnorm(c->splitk_ws, rs, S, H, c->l_h, c->l_h, next_norm, g.rms_norm_eps, next_xn, st));
+                xn_ready = true;
+            }
         }
     }
-    if (!fused) { ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * S * H * e, 0); HIPCHK(c, launch_rmsnorm(dt, c->l_h, c->fnorm, c->l_hid, S, H, g.rms_norm_eps, st)); }
+    if (!fused && !xn_ready) { ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * S * H * e, 0); HIPCHK(c, launch_rmsnorm(dt, c->l_h, c->fnorm, c->l_hid, S, H, g.rms_norm_eps, st)); }
     if (hidden_out) HIPCHK(c, hipMemcpyAsync(hidden_out, c->l_hid, (size_t)S * H * e, hipMemcpyDeviceToDevice, st));
     if (!dyn) for (int j = 0; j < nseg; ++j) segs[j].s->len += segs[j].rows;
     return MMD_OK;

@@ -128,7 +128,7 @@ from mmduet_amd.modeling_live import VideoHeadLiveLlavaQwenForCausalLM
 ocfg = O.OracleConfig(vocab_size=2048, num_hidden_layers=2, vit_layers=1)
 w = {k: v for k, v in O.random_weights(ocfg, seed=3, dtype=torch.bfloat16, scale="unit").items()}
 pcfg = VideoHeadLiveLlavaQwenConfig(vocab_size=2048, num_hidden_layers=2, vit_num_hidden_layers=2, vit_layers_removed=1, frame_num_tokens=49, frame_resolution=384)
-m = VideoHeadLiveLlavaQwenForCausalLM(pcfg, torch_dtype=torch.bfloat16, max_vit_batch=1, max_step_tokens=128, kv_initial_tokens=int(os.environ.get('MMD_KV_TOKENS', 512)))
+m = VideoHeadLiveLlavaQwenForCausalLM(pcfg, torch_dtype=torch.bfloat16, max_vit_batch=1, max_step_tokens=int(os.environ.get('MMD_MAX_STEP', 128)), kv_initial_tokens=int(os.environ.get('MMD_KV_TOKENS', 512)))
 m.load_state_dict(w)
 g = torch.Generator().manual_seed(5)
 c = None; res = []
@@ -170,6 +170,14 @@ print("RES " + json.dumps(res))
     assert got[-5:] == run(long_ctx, MMDUET_NO_FUSE='0', MMDUET_ATTN_DECODE_RING='0', MMD_KV_TOKENS='16384')[-5:]
     mid = ','.join(['100'] * 4 + ['1', '2', '1'] + ['128'] * 3 + ['1', '1', '2'] + ['128'] * 40 + ['1', '2'])          # contexts 400 / 790 / 5.9 k: 1 / 1 / 2 tiles per split
     assert run(mid, MMDUET_NO_FUSE='0', MMD_KV_TOKENS='8192') == run(mid, MMDUET_NO_FUSE='0', MMDUET_ATTN_DECODE_RING='0', MMD_KV_TOKENS='8192')
+    # a chunk's split-K down_proj folded by ONE reduce + residual + RMSNorm pass (M >= 512, K = 18944) against splitk_reduce followed by the RMSNorm launch: same
+    # slabs, same slab order, same rounding points of the residual stream; the row's sum of squares is accumulated in another order (256 threads x 4 columns vs
+    # one wave x 8 columns), so the normalised activations agree to bf16 rounding, not to the bit.  Two chunks: the second consumes the first one's fused output
+    chunk = '640,700,1'
+    fa, fb = run(chunk, MMDUET_NO_FUSE='0', MMD_MAX_STEP='768', MMD_KV_TOKENS='2048'), run(chunk, MMDUET_NO_FUSE='0', MMDUET_NO_SLAB_NORM='1', MMD_MAX_STEP='768', MMD_KV_TOKENS='2048')
+    assert fa == run(chunk, MMDUET_NO_FUSE='0', MMD_MAX_STEP='768', MMD_KV_TOKENS='2048')                  # deterministic
+    for ra, rb in zip(fa, fb):
+        assert ra == pytest.approx(rb, abs=2e-2, rel=2e-2)
     ref = run(long_ctx, MMDUET_NO_FUSE='1', MMD_KV_TOKENS='16384')          # unfused launch schedule throughout
     for ra, rb in zip(got[-5:], ref[-5:]):
         assert ra == pytest.approx(rb, abs=3e-2, rel=3e-2)
