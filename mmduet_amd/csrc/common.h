@@ -159,6 +159,7 @@ hipError_t launch_slab_rope_append(const float* slabs, int splits, const void* b
 hipError_t launch_rope_table(void* tab, int S, int half, const float* inv_freq_dev, int64_t pos0, hipStream_t st, const StepState* dyn = nullptr);   // float2 [S][half], bf16-rounded
 hipError_t launch_advance_state(StepState* st_dev, const int64_t* tok_dev, int64_t* prev_dev, int prev_cap, int64_t eos, int use_penalty, hipStream_t st);
 hipError_t launch_add_rows(int dtype, void* x, const void* add, int M, int H, int period, hipStream_t st);   // x[m,:] += add[m % period,:]
+hipError_t launch_rope_append_chunk(const void* qkv, int S, int nh, int nkv, const void* tab, int64_t pos0, void* q_out, void* Kc, void* Vc, int64_t cap, hipStream_t st);   // bf16, d = 128, transposed V, table from launch_rope_table
 hipError_t launch_rope_append(int dtype, const void* qkv, int S, int nh, int nkv, int d, const float* inv_freq_dev, int64_t pos0, void* q_out,
                               void* Kc, void* Vc, int64_t cap, int v_transposed, hipStream_t st);
 hipError_t launch_transpose_v(int dtype, const void* src, void* dst, int nkv, int64_t cap, int d, hipStream_t st);

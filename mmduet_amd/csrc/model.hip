@@ -541,7 +541,7 @@ static int alloc_workspaces(mmd_ctx* c) {
     WS(c->l_q, (size_t)S * g.num_heads * g.head_dim * e); WS(c->l_attn, (size_t)S * g.num_heads * g.head_dim * e);
     WS(c->l_act, (size_t)S * g.intermediate_size * e); WS(c->l_hid, (size_t)S * H * e);
     c->splitk_bytes = (size_t)64 << 20; WS(c->splitk_ws, c->splitk_bytes);
-    WS(c->chain_ssq, (size_t)GEMV_CHAIN_ROWS * GEMV_SSQ_STRIDE * sizeof(float)); WS(c->rope_tab, (size_t)GEMV_CHAIN_ROWS * 64 * 2 * sizeof(float));
+    WS(c->chain_ssq, (size_t)GEMV_CHAIN_ROWS * GEMV_SSQ_STRIDE * sizeof(float)); WS(c->rope_tab, (size_t)S * 64 * 2 * sizeof(float));          // (cos, sin) of a step's positions: decode steps and, since round 3, chunks
     c->attn_bytes = (size_t)128 << 20; WS(c->attn_ws, c->attn_bytes);
     WS(c->logits_ws, (size_t)g.vocab_size * sizeof(float));
     WS(c->heads_dev, (size_t)S * 4 * sizeof(float)); WS(c->rows_dev, (size_t)S * sizeof(int32_t));
@@ -1125,6 +1125,10 @@ static int llm_step_segs(mmd_ctx* c, const StepSeg* segs, int nseg, const void* 
     // rows <= 4, head_dim 128: the attention kernel prepares q / k / v from the qkv slabs itself (AttnArgs::qkv_slabs)
     const bool rope_fused = chain && d == 128 && !c->no_rope_fuse;
     if (rope_fused) HIPCHK(c, launch_rope_table(c->rope_tab, S, 64, c->inv_freq, n, st, dyn));
+    // chunks (bf16, head_dim 128): one (cos, sin) table per step and segment, read by the vectorised RoPE + append kernel of every layer; MMDUET_NO_CHUNK_ROPE=1 keeps the scalar kernel
+    static const bool no_chunk_rope = getenv("MMDUET_NO_CHUNK_ROPE") != nullptr;
+    const bool chunk_rope = !fused && dt == MMD_BF16 && d == 128 && S >= 64 && !no_chunk_rope && !c->no_fuse;
+    if (chunk_rope) for (int j = 0; j < nseg; ++j) HIPCHK(c, launch_rope_table((char*)c->rope_tab + (size_t)segs[j].row0 * 64 * 8, segs[j].rows, 64, c->inv_freq, segs[j].s->len, st, nullptr));
     bool xn_ready = false;             // the previous layer's fused slab consumer already left this layer's normalised input in l_xn
     for (int i = 0; i < g.num_layers; ++i) {
         LlmLayer& L = c->L[i];
@@ -1146,6 +1150,11 @@ static int llm_step_segs(mmd_ctx* c, const StepSeg* segs, int nseg, const void* 
             for (int j = 0; j < nseg; ++j) {
                 mmd_stream* sj = segs[j].s;
                 const size_t le = kv_layer_elems(c, sj->cap);
+                if (chunk_rope) {          // vectorised form over the step's (cos, sin) table (built once, before the layer loop)
+                    HIPCHK(c, launch_rope_append_chunk((char*)c->l_qkv + (size_t)segs[j].row0 * c->qkv_w * e, segs[j].rows, nh, nkv, (char*)c->rope_tab + (size_t)segs[j].row0 * 64 * 8, sj->len,
+                                                       (char*)c->l_q + (size_t)segs[j].row0 * nh * d * e, (char*)sj->K + (size_t)i * le * e, (char*)sj->V + (size_t)i * le * e, sj->cap, st));
+                    continue;
+                }
                 HIPCHK(c, launch_rope_append(dt, (char*)c->l_qkv + (size_t)segs[j].row0 * c->qkv_w * e, segs[j].rows, nh, nkv, d, c->inv_freq, sj->len,
                                              (char*)c->l_q + (size_t)segs[j].row0 * nh * d * e, (char*)sj->K + (size_t)i * le * e, (char*)sj->V + (size_t)i * le * e,
                                              sj->cap, 1, st));

@@ -299,6 +299,74 @@ __global__ void rope_append_kernel(const T* __restrict__ qkv, int S, int nh, int
     }
 }
 
+// The same for a CHUNK (bf16, head_dim 128, transposed V arena; S = hundreds of tokens): 16-byte loads / stores, (cos, sin) from the step's table
+// (launch_rope_table: evaluated once per step instead of per layer and head), V through an LDS transpose so that the arena's 64-token rows are written as
+// rows.  Same arithmetic and rounding points as rope_append_kernel (the table holds rnd(cosf), rnd(sinf) of the same fp32 angle).  One launch:
+// blocks [0, S) rotate q and k of one token (256 threads = 32 heads x 8 lanes; more heads loop), blocks [S, S + nblk * nkv) transpose one
+// (64-token arena block, kv head) of v.  The scalar kernel above took 16 us per layer at S = 1274 (cosf / sinf per element and head, 2-byte scatter stores).
+__global__ __launch_bounds__(256) void rope_append_chunk_kernel(const bf16_t* __restrict__ qkv, int S, int nh, int nkv, const float2* __restrict__ tab, long long pos0,
+                                                                bf16_t* __restrict__ q_out, bf16_t* __restrict__ Kc, bf16_t* __restrict__ Vc, long long cap) {
+    constexpr int D = 128;
+    __shared__ __attribute__((aligned(16))) bf16_t vt[64 * (D + 8)];
+    const int tid = threadIdx.x;
+    const int row_w = (nh + 2 * nkv) * D;
+    if ((int)blockIdx.x < S) {
+        const int s = blockIdx.x, part = tid & 7;
+        const long long pos = pos0 + s;
+        f32x4_t cs[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) cs[u] = *reinterpret_cast<const f32x4_t*>(tab + (long long)s * (D / 2) + part * 8 + u * 2);      // (cos, sin) of elements part*8 + 2u, + 2u + 1
+        for (int head = tid >> 3; head < nh + nkv; head += 32) {
+            const bf16_t* src = qkv + (long long)s * row_w + (long long)head * D + part * 8;
+            const s16x8_t a = *reinterpret_cast<const s16x8_t*>(src), b = *reinterpret_cast<const s16x8_t*>(src + D / 2);
+            s16x8_t o1, o2;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float c = cs[e >> 1][(e & 1) * 2], sn = cs[e >> 1][(e & 1) * 2 + 1];
+                const float x1 = bf2f((bf16_t)a[e]), x2 = bf2f((bf16_t)b[e]);
+                o1[e] = (short)f2bf(bf2f(f2bf(x1 * c)) + bf2f(f2bf(-x2 * sn)));
+                o2[e] = (short)f2bf(bf2f(f2bf(x2 * c)) + bf2f(f2bf(x1 * sn)));
+            }
+            bf16_t* dst = head < nh ? q_out + (long long)s * nh * D + (long long)head * D : Kc + ((long long)(head - nh) * cap + pos) * D;
+            *reinterpret_cast<s16x8_t*>(dst + part * 8) = o1;
+            *reinterpret_cast<s16x8_t*>(dst + D / 2 + part * 8) = o2;
+        }
+        return;
+    }
+    // v: arena block b (positions [64 b, 64 b + 64)) of kv head kvh; tokens of this step inside it: [lo, hi)
+    const int vb = blockIdx.x - S;
+    const int kvh = vb % nkv;
+    const long long b = (pos0 >> 6) + vb / nkv;
+    const long long lo = b * 64 > pos0 ? b * 64 : pos0, hi = (b + 1) * 64 < pos0 + S ? (b + 1) * 64 : pos0 + S;
+    for (int i = tid; i < 64 * (D / 8); i += 256) {              // [token][16-byte chunk]
+        const int t = i >> 4, ch = i & 15;
+        const long long pos = b * 64 + t;
+        if (pos >= lo && pos < hi)
+            *reinterpret_cast<s16x8_t*>(vt + t * (D + 8) + ch * 8) = *reinterpret_cast<const s16x8_t*>(qkv + (pos - pos0) * row_w + (long long)(nh + nkv + kvh) * D + ch * 8);
+    }
+    __syncthreads();
+    bf16_t* dstb = Vc + (long long)kvh * cap * D + ((b * D) << 6);          // (tok, e) at ((tok >> 6) * d + e) * 64 + (tok & 63)
+    for (int i = tid; i < D * 8; i += 256) {                     // [e][group of 8 tokens]
+        const int e = i >> 3, g8 = i & 7;
+        const long long p0 = b * 64 + g8 * 8;
+        if (p0 >= lo && p0 + 8 <= hi) {
+            s16x8_t o;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = (short)vt[(g8 * 8 + k) * (D + 8) + e];
+            *reinterpret_cast<s16x8_t*>(dstb + ((long long)e << 6) + g8 * 8) = o;
+        } else {
+            for (int k = 0; k < 8; ++k) if (p0 + k >= lo && p0 + k < hi) dstb[((long long)e << 6) + g8 * 8 + k] = vt[(g8 * 8 + k) * (D + 8) + e];
+        }
+    }
+}
+hipError_t launch_rope_append_chunk(const void* qkv, int S, int nh, int nkv, const void* tab, int64_t pos0, void* q_out, void* Kc, void* Vc, int64_t cap, hipStream_t st) {
+    if (S <= 0) return hipSuccess;
+    const int nblk = (int)(((pos0 + S - 1) >> 6) - (pos0 >> 6) + 1);
+    hipLaunchKernelGGL(rope_append_chunk_kernel, dim3(S + nblk * nkv), dim3(256), 0, st, (const bf16_t*)qkv, S, nh, nkv, (const float2*)tab, (long long)pos0,
+                       (bf16_t*)q_out, (bf16_t*)Kc, (bf16_t*)Vc, (long long)cap);
+    return hipGetLastError();
+}
+
 hipError_t launch_rope_append(int dtype, const void* qkv, int S, int nh, int nkv, int d, const float* l2, int64_t pos0, void* q_out,
                               void* Kc, void* Vc, int64_t cap, int v_tr, hipStream_t st) {
     if (S <= 0) return hipSuccess;

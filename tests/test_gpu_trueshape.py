@@ -178,6 +178,11 @@ print("RES " + json.dumps(res))
     assert fa == run(chunk, MMDUET_NO_FUSE='0', MMD_MAX_STEP='768', MMD_KV_TOKENS='2048')                  # deterministic
     for ra, rb in zip(fa, fb):
         assert ra == pytest.approx(rb, abs=2e-2, rel=2e-2)
+    # the chunk's vectorised RoPE + KV append (per-step cos / sin table, LDS-transposed V) against the scalar kernel: same arithmetic -> same bits; the chunks start at
+    # positions 0 / 640 / 1340 (partial 64-token arena blocks at both ends of the V transpose), then a decode row reads the arena back
+    assert fa == run(chunk, MMDUET_NO_FUSE='0', MMDUET_NO_CHUNK_ROPE='1', MMD_MAX_STEP='768', MMD_KV_TOKENS='2048')
+    odd = '70,333,129,1,64,2'
+    assert run(odd, MMDUET_NO_FUSE='0', MMD_MAX_STEP='384', MMD_KV_TOKENS='1024') == run(odd, MMDUET_NO_FUSE='0', MMDUET_NO_CHUNK_ROPE='1', MMD_MAX_STEP='384', MMD_KV_TOKENS='1024')
     ref = run(long_ctx, MMDUET_NO_FUSE='1', MMD_KV_TOKENS='16384')          # unfused launch schedule throughout
     for ra, rb in zip(got[-5:], ref[-5:]):
         assert ra == pytest.approx(rb, abs=3e-2, rel=3e-2)
