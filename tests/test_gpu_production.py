@@ -170,7 +170,10 @@ def _ref_attention_gpu(q, K, V, nh, nkv, d, n_ctx):
     return out.transpose(0, 1).reshape(S, nh * d)
 
 
-@pytest.mark.parametrize('S,n_ctx', [(1274, 0), (1274, 15000), (1274, 30000), (1323, 8000), (49, 30000), (131, 15000)])
+# (147 rows x 7 heads = 1029 rows per kv head: the smallest step on the 256-row phase-split kernel; 146 stays on the 128-row form; 1 / 2 / 3 key tiles per split, a partial
+#  last query block, new positions on tile boundaries, contexts deep enough for every ring slot to be refilled many times)
+@pytest.mark.parametrize('S,n_ctx', [(1274, 0), (1274, 15000), (1274, 30000), (1323, 8000), (49, 30000), (131, 15000),
+                                     (147, 0), (146, 0), (147, 1), (150, 63), (183, 64), (200, 100), (300, 70000), (637, 3), (1911, 27000), (2058, 127), (512, 4097)])
 def test_chunk_attention_at_production_sizes(ops, S, n_ctx):
     """attn_gqa128_kernel (variant 3: the arena layout with V transposed in 64-token blocks) incl. the cost-model split-KV + merge.
     tolerance: 1.8e-2 x max(1, |ref|max): bf16 P and bf16 output rounding."""
