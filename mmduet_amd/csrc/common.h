@@ -153,7 +153,7 @@ hipError_t launch_rmsnorm(int dtype, const void* x, const void* w, void* y, int 
 hipError_t launch_layernorm(int dtype, const void* x, const void* w, const void* b, void* y, int M, int H, float eps, hipStream_t st);
 // fused consumers of skinny-GEMM slabs (ops.hip)
 hipError_t launch_slab_resid_rmsnorm(const float* slabs, int splits, int M, int H, const void* resid_in, void* h_out, const void* norm_w, float eps,
-                                     void* xn_out, hipStream_t st);
+                                     void* xn_out, hipStream_t st, const float* wscale = nullptr);
 hipError_t launch_slab_rope_append(const float* slabs, int splits, const void* bias, int S, int nh, int nkv, int d, const float* inv_freq_dev,
                                    int64_t pos0, void* q_out, void* Kc, void* Vc, int64_t cap, hipStream_t st, const StepState* dyn = nullptr, int layer = 0);
 hipError_t launch_rope_table(void* tab, int S, int half, const float* inv_freq_dev, int64_t pos0, hipStream_t st, const StepState* dyn = nullptr);   // float2 [S][half], bf16-rounded

@@ -1205,10 +1205,10 @@ static int llm_step_segs(mmd_ctx* c, const StepSeg* segs, int nseg, const void* 
             // normalises for the next layer (or the final norm) -- instead of splitk_reduce (+ residual) followed by a separate RMSNorm launch re-reading the row
             int rs = 0;
             rc = gemm(c, c->l_act, I, L.wdown, I, nullptr, c->l_h, H, c->l_h, H, S, H, I, EPI_RESID, 0, GEMM_AUTO, L.wdown_p, false, L.wdown_8, L.sdown, nullptr,
-                      (dt == MMD_BF16 && H <= 4096 && (H & 3) == 0 && !c->no_fuse && !c->no_slab_norm && L.sdown == nullptr) ? &rs : nullptr); if (rc) return rc;          // (fp8 matrices: the per-channel scale lives in the reduce's epilogue)
+                      (dt == MMD_BF16 && H <= 4096 && (H & 3) == 0 && !c->no_fuse && !c->no_slab_norm) ? &rs : nullptr); if (rc) return rc;
             if (rs > 1) {
                 ProfScope ps(c, MMD_K_NORM_ROPE, 4.0 * S * H * e + 4.0 * rs * S * H, 0);
-                HIPCHK(c, launch_slab_resid_rmsnorm(c->splitk_ws, rs, S, H, c->l_h, c->l_h, next_norm, g.rms_norm_eps, next_xn, st));
+                HIPCHK(c, launch_slab_resid_rmsnorm(c->splitk_ws, rs, S, H, c->l_h, c->l_h, next_norm, g.rms_norm_eps, next_xn, st, L.sdown));          // (fp8 matrices: the tile GEMM's slabs are unscaled)
                 xn_ready = true;
             }
         }

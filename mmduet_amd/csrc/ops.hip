@@ -125,7 +125,8 @@ hipError_t launch_layernorm(int dtype, const void* x, const void* w, const void*
 // ---------------------------------------------------------------------------------------------------------------
 template <int MAXS>
 __global__ __launch_bounds__(256) void slab_resid_rmsnorm_kernel(const float* __restrict__ slabs, int splits, int M, int H, const bf16_t* __restrict__ resid,
-                                                                 bf16_t* __restrict__ h_out, const bf16_t* __restrict__ w, float eps, bf16_t* __restrict__ xn) {
+                                                                 bf16_t* __restrict__ h_out, const bf16_t* __restrict__ w, float eps, bf16_t* __restrict__ xn,
+                                                                 const float* __restrict__ wscale = nullptr) {          // wscale: per-column scale of an fp8-quantised matrix whose slabs are unscaled (tile GEMMs)
     // one block per row; thread t owns columns {4t + 1024 j}.  All slab loads of a column group are issued before the
     // first add (MAXS independent 16-byte loads in flight per thread) -- the kernel is pure load latency otherwise.
     __shared__ float red[4];
@@ -145,6 +146,7 @@ __global__ __launch_bounds__(256) void slab_resid_rmsnorm_kernel(const float* __
             f32x4_t acc = part[0];
 #pragma unroll
             for (int s = 1; s < MAXS; ++s) acc += part[s];          // same order as the serial reduce: slab 0, 1, 2, ...
+            if (wscale) acc *= *reinterpret_cast<const f32x4_t*>(wscale + c);          // (store4's order: scale, round, + residual)
             s16x4_t o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -171,12 +173,12 @@ __global__ __launch_bounds__(256) void slab_resid_rmsnorm_kernel(const float* __
     }
 }
 hipError_t launch_slab_resid_rmsnorm(const float* slabs, int splits, int M, int H, const void* resid_in, void* h_out, const void* norm_w, float eps,
-                                     void* xn_out, hipStream_t st) {
+                                     void* xn_out, hipStream_t st, const float* wscale) {
     if (M <= 0) return hipSuccess;
     if (H > 4096 || (H & 3) || splits > 16) return hipErrorInvalidValue;
-    if (splits <= 4) hipLaunchKernelGGL(slab_resid_rmsnorm_kernel<4>, dim3(M), dim3(256), 0, st, slabs, splits, M, H, (const bf16_t*)resid_in, (bf16_t*)h_out, (const bf16_t*)norm_w, eps, (bf16_t*)xn_out);
-    else if (splits <= 8) hipLaunchKernelGGL(slab_resid_rmsnorm_kernel<8>, dim3(M), dim3(256), 0, st, slabs, splits, M, H, (const bf16_t*)resid_in, (bf16_t*)h_out, (const bf16_t*)norm_w, eps, (bf16_t*)xn_out);
-    else hipLaunchKernelGGL(slab_resid_rmsnorm_kernel<16>, dim3(M), dim3(256), 0, st, slabs, splits, M, H, (const bf16_t*)resid_in, (bf16_t*)h_out, (const bf16_t*)norm_w, eps, (bf16_t*)xn_out);
+    if (splits <= 4) hipLaunchKernelGGL(slab_resid_rmsnorm_kernel<4>, dim3(M), dim3(256), 0, st, slabs, splits, M, H, (const bf16_t*)resid_in, (bf16_t*)h_out, (const bf16_t*)norm_w, eps, (bf16_t*)xn_out, wscale);
+    else if (splits <= 8) hipLaunchKernelGGL(slab_resid_rmsnorm_kernel<8>, dim3(M), dim3(256), 0, st, slabs, splits, M, H, (const bf16_t*)resid_in, (bf16_t*)h_out, (const bf16_t*)norm_w, eps, (bf16_t*)xn_out, wscale);
+    else hipLaunchKernelGGL(slab_resid_rmsnorm_kernel<16>, dim3(M), dim3(256), 0, st, slabs, splits, M, H, (const bf16_t*)resid_in, (bf16_t*)h_out, (const bf16_t*)norm_w, eps, (bf16_t*)xn_out, wscale);
     return hipGetLastError();
 }
 
