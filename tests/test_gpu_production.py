@@ -192,6 +192,29 @@ def test_chunk_attention_at_production_sizes(ops, S, n_ctx):
     assert torch.isfinite(o.float()).all() and err <= 1.8e-2, err
 
 
+@pytest.mark.parametrize('S,n_ctx', [(1274, 15000), (637, 3000), (1, 15000), (2, 70001)])
+def test_ring_attention_repeats_bit_identical_beside_a_copy_stream(ops, S, n_ctx):
+    """Race screen of the LDS-DMA rings (chunk kernel <2, 4, 8>, decode kernel <1, 4>): counted waits and slot reuse are hand-placed, and a DMA landing late or a slot refilled
+    early would show as a rare differing tile, not as a parity failure -- so the same launch is repeated with a copy stream perturbing the memory system and must give the
+    same BITS every time (tools/probes/attn_race_screen.py runs the long version: 8 shapes x 300 repeats)."""
+    nh, nkv, d = 28, 4, 128
+    dev = ops.dev
+    g = torch.Generator(device=dev).manual_seed(S + n_ctx)
+    cap = (n_ctx + S + 100 + 63) // 64 * 64
+    q = torch.randn(S, nh * d, generator=g, device=dev).to(torch.bfloat16)
+    K = torch.randn(nkv, cap, d, generator=g, device=dev).to(torch.bfloat16)
+    V = torch.randn(nkv, cap, d, generator=g, device=dev).to(torch.bfloat16)
+    noise = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
+    side = torch.cuda.Stream()
+    first = ops.attention(q, K, V, nh, nkv, d, n_ctx, True, 3).clone()
+    for r in range(60):
+        if r % 3 == 0:
+            with torch.cuda.stream(side):
+                noise[:128 << 20].copy_(noise[128 << 20:], non_blocking=True)
+        assert torch.equal(ops.attention(q, K, V, nh, nkv, d, n_ctx, True, 3), first), r
+    torch.cuda.synchronize()
+
+
 # ---- true-width models ---------------------------------------------------------------------------------------------------------------
 def _build(llm_layers, vit_layers, dtype, vocab=2048, max_vit_batch=35, max_step_tokens=1536, seed=3, tower_dtype=None):
     """(HIP model, oracle weights dict on the device in `dtype`-rounded fp32, oracle config)."""
