@@ -89,6 +89,7 @@ struct mmd_ctx {
     bool no_fuse = false;              // MMDUET_NO_FUSE=1: keep the unfused launch schedule (A/B and parity cross-check)
     bool gemm_half = false;            // the GEMMs issued right now belong to the fp16 vision tower (cfg.tower_f16): IEEE-half operands
     int tower_ring_flags = -1, tower_ring_blocks = 0;   // MMDUET_TOWER_RING / MMDUET_TOWER_RING_BLOCKS: ring GEMM form of the tower (co-residency experiments)
+    bool full_projector = false;       // set while mmd_vit_debug_tap(stage 1) recomputes the projector over ALL tokens (the shipped path runs it on the tokens the bilinear pool reads)
     bool no_slab_norm = false;         // MMDUET_NO_SLAB_NORM=1: a chunk's split-K down_proj keeps splitk_reduce + a separate RMSNorm launch (A/B)
     bool no_chain = false;             // MMDUET_NO_CHAIN=1: decode steps keep the separate reduce+residual+RMSNorm launches (A/B)
     void* rope_tab = 0;                // (cos, sin) of a decode step's positions (launch_rope_table), read by the attention kernel's fused q/k/v preparation
@@ -692,6 +693,18 @@ extern "C" int mmd_vision_pool_head(mmd_ctx* c, const void* feats, int B, void* 
 static int connector_pool(mmd_ctx* c, const void* feats, int B, void* out) {
     const mmd_config& g = c->cfg; const int dt = g.dtype; hipStream_t st = c->stream;
     const int C = g.vit_hidden, H = g.hidden_size, M = B * c->vit_tokens;
+    // bilinear pooling reads (2 out)^2 tokens of each frame: run the (row-wise) projector on those alone -- 196 of 729 rows at the shipped sizes.  The class token, if
+    // any, is not among the grid tokens the pool reads (vit_seq > vit_tokens): `feats` rows are then indexed per frame by vit_tokens as before.
+    static const bool full_proj = getenv("MMDUET_FULL_PROJECTOR") != nullptr;
+    const int pout = (c->vit_grid + g.pool_stride - 1) / g.pool_stride;
+    if (g.pool_mode == MMD_POOL_BILINEAR && !full_proj && !c->full_projector && 4 * pout * pout < c->vit_tokens && c->vit_seq == c->vit_tokens) {
+        const int Mc = B * 4 * pout * pout;
+        { ProfScope ps(c, MMD_K_OTHER, 0, 0); HIPCHK(c, launch_gather_pool_rows(dt, feats, c->v_xn, B, c->vit_grid, C, pout, st)); }
+        int rc = gemm(c, c->v_xn, C, c->p0w, C, c->p0b, nullptr, 0, c->v_p1, H, Mc, H, C, EPI_GELU_ERF, 0, GEMM_AUTO, c->p0w_p, true); if (rc) return rc;
+        rc = gemm(c, c->v_p1, H, c->p2w, H, c->p2b, nullptr, 0, c->v_p2, H, Mc, H, H, EPI_NONE, 0, GEMM_AUTO, c->p2w_p, true); if (rc) return rc;
+        { ProfScope ps(c, MMD_K_OTHER, 0, 0); HIPCHK(c, launch_pool_compact_bilinear(dt, c->v_p2, out, B, c->vit_grid, H, pout, st)); }
+        return MMD_OK;
+    }
     int rc = gemm(c, feats, C, c->p0w, C, c->p0b, nullptr, 0, c->v_p1, H, M, H, C, EPI_GELU_ERF, 0, GEMM_AUTO, c->p0w_p, true); if (rc) return rc;
     rc = gemm(c, c->v_p1, H, c->p2w, H, c->p2b, nullptr, 0, c->v_p2, H, M, H, H, EPI_NONE, 0, GEMM_AUTO, c->p2w_p, true); if (rc) return rc;
     { ProfScope ps(c, MMD_K_OTHER, 0, 0); HIPCHK(c, launch_pool(dt, c->v_p2, out, B, c->vit_grid, H, g.pool_mode, g.pool_stride, st)); }
@@ -713,6 +726,14 @@ extern "C" int mmd_vit_debug_tap(mmd_ctx* c, int stage, void* out, int64_t out_e
     int64_t M = (int64_t)c->last_vit_B * c->vit_seq;
     int64_t n = M * (stage == 0 ? c->cfg.vit_hidden : c->cfg.hidden_size);
     if (stage < 0 || stage > 1 || out_elems < n) FAIL(c, MMD_EINVAL, "bad tap request");
+    if (stage == 1 && c->last_vit_B > 0) {
+        // the shipped path runs the projector on the tokens the bilinear pool reads; the tap wants connector() of ALL tokens: recompute it from the tower output
+        // still sitting in v_h (debug entry point; the pooled result goes to a scratch row block of v_xn and is dropped)
+        c->full_projector = true;
+        const int rc = connector_pool(c, c->v_h, c->last_vit_B, c->v_xn);
+        c->full_projector = false;
+        if (rc) return rc;
+    }
     HIPCHK(c, hipMemcpyAsync(out, stage == 0 ? c->v_h : c->v_p2, (size_t)n * es(c), hipMemcpyDeviceToDevice, c->stream));
     return MMD_OK;
 }

@@ -524,6 +524,50 @@ __global__ void pool_kernel(const T* __restrict__ x, T* __restrict__ y, int g, i
     }
     y[(((long long)b * out + oy) * out + ox) * H + c] = from_f<T>(r);
 }
+// The bilinear pool (F.interpolate, no antialias) reads only the 2 x 2 neighbours of each of its out^2 sample points: (2 out)^2 = 196 of a frame's 729 tokens at the
+// shipped sizes.  The projector in front of it is row-wise, so it only has to run on those tokens -- the pooled result is the same function of the same values (the
+// reference computes the other 533 rows of `connector` and never reads them; same reasoning as the lazy lm_head).  Compact row u = (2 oy + ty) * 2 out + (2 ox + tx)
+// holds source token (tap_ty(oy), tap_tx(ox)); a tap pair that clamps at the border simply appears twice.
+template <typename T>
+__global__ void gather_pool_rows_kernel(const T* __restrict__ x, T* __restrict__ y, int g, int C, int out) {
+    const int b = blockIdx.y, u = blockIdx.x, two = 2 * out;
+    const int ry = u / two, rx = u % two;
+    int y0, y1, x0, x1; float l;
+    bilinear_tap(ry >> 1, g, out, y0, y1, l); bilinear_tap(rx >> 1, g, out, x0, x1, l);
+    const int tok = ((ry & 1) ? y1 : y0) * g + ((rx & 1) ? x1 : x0);
+    const T* src = x + ((long long)b * g * g + tok) * C;
+    T* dst = y + ((long long)b * two * two + u) * C;
+    if ((C * sizeof(T)) % 16 == 0) { for (int i = threadIdx.x; i < (int)(C * sizeof(T) / 16); i += blockDim.x) reinterpret_cast<u32x4_t*>(dst)[i] = reinterpret_cast<const u32x4_t*>(src)[i]; }
+    else for (int i = threadIdx.x; i < C; i += blockDim.x) dst[i] = src[i];
+}
+template <typename T>
+__global__ void pool_compact_bilinear_kernel(const T* __restrict__ x, T* __restrict__ y, int g, int H, int out) {
+    const int b = blockIdx.z, oy = blockIdx.y / out, ox = blockIdx.y % out, two = 2 * out;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= H) return;
+    const T* xb = x + (long long)b * two * two * H;
+    int y0, y1, x0, x1; float ly, lx;
+    bilinear_tap(oy, g, out, y0, y1, ly); bilinear_tap(ox, g, out, x0, x1, lx);          // (only the weights are needed here; the rows sit at fixed compact positions)
+    const float a = to_f<T>(xb[((long long)(2 * oy) * two + 2 * ox) * H + c]), bq = to_f<T>(xb[((long long)(2 * oy) * two + 2 * ox + 1) * H + c]);
+    const float cq = to_f<T>(xb[((long long)(2 * oy + 1) * two + 2 * ox) * H + c]), dq = to_f<T>(xb[((long long)(2 * oy + 1) * two + 2 * ox + 1) * H + c]);
+    const float top = a * (1.f - lx) + bq * lx, bot = cq * (1.f - lx) + dq * lx;
+    y[(((long long)b * out + oy) * out + ox) * H + c] = from_f<T>(top * (1.f - ly) + bot * ly);
+}
+hipError_t launch_gather_pool_rows(int dtype, const void* x, void* y, int B, int grid, int C, int out, hipStream_t st) {
+    if (B <= 0 || out <= 0) return hipSuccess;
+    dim3 g(4 * out * out, B), block(64);
+    if (dtype == MMD_F32) hipLaunchKernelGGL(gather_pool_rows_kernel<float>, g, block, 0, st, (const float*)x, (float*)y, grid, C, out);
+    else hipLaunchKernelGGL(gather_pool_rows_kernel<bf16_t>, g, block, 0, st, (const bf16_t*)x, (bf16_t*)y, grid, C, out);
+    return hipGetLastError();
+}
+hipError_t launch_pool_compact_bilinear(int dtype, const void* x, void* y, int B, int grid, int H, int out, hipStream_t st) {
+    if (B <= 0 || out <= 0) return hipSuccess;
+    dim3 g(cdiv(H, 256), out * out, B), block(256);
+    if (dtype == MMD_F32) hipLaunchKernelGGL(pool_compact_bilinear_kernel<float>, g, block, 0, st, (const float*)x, (float*)y, grid, H, out);
+    else hipLaunchKernelGGL(pool_compact_bilinear_kernel<bf16_t>, g, block, 0, st, (const bf16_t*)x, (bf16_t*)y, grid, H, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_pool(int dtype, const void* x, void* y, int B, int grid, int H, int mode, int stride, hipStream_t st) {
     int out = mode == MMD_POOL_BILINEAR ? (grid + stride - 1) / stride : mode == MMD_POOL_ADAPTIVE_AVG ? stride : grid / stride;   // adaptive: `stride` carries the output side
     if (B <= 0 || out <= 0) return hipSuccess;
