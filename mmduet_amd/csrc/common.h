@@ -166,7 +166,7 @@ hipError_t launch_transpose_v(int dtype, const void* src, void* dst, int nkv, in
 hipError_t launch_embed(int dtype, const void* table, const int64_t* ids, int k, int H, int64_t vocab, void* out, hipStream_t st);
 hipError_t launch_im2col(int dtype, const void* px, int B, int img, int patch, int grid, int Kpad, void* out, hipStream_t st);
 hipError_t launch_pool(int dtype, const void* x, void* y, int B, int grid, int H, int mode, int stride, hipStream_t st);
-hipError_t launch_gather_pool_rows(int dtype, const void* x, void* y, int B, int grid, int C, int out, hipStream_t st);            // the (2 out)^2 tokens per frame a bilinear pool reads, compacted
+hipError_t launch_gather_pool_rows(int dtype, const void* x, void* y, int B, int grid, int C, int out, hipStream_t st, int64_t ldx = 0);            // the (2 out)^2 tokens per frame a bilinear pool reads, compacted
 hipError_t launch_pool_compact_bilinear(int dtype, const void* x, void* y, int B, int grid, int H, int out, hipStream_t st);      // the pool over that compact layout
 hipError_t launch_heads(int dtype, const void* hidden, int64_t ldh, const int32_t* rows_dev, int M, const void* W4, int H, float* out,
                         hipStream_t st);

@@ -89,6 +89,8 @@ struct mmd_ctx {
     bool no_fuse = false;              // MMDUET_NO_FUSE=1: keep the unfused launch schedule (A/B and parity cross-check)
     bool gemm_half = false;            // the GEMMs issued right now belong to the fp16 vision tower (cfg.tower_f16): IEEE-half operands
     int tower_ring_flags = -1, tower_ring_blocks = 0;   // MMDUET_TOWER_RING / MMDUET_TOWER_RING_BLOCKS: ring GEMM form of the tower (co-residency experiments)
+    bool full_tower = false;           // mmd_vit_set_full_tower(1): the last encoder layer runs on ALL tokens (feature extraction, debug taps); default: on the tokens the bilinear pool reads
+    bool tower_compact = false;        // the tower's output of the current batch is the compact [B * (2 out)^2, C] block in v_col (set by vit_tower, consumed by connector_pool)
     bool full_projector = false;       // set while mmd_vit_debug_tap(stage 1) recomputes the projector over ALL tokens (the shipped path runs it on the tokens the bilinear pool reads)
     bool no_slab_norm = false;         // MMDUET_NO_SLAB_NORM=1: a chunk's split-K down_proj keeps splitk_reduce + a separate RMSNorm launch (A/B)
     bool no_chain = false;             // MMDUET_NO_CHAIN=1: decode steps keep the separate reduce+residual+RMSNorm launches (A/B)
@@ -563,7 +565,7 @@ static int alloc_workspaces(mmd_ctx* c) {
 static int connector_pool(mmd_ctx* c, const void* feats, int B, void* out);
 static int ensure_preprocess_tables(mmd_ctx* c, int T, int R);
 // the tower: patch-embed (+ class token, + pre-LN for CLIP) -> encoder layers -> optional post_layernorm; result [B * vit_seq, C] in c->v_h
-static int vit_tower(mmd_ctx* c, const void* px, int B, bool col_ready = false) {
+static int vit_tower(mmd_ctx* c, const void* px, int B, bool col_ready = false, bool for_pool = false) {
     const mmd_config& g = c->cfg; hipStream_t st = c->stream;
     // tower_f16: every tower tensor is IEEE half (the reference's autocast); pixel_values arrive in the model dtype (bf16) and become half in the im2col pass,
     // the tower's output is rounded to bf16 at the end (SigLipVisionTower returns hidden_states[-1].to(images.dtype) [3P-recalled])
@@ -580,10 +582,43 @@ static int vit_tower(mmd_ctx* c, const void* px, int B, bool col_ready = false) 
         ProfScope ps(c, MMD_K_OTHER, 0, 0); HIPCHK(c, launch_add_rows(dt, c->v_h, c->pos_emb, M, C, T, st));
     }
     if (g.vit_pre_layernorm) { HIPCHK(c, launch_layernorm(dt, c->v_h, c->pre_w, c->pre_b, c->v_h, M, C, g.vit_ln_eps, st)); }
+    // The bilinear pool behind the projector reads (2 out)^2 = 196 of a frame's 729 tokens, and everything after the LAST layer's K / V is row-wise: that layer's
+    // queries, o_proj, LayerNorm, MLP (and the projector) run on those rows alone.  K and V still come from all tokens.  Same values into the same arithmetic;
+    // callers that want the tower's full output (feature extraction, debug taps) switch it off with mmd_vit_set_full_tower.
+    static const bool no_sparse = getenv("MMDUET_FULL_PROJECTOR") != nullptr;
+    const int pout = (c->vit_grid + g.pool_stride - 1) / g.pool_stride, U = 4 * pout * pout;
+    const bool sparse_last = for_pool && !no_sparse && !c->full_tower && !c->full_projector && g.pool_mode == MMD_POOL_BILINEAR && U < T && TS == T && !g.vit_post_layernorm &&
+                             g.vit_act != 1 && g.vit_layers > 0 && !g.vision_only;
+    c->tower_compact = false;
     for (int i = 0; i < g.vit_layers; ++i) {
         VitLayer& L = c->VL[i];
         { ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * M * C * es(c), 0); HIPCHK(c, launch_layernorm(dt, c->v_h, L.ln1w, L.ln1b, c->v_xn, M, C, g.vit_ln_eps, st)); }
         rc = gemm(c, c->v_xn, C, L.wqkv, C, L.bqkv, nullptr, 0, c->v_qkv, 3 * C, M, 3 * C, C, EPI_NONE, 0, GEMM_AUTO, L.wqkv_p, true); if (rc) return rc;
+        if (sparse_last && i + 1 == g.vit_layers) {
+            const int Mc = B * U;
+            void* qc = c->v_mlp; void* hc = c->v_col;          // compact queries / residual stream (v_mlp is free until fc1, the im2col matrix is dead since the patch GEMM)
+            { ProfScope ps(c, MMD_K_OTHER, 0, 0);
+              HIPCHK(c, launch_gather_pool_rows(dt == MMD_F32 ? MMD_F32 : MMD_BF16, c->v_qkv, qc, B, c->vit_grid, C, pout, st, 3 * C));
+              HIPCHK(c, launch_gather_pool_rows(dt == MMD_F32 ? MMD_F32 : MMD_BF16, c->v_h, hc, B, c->vit_grid, C, pout, st, C)); }
+            {
+                AttnArgs a; memset(&a, 0, sizeof(a));
+                a.q = qc; a.ldq = C; a.K = (char*)c->v_qkv + (size_t)C * es(c); a.V = (char*)c->v_qkv + (size_t)2 * C * es(c);
+                a.k_hs = hd; a.k_ts = 3 * C; a.v_hs = hd; a.v_ts = 3 * C; a.out = c->v_attn; a.ldo = C;
+                a.S = U; a.nh = g.vit_heads; a.nkv = g.vit_heads; a.d = hd; a.n_ctx = TS - U; a.causal = 0;          // U query rows over all TS keys
+                a.batch = B; a.q_bstride = (int64_t)U * C; a.kv_bstride = (int64_t)TS * 3 * C; a.o_bstride = (int64_t)U * C;
+                a.ws = c->v_attn_ws; a.ws_bytes = c->v_attn_bytes; a.variant = 0;
+                ProfScope ps(c, MMD_K_ATTN_VIT, 2.0 * (M + Mc) * C * es(c), 4.0 * B * (double)U * TS * C);
+                HIPCHK(c, launch_attention(dt, a, st));
+            }
+            rc = gemm(c, c->v_attn, C, L.wo, C, L.bo, hc, C, hc, C, Mc, C, C, EPI_RESID, 0, GEMM_AUTO, L.wo_p, true); if (rc) return rc;
+            { ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * Mc * C * es(c), 0); HIPCHK(c, launch_layernorm(dt, hc, L.ln2w, L.ln2b, c->v_xn, Mc, C, g.vit_ln_eps, st)); }
+            rc = gemm(c, c->v_xn, C, L.w1, C, L.b1, nullptr, 0, c->v_mlp, c->vit_ipad, Mc, c->vit_ipad, C, EPI_GELU_TANH, 0, GEMM_AUTO, L.w1_p, true); if (rc) return rc;
+            rc = gemm(c, c->v_mlp, c->vit_ipad, L.w2, c->vit_ipad, L.b2, hc, C, hc, C, Mc, C, c->vit_ipad, EPI_RESID, 0, GEMM_AUTO, L.w2_p, true); if (rc) return rc;
+            if (g.tower_f16) { ProfScope ps(c, MMD_K_OTHER, 0, 0); HIPCHK(c, launch_convert(hc, MMD_F16, hc, MMD_BF16, (int64_t)Mc * C, st)); }
+            c->tower_compact = true;
+            c->last_vit_B = B;
+            return MMD_OK;
+        }
         {
             AttnArgs a; memset(&a, 0, sizeof(a));
             a.q = c->v_qkv; a.ldq = 3 * C; a.K = (char*)c->v_qkv + (size_t)C * es(c); a.V = (char*)c->v_qkv + (size_t)2 * C * es(c);
@@ -614,8 +649,8 @@ extern "C" int mmd_vit_encode(mmd_ctx* c, const void* px, int B, void* out) {
     NEED_FINAL(c);
     if (B <= 0) return MMD_OK;
     if (c->cfg.vision_only) FAIL(c, MMD_EINVAL, "vision-only context: use mmd_vision_tower");
-    int rc = vit_tower(c, px, B); if (rc) return rc;
-    return connector_pool(c, c->v_h, B, out);
+    int rc = vit_tower(c, px, B, false, true); if (rc) return rc;
+    return connector_pool(c, c->tower_compact ? c->v_col : c->v_h, B, out);
 }
 
 // visual_embed straight from uint8 frames: image_processor.preprocess (test/inference.py:203) and the patch-embed load are one
@@ -631,8 +666,8 @@ extern "C" int mmd_vit_encode_frames(mmd_ctx* c, const uint8_t* frames, int B, i
     { ProfScope ps(c, MMD_K_OTHER, 0, 0);
       HIPCHK(c, launch_preprocess_im2col(c->cfg.tower_f16 ? MMD_F16 : c->cfg.dtype, frames, B, R, c->cfg.vit_image, c->pp_coef, c->pp_bounds, c->pp_ksize, c->pp_tmp, c->cfg.vit_patch, c->vit_grid,
                                          c->vit_kpad, c->v_col, c->stream)); }
-    rc = vit_tower(c, nullptr, B, true); if (rc) return rc;
-    return connector_pool(c, c->v_h, B, out);
+    rc = vit_tower(c, nullptr, B, true, true); if (rc) return rc;
+    return connector_pool(c, c->tower_compact ? c->v_col : c->v_h, B, out);
 }
 
 // ---- secondary encoder path (models/vision_live.py) -------------------------------------------------------------------------------------
@@ -699,8 +734,10 @@ static int connector_pool(mmd_ctx* c, const void* feats, int B, void* out) {
     const int pout = (c->vit_grid + g.pool_stride - 1) / g.pool_stride;
     if (g.pool_mode == MMD_POOL_BILINEAR && !full_proj && !c->full_projector && 4 * pout * pout < c->vit_tokens && c->vit_seq == c->vit_tokens) {
         const int Mc = B * 4 * pout * pout;
-        { ProfScope ps(c, MMD_K_OTHER, 0, 0); HIPCHK(c, launch_gather_pool_rows(dt, feats, c->v_xn, B, c->vit_grid, C, pout, st)); }
-        int rc = gemm(c, c->v_xn, C, c->p0w, C, c->p0b, nullptr, 0, c->v_p1, H, Mc, H, C, EPI_GELU_ERF, 0, GEMM_AUTO, c->p0w_p, true); if (rc) return rc;
+        const void* fc = feats;
+        if (c->tower_compact && feats == c->v_col) c->tower_compact = false;          // the tower already left exactly these rows (consumed once)
+        else { ProfScope ps(c, MMD_K_OTHER, 0, 0); HIPCHK(c, launch_gather_pool_rows(dt, feats, c->v_xn, B, c->vit_grid, C, pout, st)); fc = c->v_xn; }
+        int rc = gemm(c, fc, C, c->p0w, C, c->p0b, nullptr, 0, c->v_p1, H, Mc, H, C, EPI_GELU_ERF, 0, GEMM_AUTO, c->p0w_p, true); if (rc) return rc;
         rc = gemm(c, c->v_p1, H, c->p2w, H, c->p2b, nullptr, 0, c->v_p2, H, Mc, H, H, EPI_NONE, 0, GEMM_AUTO, c->p2w_p, true); if (rc) return rc;
         { ProfScope ps(c, MMD_K_OTHER, 0, 0); HIPCHK(c, launch_pool_compact_bilinear(dt, c->v_p2, out, B, c->vit_grid, H, pout, st)); }
         return MMD_OK;
@@ -721,8 +758,17 @@ extern "C" int mmd_connector_pool(mmd_ctx* c, const void* tower_features, int B,
     return connector_pool(c, tower_features, B, out);
 }
 
+// feature extraction (vision_encode's [B, tokens, C]) and the debug taps need the tower's output for ALL tokens: on = the last layer is not restricted to the rows the pool reads
+extern "C" int mmd_vit_set_full_tower(mmd_ctx* c, int on) {
+    if (!c) return MMD_EINVAL;
+    c->full_tower = on != 0;
+    return MMD_OK;
+}
+
 extern "C" int mmd_vit_debug_tap(mmd_ctx* c, int stage, void* out, int64_t out_elems) {
     NEED_FINAL(c);
+    if (!c->full_tower && !c->cfg.vision_only && c->cfg.pool_mode == MMD_POOL_BILINEAR && getenv("MMDUET_FULL_PROJECTOR") == nullptr)
+        FAIL(c, MMD_EINVAL, "mmd_vit_debug_tap needs mmd_vit_set_full_tower(ctx, 1) before the encode call (the default path computes the last layer for the pooled tokens only)");
     int64_t M = (int64_t)c->last_vit_B * c->vit_seq;
     int64_t n = M * (stage == 0 ? c->cfg.vit_hidden : c->cfg.hidden_size);
     if (stage < 0 || stage > 1 || out_elems < n) FAIL(c, MMD_EINVAL, "bad tap request");

@@ -529,13 +529,13 @@ __global__ void pool_kernel(const T* __restrict__ x, T* __restrict__ y, int g, i
 // reference computes the other 533 rows of `connector` and never reads them; same reasoning as the lazy lm_head).  Compact row u = (2 oy + ty) * 2 out + (2 ox + tx)
 // holds source token (tap_ty(oy), tap_tx(ox)); a tap pair that clamps at the border simply appears twice.
 template <typename T>
-__global__ void gather_pool_rows_kernel(const T* __restrict__ x, T* __restrict__ y, int g, int C, int out) {
+__global__ void gather_pool_rows_kernel(const T* __restrict__ x, T* __restrict__ y, int g, int C, int out, long long ldx) {      // ldx: source row stride (C, or 3 C for the q third of a fused qkv row)
     const int b = blockIdx.y, u = blockIdx.x, two = 2 * out;
     const int ry = u / two, rx = u % two;
     int y0, y1, x0, x1; float l;
     bilinear_tap(ry >> 1, g, out, y0, y1, l); bilinear_tap(rx >> 1, g, out, x0, x1, l);
     const int tok = ((ry & 1) ? y1 : y0) * g + ((rx & 1) ? x1 : x0);
-    const T* src = x + ((long long)b * g * g + tok) * C;
+    const T* src = x + ((long long)b * g * g + tok) * ldx;
     T* dst = y + ((long long)b * two * two + u) * C;
     if ((C * sizeof(T)) % 16 == 0) { for (int i = threadIdx.x; i < (int)(C * sizeof(T) / 16); i += blockDim.x) reinterpret_cast<u32x4_t*>(dst)[i] = reinterpret_cast<const u32x4_t*>(src)[i]; }
     else for (int i = threadIdx.x; i < C; i += blockDim.x) dst[i] = src[i];
@@ -553,11 +553,12 @@ __global__ void pool_compact_bilinear_kernel(const T* __restrict__ x, T* __restr
     const float top = a * (1.f - lx) + bq * lx, bot = cq * (1.f - lx) + dq * lx;
     y[(((long long)b * out + oy) * out + ox) * H + c] = from_f<T>(top * (1.f - ly) + bot * ly);
 }
-hipError_t launch_gather_pool_rows(int dtype, const void* x, void* y, int B, int grid, int C, int out, hipStream_t st) {
+hipError_t launch_gather_pool_rows(int dtype, const void* x, void* y, int B, int grid, int C, int out, hipStream_t st, int64_t ldx) {
     if (B <= 0 || out <= 0) return hipSuccess;
+    if (ldx <= 0) ldx = C;
     dim3 g(4 * out * out, B), block(64);
-    if (dtype == MMD_F32) hipLaunchKernelGGL(gather_pool_rows_kernel<float>, g, block, 0, st, (const float*)x, (float*)y, grid, C, out);
-    else hipLaunchKernelGGL(gather_pool_rows_kernel<bf16_t>, g, block, 0, st, (const bf16_t*)x, (bf16_t*)y, grid, C, out);
+    if (dtype == MMD_F32) hipLaunchKernelGGL(gather_pool_rows_kernel<float>, g, block, 0, st, (const float*)x, (float*)y, grid, C, out, (long long)ldx);
+    else hipLaunchKernelGGL(gather_pool_rows_kernel<bf16_t>, g, block, 0, st, (const bf16_t*)x, (bf16_t*)y, grid, C, out, (long long)ldx);          // (any 2-byte type: bf16 / f16 rows are copied as bits)
     return hipGetLastError();
 }
 hipError_t launch_pool_compact_bilinear(int dtype, const void* x, void* y, int B, int grid, int H, int out, hipStream_t st) {

@@ -417,11 +417,21 @@ class VideoHeadLiveLlavaQwenForCausalLM:
         scratch = torch.empty(min(B, self.max_vit_batch) * self.tokens_per_frame, self.config.hidden_size, dtype=self.dtype, device=self.device)
         with self._lock:
             self._bind_stream()
-            for b0 in range(0, B, self.max_vit_batch):
-                b1 = min(B, b0 + self.max_vit_batch)
-                check(lib().mmd_vit_encode(self._ctx, _ptr(frames[b0:b1]), b1 - b0, _ptr(scratch)), self._ctx, 'mmd_vit_encode')
-                check(lib().mmd_vit_debug_tap(self._ctx, 0, _ptr(out[b0:b1]), (b1 - b0) * T * C), self._ctx, 'mmd_vit_debug_tap')
+            check(lib().mmd_vit_set_full_tower(self._ctx, 1), self._ctx, 'mmd_vit_set_full_tower')          # vision_encode's output is the tower over ALL tokens
+            try:
+                for b0 in range(0, B, self.max_vit_batch):
+                    b1 = min(B, b0 + self.max_vit_batch)
+                    check(lib().mmd_vit_encode(self._ctx, _ptr(frames[b0:b1]), b1 - b0, _ptr(scratch)), self._ctx, 'mmd_vit_encode')
+                    check(lib().mmd_vit_debug_tap(self._ctx, 0, _ptr(out[b0:b1]), (b1 - b0) * T * C), self._ctx, 'mmd_vit_debug_tap')
+            finally:
+                check(lib().mmd_vit_set_full_tower(self._ctx, 0), self._ctx, 'mmd_vit_set_full_tower')
         return out
+
+    def set_full_tower(self, on: bool):
+        """Debug / feature extraction: have the tower compute its last layer (and the projector) for every token instead of the (2 out)^2 the bilinear pool reads;
+        `vit_debug_tap` needs it switched on BEFORE the visual_embed call it inspects."""
+        with self._lock:
+            check(lib().mmd_vit_set_full_tower(self._ctx, 1 if on else 0), self._ctx, 'mmd_vit_set_full_tower')
 
     def vit_debug_tap(self, stage: int, B: int):
         n = B * self.config.vit_grid ** 2

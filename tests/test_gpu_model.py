@@ -28,10 +28,16 @@ def f32(request):
 def test_vision_stages_fp32(f32):
     tag, m, cfgd, w, ops = f32
     px = ops['pixel_values'].cuda()
-    ve = m.visual_embed(px)
-    assert maxerr(m.vit_debug_tap(0, px.shape[0]), ops['tower'].flatten(0, 1)) < F32_TOL
-    assert maxerr(m.vit_debug_tap(1, px.shape[0]), ops['connector'].flatten(0, 1)) < F32_TOL
+    ve_default = m.visual_embed(px)                      # shipped path: last layer + projector on the tokens the bilinear pool reads (where that is fewer than all)
+    m.set_full_tower(True)                               # the taps want tower / connector outputs for every token
+    try:
+        ve = m.visual_embed(px)
+        assert maxerr(m.vit_debug_tap(0, px.shape[0]), ops['tower'].flatten(0, 1)) < F32_TOL
+        assert maxerr(m.vit_debug_tap(1, px.shape[0]), ops['connector'].flatten(0, 1)) < F32_TOL
+    finally:
+        m.set_full_tower(False)
     assert maxerr(ve, ops['visual_embed']) < F32_TOL
+    assert maxerr(ve_default, ops['visual_embed']) < F32_TOL
     assert ve.shape == ops['visual_embed'].shape
 
 
