@@ -165,6 +165,7 @@ hipError_t launch_rope_append(int dtype, const void* qkv, int S, int nh, int nkv
 hipError_t launch_transpose_v(int dtype, const void* src, void* dst, int nkv, int64_t cap, int d, hipStream_t st);
 hipError_t launch_embed(int dtype, const void* table, const int64_t* ids, int k, int H, int64_t vocab, void* out, hipStream_t st);
 hipError_t launch_im2col(int dtype, const void* px, int B, int img, int patch, int grid, int Kpad, void* out, hipStream_t st);
+hipError_t launch_gather_rows2(const void* xa, int64_t lda, void* ya, int Wa, const void* xb, int64_t ldb, void* yb, int Wb, const int32_t* rows_host, int n, hipStream_t st);   // n <= 64; rows ride in the kernel argument
 hipError_t launch_pool(int dtype, const void* x, void* y, int B, int grid, int H, int mode, int stride, hipStream_t st);
 hipError_t launch_gather_pool_rows(int dtype, const void* x, void* y, int B, int grid, int C, int out, hipStream_t st, int64_t ldx = 0);            // the (2 out)^2 tokens per frame a bilinear pool reads, compacted
 hipError_t launch_pool_compact_bilinear(int dtype, const void* x, void* y, int B, int grid, int H, int out, hipStream_t st);      // the pool over that compact layout

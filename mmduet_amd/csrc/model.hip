@@ -89,6 +89,7 @@ struct mmd_ctx {
     bool no_fuse = false;              // MMDUET_NO_FUSE=1: keep the unfused launch schedule (A/B and parity cross-check)
     bool gemm_half = false;            // the GEMMs issued right now belong to the fp16 vision tower (cfg.tower_f16): IEEE-half operands
     int tower_ring_flags = -1, tower_ring_blocks = 0;   // MMDUET_TOWER_RING / MMDUET_TOWER_RING_BLOCKS: ring GEMM form of the tower (co-residency experiments)
+    int hid_compact = 0;               // > 0: l_hid holds that many compact rows (in the order of the `need` list) instead of all S rows of the step
     bool full_tower = false;           // mmd_vit_set_full_tower(1): the last encoder layer runs on ALL tokens (feature extraction, debug taps); default: on the tokens the bilinear pool reads
     bool tower_compact = false;        // the tower's output of the current batch is the compact [B * (2 out)^2, C] block in v_col (set by vit_tower, consumed by connector_pool)
     bool full_projector = false;       // set while mmd_vit_debug_tap(stage 1) recomputes the projector over ALL tokens (the shipped path runs it on the tokens the bilinear pool reads)
@@ -1135,8 +1136,9 @@ static int kv_reserve(mmd_ctx* c, mmd_stream* s, int64_t need) {
 // arena; every GEMM / norm runs once over all S rows, RoPE + KV append + attention run per segment on that stream's arena.
 struct StepSeg { mmd_stream* s; int row0; int rows; };
 
-static int llm_step_segs(mmd_ctx* c, const StepSeg* segs, int nseg, const void* embeds, int S, void* hidden_out, const StepState* dyn) {
+static int llm_step_segs(mmd_ctx* c, const StepSeg* segs, int nseg, const void* embeds, int S, void* hidden_out, const StepState* dyn, const int32_t* need_rows = nullptr, int n_need = 0) {
     NEED_FINAL(c);
+    c->hid_compact = 0;
     if (S <= 0 || nseg <= 0) return MMD_OK;
     const mmd_config& g = c->cfg; const int dt = g.dtype; const size_t e = es(c); hipStream_t st = c->stream;
     if (S > g.max_step_tokens) FAIL(c, MMD_ERANGE, "step of %d tokens exceeds max_step_tokens %d", S, g.max_step_tokens);
@@ -1177,10 +1179,10 @@ static int llm_step_segs(mmd_ctx* c, const StepSeg* segs, int nseg, const void* 
     GemvChain ch_fin, ch_xn;
     ch_fin.fin_h = c->l_h; ch_fin.fin_ssq = c->chain_ssq;
     ch_xn.xn_h = c->l_h; ch_xn.xn_ssq = c->chain_ssq; ch_xn.xn_eps = g.rms_norm_eps;
-    auto slab_gemm = [&](const void* X, int64_t ldx, const void* Wp, int N, int K, int* splits, const void* Wp8, const float* wscale, const GemvChain* chn = nullptr) -> int {
+    auto slab_gemm = [&](const void* X, int64_t ldx, const void* Wp, int N, int K, int* splits, const void* Wp8, const float* wscale, const GemvChain* chn = nullptr, int Mrows = 0) -> int {
         GemmArgs a; memset(&a, 0, sizeof(a));
         a.chain = chn;
-        a.X = X; a.ldx = ldx; a.Wp = Wp; a.Wp8 = Wp8; a.wscale = wscale; a.M = S; a.N = N; a.K = K; a.epi = EPI_NONE; a.variant = GEMM_SKINNY;
+        a.X = X; a.ldx = ldx; a.Wp = Wp; a.Wp8 = Wp8; a.wscale = wscale; a.M = Mrows > 0 ? Mrows : S; a.N = N; a.K = K; a.epi = EPI_NONE; a.variant = GEMM_SKINNY;
         a.splitk_ws = c->splitk_ws; a.splitk_ws_bytes = c->splitk_bytes; a.slabs_out = splits;
         ProfScope ps(c, MMD_K_GEMM_SKINNY, (double)S * K * e + (double)N * K * (Wp8 ? 1.0 : e) + (double)S * N * e, 2.0 * S * N * K);
         HIPCHK(c, launch_gemm(dt, a, st, nullptr));
@@ -1196,6 +1198,21 @@ static int llm_step_segs(mmd_ctx* c, const StepSeg* segs, int nseg, const void* 
     static const bool no_chunk_rope = getenv("MMDUET_NO_CHUNK_ROPE") != nullptr;
     const bool chunk_rope = !fused && dt == MMD_BF16 && d == 128 && S >= 64 && !no_chunk_rope && !c->no_fuse;
     if (chunk_rope) for (int j = 0; j < nseg; ++j) HIPCHK(c, launch_rope_table((char*)c->rope_tab + (size_t)segs[j].row0 * 64 * 8, segs[j].rows, 64, c->inv_freq, segs[j].s->len, st, nullptr));
+    // The hidden states of a chunk's LAST layer are read at a few rows only (the frame-end rows of the two heads, the row whose logits are wanted); its K / V must exist
+    // for every token, but its o_proj and MLP are row-wise: they run on the rows somebody reads, through the weight-streaming kernels (M <= 64).  The reference computes all
+    // rows and drops them (the lm_head over all positions is "pure waste the build skips" -- the same holds one layer down).
+    static const bool no_sparse_last = getenv("MMDUET_FULL_LAST_LAYER") != nullptr;
+    bool sparse_last = false;
+    if (need_rows && n_need > 0 && n_need <= 64 && !fused && S > 64 && dt == MMD_BF16 && H <= 4096 && (H & 3) == 0 && !c->no_fuse && !no_sparse_last && !hidden_out && !dyn) {
+        GemmArgs probe; memset(&probe, 0, sizeof(probe));
+        probe.X = c->l_q; probe.ldx = nh * d; probe.Wp = c->L[0].wo_p; probe.M = n_need; probe.N = H; probe.K = nh * d; probe.epi = EPI_NONE;
+        probe.splitk_ws = c->splitk_ws; probe.splitk_ws_bytes = c->splitk_bytes;
+        GemmArgs p2 = probe; p2.Wp = c->L[0].wdown_p; p2.K = I; p2.ldx = I; p2.X = c->l_act;
+        sparse_last = gemm_can_slab(dt, probe) && gemm_can_slab(dt, p2);
+        if (sparse_last) {
+            for (int k = 0; k < n_need; ++k) if (need_rows[k] < 0 || need_rows[k] >= S) FAIL(c, MMD_ERANGE, "needed row %d outside the step", need_rows[k]);
+        }
+    }
     bool xn_ready = false;             // the previous layer's fused slab consumer already left this layer's normalised input in l_xn
     for (int i = 0; i < g.num_layers; ++i) {
         LlmLayer& L = c->L[i];
@@ -1246,6 +1263,22 @@ static int llm_step_segs(mmd_ctx* c, const StepSeg* segs, int nseg, const void* 
         }
         const void* next_norm = (i + 1 < g.num_layers) ? c->L[i + 1].ln1 : c->fnorm;
         void* next_xn = (i + 1 < g.num_layers) ? c->l_xn : c->l_hid;
+        if (sparse_last && i + 1 == g.num_layers) {
+            void* attn_c = c->l_q; void* h_c = c->l_qkv;          // (both dead here: the queries were consumed by the attention above, the fused qkv rows by RoPE + append)
+            { ProfScope ps(c, MMD_K_OTHER, 0, 0);
+              HIPCHK(c, launch_gather_rows2(c->l_attn, (int64_t)nh * d, attn_c, nh * d, c->l_h, H, h_c, H, need_rows, n_need, st)); }
+            int sp = 1;
+            rc = slab_gemm(attn_c, (int64_t)nh * d, L.wo_p, H, nh * d, &sp, L.wo_8, L.so, nullptr, n_need); if (rc) return rc;
+            { ProfScope ps(c, MMD_K_NORM_ROPE, 4.0 * n_need * H * e, 0);
+              HIPCHK(c, launch_slab_resid_rmsnorm(c->splitk_ws, sp, n_need, H, h_c, h_c, L.ln2, g.rms_norm_eps, c->l_xn, st)); }
+            rc = gemm(c, c->l_xn, H, L.wgu, H, nullptr, nullptr, 0, c->l_act, I, n_need, 2 * I, H, EPI_SWIGLU, 0, GEMM_AUTO, L.wgu_p, false, L.wgu_8, L.sgu); if (rc) return rc;
+            rc = slab_gemm(c->l_act, I, L.wdown_p, H, I, &sp, L.wdown_8, L.sdown, nullptr, n_need); if (rc) return rc;
+            { ProfScope ps(c, MMD_K_NORM_ROPE, 4.0 * n_need * H * e, 0);
+              HIPCHK(c, launch_slab_resid_rmsnorm(c->splitk_ws, sp, n_need, H, h_c, h_c, c->fnorm, g.rms_norm_eps, c->l_hid, st)); }
+            c->hid_compact = n_need;
+            xn_ready = true;          // (the final norm is done)
+            continue;
+        }
         if (chain) {
             rc = slab_gemm(c->l_attn, (int64_t)nh * d, L.wo_p, H, nh * d, &splits, L.wo_8, L.so, &ch_fin); if (rc) return rc;
             ch_xn.xn_gamma = L.ln2;
@@ -1325,13 +1358,17 @@ extern "C" int mmd_frame_step_multi(mmd_ctx* c, mmd_stream* const* streams, cons
     if ((n_head_rows && (!head_rows || !heads_out_host)) || (n_hidden_rows && (!hidden_rows || !hidden_rows_out))) FAIL(c, MMD_EINVAL, "null row/result pointer");
     for (int i = 0; i < n_head_rows; ++i) if (head_rows[i] < 0 || head_rows[i] >= S) FAIL(c, MMD_ERANGE, "head row %d outside the step", head_rows[i]);
     for (int i = 0; i < n_hidden_rows; ++i) if (hidden_rows[i] < 0 || hidden_rows[i] >= S) FAIL(c, MMD_ERANGE, "hidden row %d outside the step", hidden_rows[i]);
-    rc = llm_step_segs(c, segs.data(), n_segs, embeds, S, nullptr, nullptr); if (rc) return rc;
+    // the rows whose final hidden state is read: heads first, then the hidden / logit rows (llm_step_segs may then leave l_hid compact, in this order)
+    int32_t need[64]; int n_need = 0;
+    if (n_head_rows + n_hidden_rows <= 64) { for (int i = 0; i < n_head_rows; ++i) need[n_need++] = head_rows[i]; for (int i = 0; i < n_hidden_rows; ++i) need[n_need++] = hidden_rows[i]; }
+    rc = llm_step_segs(c, segs.data(), n_segs, embeds, S, nullptr, nullptr, n_need ? need : nullptr, n_need); if (rc) return rc;
+    const bool compact = c->hid_compact > 0;
     hipStream_t st = c->stream; const int H = c->cfg.hidden_size; const size_t e = es(c);
     for (int i = 0; i < n_hidden_rows; ++i)
-        HIPCHK(c, hipMemcpyAsync((char*)hidden_rows_out + (size_t)i * H * e, (char*)c->l_hid + (size_t)hidden_rows[i] * H * e, (size_t)H * e, hipMemcpyDeviceToDevice, st));
+        HIPCHK(c, hipMemcpyAsync((char*)hidden_rows_out + (size_t)i * H * e, (char*)c->l_hid + (size_t)(compact ? n_head_rows + i : hidden_rows[i]) * H * e, (size_t)H * e, hipMemcpyDeviceToDevice, st));
     if (n_hidden_rows && logits_out) { rc = mmd_lm_head(c, hidden_rows_out, n_hidden_rows, logits_out); if (rc) return rc; }
     if (n_head_rows) {
-        for (int i = 0; i < n_head_rows; ++i) c->rows_host[i] = head_rows[i];
+        for (int i = 0; i < n_head_rows; ++i) c->rows_host[i] = compact ? i : head_rows[i];
         HIPCHK(c, hipMemcpyAsync(c->rows_dev, c->rows_host, sizeof(int32_t) * n_head_rows, hipMemcpyHostToDevice, st));
         { ProfScope ps(c, MMD_K_OTHER, 0, 0);
           HIPCHK(c, launch_heads(c->cfg.dtype, c->l_hid, H, c->rows_dev, n_head_rows, c->heads4, H, c->heads_dev, st)); }
@@ -1358,9 +1395,13 @@ extern "C" int mmd_lm_head(mmd_ctx* c, const void* hidden, int M, float* logits)
 extern "C" int mmd_frame_step(mmd_ctx* c, mmd_stream* s, const void* embeds, int S, const int32_t* rows_host, int n_rows, float* out_host) {
     NEED_FINAL(c);
     if (n_rows < 0 || n_rows > S) FAIL(c, MMD_EINVAL, "bad head row count");
-    int rc = mmd_llm_step(c, s, embeds, S, nullptr); if (rc) return rc;
+    for (int i = 0; i < n_rows; ++i) if (rows_host[i] < 0 || rows_host[i] >= S) FAIL(c, MMD_ERANGE, "head row %d outside the step", rows_host[i]);
+    if (!s || s->ctx != c) FAIL(c, MMD_EINVAL, "stream does not belong to this context");
+    StepSeg one{s, 0, S};
+    int rc = S > 0 ? llm_step_segs(c, &one, 1, embeds, S, nullptr, nullptr, (n_rows > 0 && n_rows <= 64) ? rows_host : nullptr, n_rows) : MMD_OK; if (rc) return rc;
     if (n_rows == 0) return MMD_OK;
-    for (int i = 0; i < n_rows; ++i) { if (rows_host[i] < 0 || rows_host[i] >= S) FAIL(c, MMD_ERANGE, "head row %d outside the step", rows_host[i]); c->rows_host[i] = rows_host[i]; }
+    const bool compact = c->hid_compact > 0;
+    for (int i = 0; i < n_rows; ++i) c->rows_host[i] = compact ? i : rows_host[i];
     hipStream_t st = c->stream;
     HIPCHK(c, hipMemcpyAsync(c->rows_dev, c->rows_host, sizeof(int32_t) * n_rows, hipMemcpyHostToDevice, st));
     { ProfScope ps(c, MMD_K_OTHER, 0, 0);

@@ -569,6 +569,27 @@ hipError_t launch_pool_compact_bilinear(int dtype, const void* x, void* y, int B
     return hipGetLastError();
 }
 
+// ya[i, :] = xa[rows[i], :], yb[i, :] = xb[rows[i], :]  (2-byte elements; the rows of a chunk's last decoder layer that anything downstream reads).  The row list
+// travels as a kernel argument: no staging copy, nothing for a later step to overwrite.  grid = (n, 2).
+struct NeedRows { int32_t r[64]; };
+__global__ void gather_rows2_kernel(const unsigned short* __restrict__ xa, long long lda, unsigned short* __restrict__ ya, int Wa,
+                                    const unsigned short* __restrict__ xb, long long ldb, unsigned short* __restrict__ yb, int Wb, NeedRows rows) {
+    const bool second = blockIdx.y != 0;
+    const long long ldx = second ? ldb : lda; const int W = second ? Wb : Wa;
+    const unsigned short* src = (second ? xb : xa) + (long long)rows.r[blockIdx.x] * ldx;
+    unsigned short* dst = (second ? yb : ya) + (long long)blockIdx.x * W;
+    if ((W & 7) == 0 && (ldx & 7) == 0) { for (int i = threadIdx.x; i < W / 8; i += blockDim.x) reinterpret_cast<u32x4_t*>(dst)[i] = reinterpret_cast<const u32x4_t*>(src)[i]; }
+    else for (int i = threadIdx.x; i < W; i += blockDim.x) dst[i] = src[i];
+}
+hipError_t launch_gather_rows2(const void* xa, int64_t lda, void* ya, int Wa, const void* xb, int64_t ldb, void* yb, int Wb, const int32_t* rows_host, int n, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    if (n > 64) return hipErrorInvalidValue;
+    NeedRows rows; for (int i = 0; i < 64; ++i) rows.r[i] = rows_host[i < n ? i : n - 1];
+    hipLaunchKernelGGL(gather_rows2_kernel, dim3(n, 2), dim3(256), 0, st, (const unsigned short*)xa, (long long)lda, (unsigned short*)ya, Wa,
+                       (const unsigned short*)xb, (long long)ldb, (unsigned short*)yb, Wb, rows);
+    return hipGetLastError();
+}
+
 hipError_t launch_pool(int dtype, const void* x, void* y, int B, int grid, int H, int mode, int stride, hipStream_t st) {
     int out = mode == MMD_POOL_BILINEAR ? (grid + stride - 1) / stride : mode == MMD_POOL_ADAPTIVE_AVG ? stride : grid / stride;   // adaptive: `stride` carries the output side
     if (B <= 0 || out <= 0) return hipSuccess;

@@ -188,6 +188,52 @@ print("RES " + json.dumps(res))
         assert ra == pytest.approx(rb, abs=3e-2, rel=3e-2)
 
 
+def test_chunk_last_layer_on_read_rows_only(true_shape):
+    """A chunk's last decoder layer runs o_proj / MLP / final norm only on the rows something reads (frame-end head rows, the logit row) through the weight-streaming
+    kernels; MMDUET_FULL_LAST_LAYER=1 keeps all rows on the tile GEMMs.  Same rows, same weights, other GEMM kernels -> bf16-rounding-level agreement on the chunk itself,
+    and the KV arena it leaves behind is the same to the bit (a following small step reads it back)."""
+    import subprocess, sys, os, json
+    code = r'''
+import os, sys, json, torch
+sys.path.insert(0, os.environ["MMD_ROOT"]); sys.path.insert(0, os.path.join(os.environ["MMD_ROOT"], "tests"))
+from oracle import duet_oracle as O
+from mmduet_amd.configuration_live import VideoHeadLiveLlavaQwenConfig
+from mmduet_amd.modeling_live import VideoHeadLiveLlavaQwenForCausalLM
+ocfg = O.OracleConfig(vocab_size=2048, num_hidden_layers=2, vit_layers=1)
+w = {k: v for k, v in O.random_weights(ocfg, seed=3, dtype=torch.bfloat16, scale="unit").items()}
+pcfg = VideoHeadLiveLlavaQwenConfig(vocab_size=2048, num_hidden_layers=2, vit_num_hidden_layers=2, vit_layers_removed=1, frame_num_tokens=49, frame_resolution=384)
+m = VideoHeadLiveLlavaQwenForCausalLM(pcfg, torch_dtype=torch.bfloat16, max_vit_batch=1, max_step_tokens=768, kv_initial_tokens=4096)
+m.load_state_dict(w)
+g = torch.Generator().manual_seed(11)
+def rnd(S): return (torch.randn(S, 3584, generator=g) * 0.5).to(torch.bfloat16).cuda()
+res = []
+# single stream: 64 frame-end rows of a 640-row chunk, then one row twice + the first row of a 333-row chunk, then 65 rows (all rows computed), then a small step
+c = None
+for S, rows in ((640, list(range(9, 640, 10))), (333, [332, 332, 0]), (130, list(range(0, 130, 2))), (5, [4])):
+    h, c = m.frame_step(rnd(S), c, rows)
+    res.append(h.flatten().tolist())
+# two streams in one forward: heads on one, last-row logits on the other; then each stream alone on a small step
+a = m.multi_step([dict(x=rnd(300), cache=None, head_rows=[99, 199, 299], hidden='none'), dict(x=rnd(150), cache=None, head_rows=[], hidden='last')], want_logits=True)
+res.append(a[0]['heads'].flatten().tolist() + a[1]['logits'][0, :16].float().cpu().tolist() + a[1]['hidden'].float().cpu().flatten()[:16].tolist())
+for k in (0, 1):
+    h, _ = m.frame_step(rnd(3), a[k]['cache'], [2]); res.append(h.flatten().tolist())
+print("RES " + json.dumps(res))
+'''
+    from conftest import ROOT
+    def run(**kw):
+        env = dict(os.environ, MMD_ROOT=ROOT, **kw)
+        r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith('RES ')][0][4:])
+    a, b, a2 = run(), run(MMDUET_FULL_LAST_LAYER='1'), run()
+    assert a == a2
+    assert len(a[0]) == 64 * 4 and len(a[2]) == 65 * 4
+    for ra, rb in zip(a, b):
+        assert ra == pytest.approx(rb, abs=3e-2, rel=3e-2)
+    assert a[2] == b[2]                         # 65 read rows: both runs take the all-rows path
+    assert a[3] == b[3] and a[5] == b[5] and a[6] == b[6]        # later steps read only K / V, which do not depend on the last layer's tail
+
+
 def test_multi_stream_step_true_shape(true_shape):
     """bf16 at the 7B widths: one forward over three arenas (a 98-row frame chunk, a 49-row frame, one decode row) against the oracle
     run stream by stream -- the merged forward takes the tile-GEMM path where the single-stream steps take the weight-streaming one."""
