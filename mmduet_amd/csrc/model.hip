@@ -94,6 +94,7 @@ struct mmd_ctx {
     bool tower_compact = false;        // the tower's output of the current batch is the compact [B * (2 out)^2, C] block in v_col (set by vit_tower, consumed by connector_pool)
     bool full_projector = false;       // set while mmd_vit_debug_tap(stage 1) recomputes the projector over ALL tokens (the shipped path runs it on the tokens the bilinear pool reads)
     bool no_slab_norm = false;         // MMDUET_NO_SLAB_NORM=1: a chunk's split-K down_proj keeps splitk_reduce + a separate RMSNorm launch (A/B)
+    bool full_last_layer = false;      // MMDUET_FULL_LAST_LAYER=1: a chunk's last decoder layer keeps o_proj / MLP / final norm on all rows (A/B)
     bool no_chain = false;             // MMDUET_NO_CHAIN=1: decode steps keep the separate reduce+residual+RMSNorm launches (A/B)
     void* rope_tab = 0;                // (cos, sin) of a decode step's positions (launch_rope_table), read by the attention kernel's fused q/k/v preparation
     bool no_rope_fuse = false;         // MMDUET_NO_ROPE_FUSE=1: decode steps keep the slab_rope_append launch (A/B)
@@ -210,6 +211,7 @@ extern "C" int mmd_create(const mmd_config* cfg, int device, mmd_ctx** out) {
     { const char* nf = getenv("MMDUET_NO_FUSE"); c->no_fuse = nf && nf[0] == '1'; }
     { const char* nf = getenv("MMDUET_NO_CHAIN"); c->no_chain = nf && nf[0] == '1'; }
     { const char* nf = getenv("MMDUET_NO_SLAB_NORM"); c->no_slab_norm = nf && nf[0] == '1'; }
+    { const char* nf = getenv("MMDUET_FULL_LAST_LAYER"); c->full_last_layer = nf && nf[0] == '1'; }
     { const char* nf = getenv("MMDUET_NO_ROPE_FUSE"); c->no_rope_fuse = nf && nf[0] == '1'; }
     { const char* e = getenv("MMDUET_TOWER_RING"); if (e) c->tower_ring_flags = atoi(e); e = getenv("MMDUET_TOWER_RING_BLOCKS"); if (e) c->tower_ring_blocks = atoi(e); }
     // graph replay of the decode step is opt-in (MMDUET_GRAPH=1): measured on MI355X it is not faster than eager launches
@@ -1201,9 +1203,8 @@ static int llm_step_segs(mmd_ctx* c, const StepSeg* segs, int nseg, const void* 
     // The hidden states of a chunk's LAST layer are read at a few rows only (the frame-end rows of the two heads, the row whose logits are wanted); its K / V must exist
     // for every token, but its o_proj and MLP are row-wise: they run on the rows somebody reads, through the weight-streaming kernels (M <= 64).  The reference computes all
     // rows and drops them (the lm_head over all positions is "pure waste the build skips" -- the same holds one layer down).
-    static const bool no_sparse_last = getenv("MMDUET_FULL_LAST_LAYER") != nullptr;
     bool sparse_last = false;
-    if (need_rows && n_need > 0 && n_need <= 64 && !fused && S > 64 && dt == MMD_BF16 && H <= 4096 && (H & 3) == 0 && !c->no_fuse && !no_sparse_last && !hidden_out && !dyn) {
+    if (need_rows && n_need > 0 && n_need <= 64 && !fused && S > 64 && dt == MMD_BF16 && H <= 4096 && (H & 3) == 0 && !c->no_fuse && !c->full_last_layer && !hidden_out && !dyn) {
         GemmArgs probe; memset(&probe, 0, sizeof(probe));
         probe.X = c->l_q; probe.ldx = nh * d; probe.Wp = c->L[0].wo_p; probe.M = n_need; probe.N = H; probe.K = nh * d; probe.epi = EPI_NONE;
         probe.splitk_ws = c->splitk_ws; probe.splitk_ws_bytes = c->splitk_bytes;
