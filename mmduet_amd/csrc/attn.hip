@@ -1164,6 +1164,224 @@ __global__ __launch_bounds__(256, 2) void attn_rowmajor_kernel(AttnP p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// attn_d72_ring_kernel: the SigLIP-so400m shape of attn_rowmajor_kernel (head_dim 72, bidirectional) with the K / V tiles brought in by LDS-DMA into two
+// slots instead of through staging registers.  attn_rowmajor_kernel holds one tile in LDS and the next in 24 staging registers, commits them between two block
+// barriers per tile and gathers V in 16-byte pieces from 32 different rows per load; it runs three blocks per CU at 146 registers.  Here tile i + 1 lands in the
+// other slot while tile i is consumed, ONE raw s_barrier per tile both publishes tile i and retires the slot of tile i - 1, nothing is staged in registers
+// (128 registers, 40 KB of LDS: four blocks per CU), and both DMAs read 144 contiguous bytes per key.  187 -> 145 us per layer at 35 frames (MI355X, in the model).
+// Same products, same summation order outside the matrix instructions as attn_rowmajor_kernel<3, 5, *, true>; the tower's output is the same to the bit on the seeded
+// frames of tools/probes/vit_ring_ab.py (MMDUET_VIT_ATTN_RING=0 keeps the register-staged kernel).
+//   K image: [64 keys][72] UNPADDED (row stride 144 B = 36 banks: 9 * lr mod 16 is a permutation, the 16-lane b128 fragment reads are conflict-free), padded to ten
+//            1 KB DMA blocks by 64 duplicate chunks.  Dims 0..63 take two 32-deep MFMAs, dims 64..71 one 16-deep MFMA (see qt below).
+//   V image: [64 keys][80] ROW-MAJOR (row stride 160 B: the tenth 16-byte place of a key re-reads its ninth chunk -- output columns 72..79 are never stored).
+//            ds_read_b64_tr_b16 takes one address per lane and transposes by lane position, so the 4-key x 16-dim block a 16-lane group wants need not be
+//            contiguous: lane (key lr >> 2, dims 4 * (lr & 3)) points into the row-major rows (stride 40 dwords = 8 mod 32: the group's 16 x 8 bytes fall on
+//            distinct banks).  With the blocked [d-tile][quad][4][16] image of attn_rowmajor_kernel a 1 KB DMA block touches 32 cache lines and uses a quarter
+//            of each; row-major it touches 7-8 (measured: 153 -> 145 us).
+// Waves 0-1 bring K, waves 2-3 V: five 1 KB blocks each per tile.
+// ------------------------------------------------------------------------------------------------------------------
+template <bool F16>
+__global__ __launch_bounds__(256, 4) void attn_d72_ring_kernel(AttnP p) {
+    constexpr int RT = 2, KT = 64, NC = 2, DVT = 5, D = 72, NPW = 5, NSLOT = 2;
+    constexpr int IMG = 10 * 512;                                 // elements per image (10 KB)
+    extern __shared__ __attribute__((aligned(16))) bf16_t ring72[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lq = lane >> 4;
+    const int G = p.nh / p.nkv;
+    int bx, by, bz; xcd_block_id(bx, by, bz);
+    const int head = by, kvh = head / G, b = bz;
+    const int kend = (int)(p.n_ctx + p.S);
+    const bf16_t* Kg = (const bf16_t*)p.K + b * p.kv_bs + kvh * p.k_hs;
+    const bf16_t* Vg = (const bf16_t*)p.V + b * p.kv_bs + kvh * p.v_hs;
+    const int row_base = bx * (64 * RT) + wave * (16 * RT);
+
+    int my_tok[RT]; bool row_ok[RT];
+    bf16x8_t qf[RT][NC];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        my_tok[rt] = row_base + rt * 16 + lr;
+        row_ok[rt] = my_tok[rt] < p.S;
+        const bf16_t* qrow = (const bf16_t*)p.q + b * p.q_bs + (long long)(row_ok[rt] ? my_tok[rt] : 0) * p.ldq + (long long)head * D;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int e = c * 32 + lq * 8;
+            s16x8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (row_ok[rt] && e + 8 <= D) v = *reinterpret_cast<const s16x8_t*>(qrow + e);
+            qf[rt][c] = __builtin_bit_cast(bf16x8_t, v);
+        }
+    }
+    // dims 64..71 go through ONE 16-deep MFMA (dims 64..79: 8-byte fragments, lanes lq >= 2 hold zeros) instead of a 32-deep one that is three quarters padding:
+    // four registers fewer (what keeps the kernel at 128 and four blocks on a CU), a quarter fewer K bytes out of LDS for that step, half its matrix time
+    s16x4_t qt[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        qt[rt] = s16x4_t{0, 0, 0, 0};
+        if (row_ok[rt] && lq < 2) {
+            const bf16_t* qrow = (const bf16_t*)p.q + b * p.q_bs + (long long)my_tok[rt] * p.ldq + (long long)head * D;
+            qt[rt] = *reinterpret_cast<const s16x4_t*>(qrow + 64 + lq * 4);
+        }
+    }
+    const bool wave_active = row_base < p.S;
+
+    // this lane's five pieces of a tile: (key, byte column) of the 16 bytes that belong at its place of the wave's five 1 KB blocks
+    const bool isK = wave < 2;
+    const char* src = (const char*)(isK ? Kg : Vg);
+    const int ts2 = (int)(isK ? p.k_ts : p.v_ts) * 2;
+    unsigned poff[NPW];                                           // byte offset of the piece inside a tile that starts at key 0
+#pragma unroll
+    for (int u = 0; u < NPW; ++u) {
+        const int ci = ((isK ? wave : wave - 2) * NPW + u) * 64 + lane;                 // 0 .. 639
+        if (isK) {
+            int key = ci / 9, c = ci - key * 9;
+            if (ci >= 64 * 9) { key = 63; c = 8; }
+            poff[u] = (unsigned)(key * ts2 + c * 16);
+        } else {
+            const int key = ci / 10, c = ci - key * 10;                  // ten 16-byte places per key, the tenth (padding) re-reads the ninth chunk
+            poff[u] = (unsigned)(key * ts2 + (c < 9 ? c : 8) * 16);
+        }
+    }
+    const unsigned last_row = (unsigned)((kend - 1) * ts2 + (D - 8) * 2);          // a key past the end re-reads the last chunk of the last row (finite; its scores are masked, its P is 0); row stride >= 144 B > 128
+    auto stage = [&](int slot, int k0) {
+        bf16_t* img = ring72 + slot * (2 * IMG) + (isK ? 0 : IMG) + (isK ? wave : wave - 2) * (NPW * 512);
+        const unsigned t0 = (unsigned)(k0 * ts2);
+#pragma unroll
+        for (int u = 0; u < NPW; ++u) {
+            unsigned off = min(t0 + poff[u], last_row);
+            asm volatile("" : "+v"(off));
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off), (__attribute__((address_space(3))) void*)(img + u * 512), 16, 0, 0);
+        }
+    };
+
+    f32x4_t oacc[RT][DVT];
+    float m_run[RT], l_run[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        m_run[rt] = -INFINITY; l_run[rt] = 0.f;
+#pragma unroll
+        for (int t = 0; t < DVT; ++t) oacc[rt][t] = f32x4_t{0, 0, 0, 0};
+    }
+
+    const int ntile = (kend + KT - 1) >> 6;
+#pragma unroll
+    for (int i = 0; i < NSLOT - 1; ++i) if (i < ntile) stage(i, i * KT);
+    // the q fragments are ordinary loads: hipcc waits for them with vmcnt(0), which would drain the ring wherever their first use lands -- make that here, once
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) asm volatile("" :: "v"(qf[rt][c]));
+    asm volatile("" :: "v"(qt[0])); asm volatile("" :: "v"(qt[1]));
+
+    for (int i = 0; i < ntile; ++i) {
+        const int k0 = i * KT;
+        // tile i's own five blocks have landed once at most the younger tiles' are outstanding; the barrier publishes everybody's and retires the slot of tile i - 1
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (i + NSLOT - 1 < ntile) stage((i + NSLOT - 1) % NSLOT, k0 + (NSLOT - 1) * KT);
+        if (!wave_active) continue;
+        const bf16_t* Ks = ring72 + (i % NSLOT) * (2 * IMG);
+        const bf16_t* Vs = Ks + IMG;
+        const bool need_mask = k0 + KT > kend;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f32x4_t st[RT][2];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) { st[rt][0] = f32x4_t{0, 0, 0, 0}; st[rt][1] = f32x4_t{0, 0, 0, 0}; }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + (h * 32 + t * 16 + lr) * D + c * 32 + lq * 8);
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) st[rt][t] = mfma16<F16>(kf, qf[rt][c], st[rt][t]);
+                }
+                const s16x4_t kt = *reinterpret_cast<const s16x4_t*>(Ks + (h * 32 + t * 16 + lr) * D + 64 + lq * 4);       // (lq >= 2: the next key's first dims -- finite, against zeros)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    if constexpr (F16) st[rt][t] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4_t, kt), __builtin_bit_cast(f16x4_t, qt[rt]), st[rt][t], 0, 0, 0);
+                    else st[rt][t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kt, qt[rt], st[rt][t], 0, 0, 0);
+                }
+            }
+            bf16x8_t pf[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                float sv[8];
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sv[t * 4 + r] = st[rt][t][r];
+                if (need_mask) {                  // wave-uniform: the tile at the end of the keys only
+                    int lim = (row_ok[rt] ? kend : 0) - (k0 + h * 32 + lq * 4);
+                    asm volatile("" : "+v"(lim));             // (keeps this a BRANCH and the compares inside it: hipcc otherwise evaluates 7 compares + 8 selects per row tile in EVERY tile)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (!(t * 16 + r < lim)) sv[t * 4 + r] = -INFINITY;
+                }
+                float mx = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
+                mx = quad_lanes_max(mx);
+                mx *= p.scale_log2;
+                if (mx > m_run[rt] + ATTN_DEFER) {
+                    const float alpha = __builtin_amdgcn_exp2f(m_run[rt] - mx);
+                    l_run[rt] *= alpha;
+#pragma unroll
+                    for (int t = 0; t < DVT; ++t) oacc[rt][t] *= alpha;
+                    m_run[rt] = mx;
+                }
+                const float neg_m = m_run[rt] == -INFINITY ? 0.f : -m_run[rt];
+                float psum = 0.f;
+                s16x8_t pk;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { float pv = __builtin_amdgcn_exp2f(fmaf(sv[e], p.scale_log2, neg_m)); psum += pv; pk[e] = (short)f2raw<F16>(pv); }
+                l_run[rt] += psum;
+                pf[rt] = __builtin_bit_cast(bf16x8_t, pk);
+            }
+            // the five d-tiles' V^T fragments of this half tile, read BEHIND the softmax (20 registers that are then not live across it).  ds_read_b64_tr_b16 through
+            // the builtin carries no memory operand and hipcc drains the DMA ring (vmcnt(0)) in front of it: issued from one asm block instead, and waited for there
+            s16x4_t vlo[DVT], vhi[DVT];
+            {
+                const unsigned va = (unsigned)(uintptr_t)((const __attribute__((address_space(3))) bf16_t*)Vs) + (unsigned)((h * 32 + lq * 4 + (lr >> 2)) * 160 + (lr & 3) * 8);
+                asm volatile("ds_read_b64_tr_b16 %0, %10\n\tds_read_b64_tr_b16 %1, %10 offset:2560\n\t"
+                             "ds_read_b64_tr_b16 %2, %10 offset:32\n\tds_read_b64_tr_b16 %3, %10 offset:2592\n\t"
+                             "ds_read_b64_tr_b16 %4, %10 offset:64\n\tds_read_b64_tr_b16 %5, %10 offset:2624\n\t"
+                             "ds_read_b64_tr_b16 %6, %10 offset:96\n\tds_read_b64_tr_b16 %7, %10 offset:2656\n\t"
+                             "ds_read_b64_tr_b16 %8, %10 offset:128\n\tds_read_b64_tr_b16 %9, %10 offset:2688\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(vlo[0]), "=&v"(vhi[0]), "=&v"(vlo[1]), "=&v"(vhi[1]), "=&v"(vlo[2]), "=&v"(vhi[2]), "=&v"(vlo[3]), "=&v"(vhi[3]), "=&v"(vlo[4]), "=&v"(vhi[4])
+                             : "v"(va) : "memory");
+            }
+#pragma unroll
+            for (int t = 0; t < DVT; ++t) {
+                const s16x4_t lo = vlo[t], hi = vhi[t];
+                s16x8_t vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                bf16x8_t vfb = __builtin_bit_cast(bf16x8_t, vf);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) oacc[rt][t] = mfma16<F16>(vfb, pf[rt], oacc[rt][t]);
+            }
+        }
+    }
+
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        float l = l_run[rt];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        if (!row_ok[rt]) continue;
+        bf16_t* orow = (bf16_t*)p.out + b * p.o_bs + (long long)my_tok[rt] * p.ldo + (long long)head * D;
+        const float inv = l > 0.f ? 1.0f / l : 0.f;
+#pragma unroll
+        for (int t = 0; t < DVT; ++t) {
+            const int e = t * 16 + lq * 4;
+            if (e + 4 <= D) {
+                s16x4_t o = {(short)f2raw<F16>(oacc[rt][t][0] * inv), (short)f2raw<F16>(oacc[rt][t][1] * inv), (short)f2raw<F16>(oacc[rt][t][2] * inv), (short)f2raw<F16>(oacc[rt][t][3] * inv)};
+                *reinterpret_cast<s16x4_t*>(orow + e) = o;
+            }
+        }
+    }
+}
+
 template <int NC, int DVT, bool EXACT = false>
 static hipError_t launch_rowmajor(AttnP& p, const AttnArgs& a, hipStream_t st, bool f16 = false) {
     p.splits = 1; p.kv_per_split = 0;
@@ -1226,6 +1444,19 @@ hipError_t launch_attention(int dtype, const AttnArgs& a, hipStream_t st) {
         if (!can_rowmajor) return hipErrorInvalidValue;
         if (a.d <= 32) return launch_rowmajor<1, 2>(p, a, st, f16);
         if (a.d <= 64) return launch_rowmajor<2, 4>(p, a, st, f16);
+        if (a.d == 72 && !a.causal && (a.k_ts % 8) == 0 && (a.v_ts % 8) == 0 && (a.k_hs % 8) == 0 && (a.v_hs % 8) == 0 && (a.kv_bstride % 8) == 0 &&
+            ((uintptr_t)a.K % 16) == 0 && ((uintptr_t)a.V % 16) == 0 && a.n_ctx + a.S > 0) {
+            // SigLIP-so400m, bidirectional: K / V tiles by LDS-DMA into two slots, four blocks per CU (MMDUET_VIT_ATTN_RING=0: the register-staged kernel, A/B)
+            static const bool ring_off = getenv("MMDUET_VIT_ATTN_RING") && atoi(getenv("MMDUET_VIT_ATTN_RING")) == 0;
+            if (!ring_off) {
+                p.splits = 1; p.kv_per_split = 0;
+                const dim3 grid(cdiv(a.S, 128), a.nh, a.batch);
+                const size_t lds = (size_t)2 * 2 * 10 * 512 * sizeof(bf16_t);
+                if (f16) hipLaunchKernelGGL((attn_d72_ring_kernel<true>), grid, dim3(256), lds, st, p);
+                else hipLaunchKernelGGL((attn_d72_ring_kernel<false>), grid, dim3(256), lds, st, p);
+                return hipGetLastError();
+            }
+        }
         if (a.d > 64 && a.d <= 80) return launch_rowmajor<3, 5, true>(p, a, st, f16);          // SigLIP-so400m: 72 -> five 16-wide output tiles, known at compile time
         if (a.d <= 96) return launch_rowmajor<3, 6>(p, a, st, f16);
         return launch_rowmajor<4, 8>(p, a, st, f16);

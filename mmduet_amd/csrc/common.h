@@ -27,6 +27,7 @@ __device__ __forceinline__ bf16_t f2bf(float f) {            // round-to-nearest
 constexpr int MMD_F16 = 2;             // internal launcher dtype, never a context dtype: 2-byte IEEE half activations / weights, fp32 accumulate and statistics
 typedef _Float16 f16_t;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
 __device__ __forceinline__ float h2f(uint16_t r) { return (float)__builtin_bit_cast(_Float16, r); }
 __device__ __forceinline__ uint16_t f2h(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }          // round-to-nearest-even (v_cvt_f16_f32)
 // raw 16-bit storage <-> float for kernels that move 2-byte elements as integer vectors

@@ -68,3 +68,26 @@ def test_two_slot_forms_unchanged(attn_isa):
     for name in ('_Z18attn_gqa128_kernelILi2ELi2ELi4EEv5AttnP', '_Z18attn_gqa128_kernelILi1ELi2ELi4EEv5AttnP'):
         lines, meta = _kernel(attn_isa, name)
         assert not any('scratch_' in l for l in lines), name
+
+
+@pytest.mark.parametrize('mangled', ['_Z20attn_d72_ring_kernelILb1EEv5AttnP', '_Z20attn_d72_ring_kernelILb0EEv5AttnP'])
+def test_vit_ring_kernel_fits_four_blocks_and_keeps_its_dma_in_flight(attn_isa, mangled):
+    """attn_d72_ring_kernel (fp16 / bf16 tower): 128 registers and no scratch are what put four blocks on a CU (at 130 it is three; a spill reload is VMEM and drains the
+    DMA of the next tile); the only vmcnt wait of the tile loop is the hand-written one in front of the barrier -- hipcc's own would sit in front of the transposing V
+    reads (it did, while they went through the builtin) and serialise every tile behind its successor's DMA."""
+    lines, meta = _kernel(attn_isa, mangled)
+    assert not any('scratch_' in l for l in lines), 'the ViT ring attention spills'
+    assert re.search(r'; ScratchSize: 0\b', meta)
+    assert int(re.search(r'; NumVgprs: (\d+)', meta).group(1)) <= 128
+    hdr = [i for i, l in enumerate(lines) if 'This Inner Loop Header: Depth=1' in l]
+    inl = [i for i, l in enumerate(lines) if re.search(r'in Loop: Header=BB\d+_\d+ Depth=1', l)]
+    assert len(hdr) == 1 and inl and max(inl) > hdr[0]
+    end = next(i for i in range(max(inl) + 1, len(lines)) if re.match(r'\.LBB\d+_\d+:', lines[i]))          # the label behind the loop's last block
+    loop = lines[hdr[0]:end]
+    assert sum('s_barrier' in l for l in loop) == 1
+    assert sum('global_load_lds_dwordx4' in l for l in loop) == 5          # this wave's five 1 KB blocks of the next tile
+    assert sum('v_mfma_f32_16x16x32' in l for l in loop) == 36 and sum('v_mfma_f32_16x16x16' in l for l in loop) == 8
+    assert sum('ds_read_b64_tr_b16' in l for l in loop) == 20
+    waits = [(i, l.strip()) for i, l in enumerate(loop) if 'vmcnt' in l]
+    assert len(waits) == 1 and waits[0][1] == 's_waitcnt vmcnt(0)' and 'ASMSTART' in loop[waits[0][0] - 1], waits
+    assert not any(re.match(r'\s*global_load_dword', l) for l in loop), 'an ordinary global load inside the ring loop'

@@ -268,6 +268,39 @@ def test_tower_batch_of_35_frames_true_width(width2):
     assert e_ours <= 3 * e_ref + 2e-2 * max(1.0, scale), (e_ours, e_ref, scale)
 
 
+def test_vit_ring_attention_equals_register_staged_kernel():
+    """attn_d72_ring_kernel (K / V by LDS-DMA, row-major V image, 16-deep MFMA for dims 64..71) against attn_rowmajor_kernel<3, 5> (MMDUET_VIT_ATTN_RING=0) inside the
+    tower at the true widths: fp16 and bf16 tower, 35 frames (6 query blocks x 16 heads x 35, last key tile 25 of 64) and 3 frames, the pooled output of the sparse last
+    layer (196 query rows over 729 keys) and of the full tower.  Same products, same order outside the matrix instructions -> equal digests."""
+    import subprocess, sys, hashlib
+    code = r'''
+import os, sys, json, hashlib, torch
+sys.path.insert(0, os.environ["MMD_ROOT"]); sys.path.insert(0, os.path.join(os.environ["MMD_ROOT"], "tests"))
+from test_gpu_production import _build
+res = {}
+for tower in ("fp16", "bf16"):
+    m, w, ocfg = _build(1, 2, torch.bfloat16, max_vit_batch=35, max_step_tokens=64, tower_dtype=tower)
+    g = torch.Generator(device=m.device).manual_seed(5)
+    for nf in (35, 3):
+        px = torch.randn(nf, 3, 384, 384, generator=g, device=m.device).to(torch.bfloat16)
+        for full in (False, True):
+            m.set_full_tower(full)
+            y = m.visual_embed(px); torch.cuda.synchronize()
+            assert torch.isfinite(y.float()).all()
+            res[f"{tower}_{nf}_{int(full)}"] = hashlib.sha256(y.float().cpu().numpy().tobytes()).hexdigest()
+    m.set_full_tower(False)
+    del m, w; torch.cuda.empty_cache()
+print("RES " + json.dumps(res))
+'''
+    def run(**kw):
+        r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, MMD_ROOT=ROOT, **kw), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith('RES ')][0][4:])
+    ring, staged = run(), run(MMDUET_VIT_ATTN_RING='0')
+    assert len(ring) == 8 and len(set(ring.values())) >= 4
+    assert ring == staged
+
+
 def test_chunk_of_26_frames_equals_26_frame_steps_true_width(width2):
     """(d) k = 26 (M = 1274 + prefix: ring GEMMs, gqa128 chunk attention) vs 26 one-frame steps (weight-streaming kernels) vs the fp32 oracle.
     tolerance on head logits: 6e-2 (bf16, 2 layers), and chunk == per-frame within the same bound."""
