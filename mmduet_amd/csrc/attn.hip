@@ -1183,8 +1183,10 @@ __global__ __launch_bounds__(256, 2) void attn_rowmajor_kernel(AttnP p) {
 // ------------------------------------------------------------------------------------------------------------------
 template <bool F16>
 __global__ __launch_bounds__(256, 4) void attn_d72_ring_kernel(AttnP p) {
-    constexpr int RT = 2, KT = 64, NC = 2, DVT = 5, D = 72, NPW = 5, NSLOT = 2;
-    constexpr int IMG = 10 * 512;                                 // elements per image (10 KB)
+    constexpr int WAVES = 4, RT = 2, NC = 2, DVT = 5, D = 72, KT = 64, NSLOT = 2;
+    constexpr int NBLK = 10;                                          // 1 KB DMA blocks per image: K [64][72] padded to that, V [64][80]
+    constexpr int NPW = NBLK / 2;                                     // ... per wave and tile: waves 0-1 bring K, waves 2-3 V
+    constexpr int IMG = NBLK * 512;                                   // elements per image
     extern __shared__ __attribute__((aligned(16))) bf16_t ring72[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1195,7 +1197,7 @@ __global__ __launch_bounds__(256, 4) void attn_d72_ring_kernel(AttnP p) {
     const int kend = (int)(p.n_ctx + p.S);
     const bf16_t* Kg = (const bf16_t*)p.K + b * p.kv_bs + kvh * p.k_hs;
     const bf16_t* Vg = (const bf16_t*)p.V + b * p.kv_bs + kvh * p.v_hs;
-    const int row_base = bx * (64 * RT) + wave * (16 * RT);
+    const int row_base = bx * (16 * RT * WAVES) + wave * (16 * RT);
 
     int my_tok[RT]; bool row_ok[RT];
     bf16x8_t qf[RT][NC];
@@ -1226,16 +1228,17 @@ __global__ __launch_bounds__(256, 4) void attn_d72_ring_kernel(AttnP p) {
     const bool wave_active = row_base < p.S;
 
     // this lane's five pieces of a tile: (key, byte column) of the 16 bytes that belong at its place of the wave's five 1 KB blocks
-    const bool isK = wave < 2;
+    const bool isK = wave < WAVES / 2;
+    const int wsub = isK ? wave : wave - WAVES / 2;
     const char* src = (const char*)(isK ? Kg : Vg);
     const int ts2 = (int)(isK ? p.k_ts : p.v_ts) * 2;
     unsigned poff[NPW];                                           // byte offset of the piece inside a tile that starts at key 0
 #pragma unroll
     for (int u = 0; u < NPW; ++u) {
-        const int ci = ((isK ? wave : wave - 2) * NPW + u) * 64 + lane;                 // 0 .. 639
+        const int ci = (wsub * NPW + u) * 64 + lane;                 // 0 .. 639
         if (isK) {
             int key = ci / 9, c = ci - key * 9;
-            if (ci >= 64 * 9) { key = 63; c = 8; }
+            if (ci >= KT * 9) { key = KT - 1; c = 8; }
             poff[u] = (unsigned)(key * ts2 + c * 16);
         } else {
             const int key = ci / 10, c = ci - key * 10;                  // ten 16-byte places per key, the tenth (padding) re-reads the ninth chunk
@@ -1244,13 +1247,13 @@ __global__ __launch_bounds__(256, 4) void attn_d72_ring_kernel(AttnP p) {
     }
     const unsigned last_row = (unsigned)((kend - 1) * ts2 + (D - 8) * 2);          // a key past the end re-reads the last chunk of the last row (finite; its scores are masked, its P is 0); row stride >= 144 B > 128
     auto stage = [&](int slot, int k0) {
-        bf16_t* img = ring72 + slot * (2 * IMG) + (isK ? 0 : IMG) + (isK ? wave : wave - 2) * (NPW * 512);
+        bf16_t* img = ring72 + slot * (2 * IMG) + (isK ? 0 : IMG);
         const unsigned t0 = (unsigned)(k0 * ts2);
 #pragma unroll
         for (int u = 0; u < NPW; ++u) {
             unsigned off = min(t0 + poff[u], last_row);
             asm volatile("" : "+v"(off));
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off), (__attribute__((address_space(3))) void*)(img + u * 512), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off), (__attribute__((address_space(3))) void*)(img + (wsub * NPW + u) * 512), 16, 0, 0);
         }
     };
 
@@ -1320,7 +1323,8 @@ __global__ __launch_bounds__(256, 4) void attn_d72_ring_kernel(AttnP p) {
                         for (int r = 0; r < 4; ++r)
                             if (!(t * 16 + r < lim)) sv[t * 4 + r] = -INFINITY;
                 }
-                float mx = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
+                // (a chain, not a tree: every step but the last folds into a three-input v_max3_f32 -- 4 instructions for the 8 values instead of 7; max is exact in any order)
+                float mx = fmaxf(fmaxf(fmaxf(fmaxf(fmaxf(fmaxf(fmaxf(sv[0], sv[1]), sv[2]), sv[3]), sv[4]), sv[5]), sv[6]), sv[7]);
                 mx = quad_lanes_max(mx);
                 mx *= p.scale_log2;
                 if (mx > m_run[rt] + ATTN_DEFER) {
@@ -1334,7 +1338,12 @@ __global__ __launch_bounds__(256, 4) void attn_d72_ring_kernel(AttnP p) {
                 float psum = 0.f;
                 s16x8_t pk;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { float pv = __builtin_amdgcn_exp2f(fmaf(sv[e], p.scale_log2, neg_m)); psum += pv; pk[e] = (short)f2raw<F16>(pv); }
+                for (int e = 0; e < 8; e += 2) {          // the scale-and-shift FMA two elements at a time (v_pk_fma_f32: the same fused operation per element)
+                    const f32x2_t a = __builtin_elementwise_fma(f32x2_t{sv[e], sv[e + 1]}, f32x2_t{p.scale_log2, p.scale_log2}, f32x2_t{neg_m, neg_m});
+                    const float p0 = __builtin_amdgcn_exp2f(a[0]), p1 = __builtin_amdgcn_exp2f(a[1]);
+                    psum += p0; psum += p1;
+                    pk[e] = (short)f2raw<F16>(p0); pk[e + 1] = (short)f2raw<F16>(p1);
+                }
                 l_run[rt] += psum;
                 pf[rt] = __builtin_bit_cast(bf16x8_t, pk);
             }
@@ -1450,8 +1459,8 @@ hipError_t launch_attention(int dtype, const AttnArgs& a, hipStream_t st) {
             static const bool ring_off = getenv("MMDUET_VIT_ATTN_RING") && atoi(getenv("MMDUET_VIT_ATTN_RING")) == 0;
             if (!ring_off) {
                 p.splits = 1; p.kv_per_split = 0;
-                const dim3 grid(cdiv(a.S, 128), a.nh, a.batch);
                 const size_t lds = (size_t)2 * 2 * 10 * 512 * sizeof(bf16_t);
+                const dim3 grid(cdiv(a.S, 128), a.nh, a.batch);
                 if (f16) hipLaunchKernelGGL((attn_d72_ring_kernel<true>), grid, dim3(256), lds, st, p);
                 else hipLaunchKernelGGL((attn_d72_ring_kernel<false>), grid, dim3(256), lds, st, p);
                 return hipGetLastError();

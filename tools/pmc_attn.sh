@@ -12,4 +12,4 @@ for pass in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LD
   [ -n "$db" ] && python3 $R/tools/pmc_summary.py $db 2>/dev/null > $O/${tag}_pmc_attn_$i.txt
   rm -rf $O/pmc_$tag
 done
-grep -A9 "attn_gqa128_kernel<2, 4, 8>\|attn_rowmajor_kernel" $O/${tag}_pmc_attn_1.txt $O/${tag}_pmc_attn_2.txt | cut -c1-120
+grep -A9 "attn_gqa128_kernel<2, 4, 8>\|attn_rowmajor_kernel\|attn_d72_ring_kernel" $O/${tag}_pmc_attn_1.txt $O/${tag}_pmc_attn_2.txt | cut -c1-120

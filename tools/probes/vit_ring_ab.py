@@ -28,8 +28,9 @@ if len(sys.argv) > 1 and sys.argv[1] == 'child':
     print('RES ' + json.dumps(out))
     sys.exit(0)
 res = {}
-for mode in (os.environ.get('RING_MODES', '0,2,4,5,0,2,4,5').split(',')):
-    r = subprocess.run([sys.executable, os.path.abspath(__file__), 'child'], env=dict(os.environ, MMDUET_VIT_ATTN_RING=mode), capture_output=True, text=True, timeout=900)
+for mode in (os.environ.get('RING_MODES', '0,1,0,1').split(',')):
+    extra = dict(MMDUET_VIT_ATTN_RING=mode)
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), 'child'], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=900)
     line = [l for l in r.stdout.splitlines() if l.startswith('RES ')]
     if not line:
         print('mode', mode, 'FAILED', r.stderr[-1500:]); continue
