@@ -1454,7 +1454,7 @@ hipError_t launch_attention(int dtype, const AttnArgs& a, hipStream_t st) {
         if (a.d <= 32) return launch_rowmajor<1, 2>(p, a, st, f16);
         if (a.d <= 64) return launch_rowmajor<2, 4>(p, a, st, f16);
         if (a.d == 72 && !a.causal && (a.k_ts % 8) == 0 && (a.v_ts % 8) == 0 && (a.k_hs % 8) == 0 && (a.v_hs % 8) == 0 && (a.kv_bstride % 8) == 0 &&
-            ((uintptr_t)a.K % 16) == 0 && ((uintptr_t)a.V % 16) == 0 && a.n_ctx + a.S > 0) {
+            ((uintptr_t)a.K % 16) == 0 && ((uintptr_t)a.V % 16) == 0 && ((uintptr_t)a.q % 16) == 0 && (a.ldq % 8) == 0 && (a.q_bstride % 8) == 0 && a.n_ctx + a.S > 0) {
             // SigLIP-so400m, bidirectional: K / V tiles by LDS-DMA into two slots, four blocks per CU (MMDUET_VIT_ATTN_RING=0: the register-staged kernel, A/B)
             static const bool ring_off = getenv("MMDUET_VIT_ATTN_RING") && atoi(getenv("MMDUET_VIT_ATTN_RING")) == 0;
             if (!ring_off) {
