@@ -268,6 +268,29 @@ def test_tower_batch_of_35_frames_true_width(width2):
     assert e_ours <= 3 * e_ref + 2e-2 * max(1.0, scale), (e_ours, e_ref, scale)
 
 
+def test_vit_ring_attention_repeats_bit_identical_beside_a_copy_stream(width2):
+    """Race screen of attn_d72_ring_kernel (two-slot LDS-DMA ring, one hand-placed wait + raw barrier per tile, V fragments read from an asm block the compiler cannot see
+    into): the 35-frame tower (2 layers: 2 x 3 360 blocks per pass, incl. the 196-row last layer) and a 3-frame one are repeated beside a copy stream that perturbs the
+    memory system; a DMA landing late or a slot refilled early would show as a rare differing tile, not as a parity failure."""
+    m, _, _ = width2
+    dev = m.device
+    g = torch.Generator(device=dev).manual_seed(9)
+    noise = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
+    side = torch.cuda.Stream()
+    for nf, reps in ((35, 40), (3, 60)):
+        px = torch.randn(nf, 3, 384, 384, generator=g, device=dev).to(torch.bfloat16)
+        for full in (False, True):
+            m.set_full_tower(full)
+            first = m.visual_embed(px).clone()
+            for r in range(reps):
+                if r % 3 == 0:
+                    with torch.cuda.stream(side):
+                        noise[:128 << 20].copy_(noise[128 << 20:], non_blocking=True)
+                assert torch.equal(m.visual_embed(px), first), (nf, full, r)
+    m.set_full_tower(False)
+    torch.cuda.synchronize()
+
+
 def test_vit_ring_attention_equals_register_staged_kernel():
     """attn_d72_ring_kernel (K / V by LDS-DMA, row-major V image, 16-deep MFMA for dims 64..71) against attn_rowmajor_kernel<3, 5> (MMDUET_VIT_ATTN_RING=0) inside the
     tower at the true widths: fp16 and bf16 tower, 35 frames (6 query blocks x 16 heads x 35, last key tile 25 of 64) and 3 frames, the pooled output of the sparse last
