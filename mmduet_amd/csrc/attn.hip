@@ -1169,7 +1169,7 @@ __global__ __launch_bounds__(256, 2) void attn_rowmajor_kernel(AttnP p) {
 // slots instead of through staging registers.  attn_rowmajor_kernel holds one tile in LDS and the next in 24 staging registers, commits them between two block
 // barriers per tile and gathers V in 16-byte pieces from 32 different rows per load; it runs three blocks per CU at 146 registers.  Here tile i + 1 lands in the
 // other slot while tile i is consumed, ONE raw s_barrier per tile both publishes tile i and retires the slot of tile i - 1, nothing is staged in registers
-// (128 registers, 40 KB of LDS: four blocks per CU), and both DMAs read 144 contiguous bytes per key.  187 -> 145 us per layer at 35 frames (MI355X, in the model).
+// (<= 128 registers, 40 KB of LDS: four blocks per CU), and both DMAs read 144 contiguous bytes per key.  187 -> 140-149 us per layer at 35 frames (MI355X, in the model).
 // Same products, same summation order outside the matrix instructions as attn_rowmajor_kernel<3, 5, *, true>; the tower's output is the same to the bit on the seeded
 // frames of tools/probes/vit_ring_ab.py (MMDUET_VIT_ATTN_RING=0 keeps the register-staged kernel).
 //   K image: [64 keys][72] UNPADDED (row stride 144 B = 36 banks: 9 * lr mod 16 is a permutation, the 16-lane b128 fragment reads are conflict-free), padded to ten
@@ -1347,19 +1347,18 @@ __global__ __launch_bounds__(256, 4) void attn_d72_ring_kernel(AttnP p) {
                 l_run[rt] += psum;
                 pf[rt] = __builtin_bit_cast(bf16x8_t, pk);
             }
-            // the five d-tiles' V^T fragments of this half tile, read BEHIND the softmax (20 registers that are then not live across it).  ds_read_b64_tr_b16 through
-            // the builtin carries no memory operand and hipcc drains the DMA ring (vmcnt(0)) in front of it: issued from one asm block instead, and waited for there
+            // the five d-tiles' V^T fragments of this half tile, read BEHIND the softmax (20 registers that are then not live across it).  ds_read_b64_tr_b16 through the
+            // builtin carries no memory operand, so hipcc waits vmcnt(0) in front of the first one of a tile: the next tile's DMA gets the score MFMAs + softmax of one half
+            // tile to land instead of the whole tile.  With four blocks per CU that costs nothing measurable -- and the alternative, issuing the reads from an inline-asm
+            // block the compiler cannot see into, gave run-to-run DIFFERENT results as soon as the score MFMAs were reordered (profiles/r03_attention_experiments.md): kept visible
             s16x4_t vlo[DVT], vhi[DVT];
             {
-                const unsigned va = (unsigned)(uintptr_t)((const __attribute__((address_space(3))) bf16_t*)Vs) + (unsigned)((h * 32 + lq * 4 + (lr >> 2)) * 160 + (lr & 3) * 8);
-                asm volatile("ds_read_b64_tr_b16 %0, %10\n\tds_read_b64_tr_b16 %1, %10 offset:2560\n\t"
-                             "ds_read_b64_tr_b16 %2, %10 offset:32\n\tds_read_b64_tr_b16 %3, %10 offset:2592\n\t"
-                             "ds_read_b64_tr_b16 %4, %10 offset:64\n\tds_read_b64_tr_b16 %5, %10 offset:2624\n\t"
-                             "ds_read_b64_tr_b16 %6, %10 offset:96\n\tds_read_b64_tr_b16 %7, %10 offset:2656\n\t"
-                             "ds_read_b64_tr_b16 %8, %10 offset:128\n\tds_read_b64_tr_b16 %9, %10 offset:2688\n\t"
-                             "s_waitcnt lgkmcnt(0)"
-                             : "=&v"(vlo[0]), "=&v"(vhi[0]), "=&v"(vlo[1]), "=&v"(vhi[1]), "=&v"(vlo[2]), "=&v"(vhi[2]), "=&v"(vlo[3]), "=&v"(vhi[3]), "=&v"(vlo[4]), "=&v"(vhi[4])
-                             : "v"(va) : "memory");
+                const char __attribute__((address_space(3)))* vb = (const char __attribute__((address_space(3)))*)Vs + ((h * 32 + lq * 4 + (lr >> 2)) * 160 + (lr & 3) * 8);
+#pragma unroll
+                for (int t = 0; t < DVT; ++t) {
+                    vlo[t] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(vb + t * 32));
+                    vhi[t] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(vb + t * 32 + 2560));
+                }
             }
 #pragma unroll
             for (int t = 0; t < DVT; ++t) {
