@@ -165,7 +165,7 @@ ATTN_CASES = [  # S, nh, nkv, d, n_ctx, causal
     (1, 4, 2, 16, 0, True), (7, 4, 2, 16, 5, True), (49, 4, 1, 32, 300, True), (130, 4, 2, 16, 41, True),
     (49, 28, 4, 128, 0, True), (49, 28, 4, 128, 3000, True), (1, 28, 4, 128, 2500, True), (3, 28, 4, 128, 70, True), (98, 28, 4, 128, 777, True),
     (49, 28, 4, 128, 15000, True), (20, 8, 8, 128, 100, False), (729, 16, 16, 72, 0, False), (300, 4, 4, 72, 0, False), (130, 2, 1, 24, 0, False), (200, 8, 8, 72, 0, False),
-    (16, 2, 2, 24, 0, False), (33, 4, 4, 64, 100, False),
+    (16, 2, 2, 24, 0, False), (33, 4, 4, 64, 100, False), (577, 16, 16, 64, 0, False), (257, 12, 12, 64, 0, False), (196, 16, 16, 72, 533, False), (64, 3, 3, 64, 0, False),
 ]
 
 
@@ -196,6 +196,36 @@ def _attention(ops, S, nh, nkv, d, n_ctx, causal, variant):
     ref = ref_attention(rt(q, ops.dtype), rt(K, ops.dtype), rt(V, ops.dtype), nh, nkv, d, n_ctx, causal, ops.dtype)
     assert torch.isfinite(o.float()).all()
     assert_close(o, ref, ops.dtype, scale=1.5, what=f'attention v{variant}')
+
+
+def test_vit_ring_attention_bits_equal_register_staged_kernel_at_op_level():
+    """attn_d72_ring_kernel against attn_rowmajor_kernel<3, 5> (MMDUET_VIT_ATTN_RING=0) through the raw attention op, bf16: the tower's shapes (SigLIP 729 x 16 x 72, its
+    196-row last layer over 729 keys) and ragged ends (1 .. 64 keys in the last tile, fewer rows than a block, many heads).  Same products in the same order outside the
+    matrix instructions -> equal bits.  (head_dim 64 -- the secondary towers -- stays on attn_rowmajor_kernel<2, 4>: it already runs four blocks per CU, the ring form
+    measured 1755-1782 against 1786-1787 frames/s on the native-336 line.)"""
+    import subprocess, sys, os, json
+    from conftest import ROOT
+    code = r'''
+import os, sys, json, hashlib, torch
+sys.path.insert(0, os.environ["MMD_ROOT"]); sys.path.insert(0, os.path.join(os.environ["MMD_ROOT"], "tests"))
+from rawops import RawOps
+ops = RawOps(torch.bfloat16)
+res = {}
+for S, nh, d, n_ctx in ((729, 16, 72, 0), (196, 16, 72, 533), (577, 24, 72, 0), (257, 12, 72, 0), (65, 2, 72, 0), (64, 2, 72, 1), (130, 3, 72, 63), (70, 2, 72, 58)):
+    g = torch.Generator().manual_seed(S * 7 + d)
+    cap = (n_ctx + S + 37 + 63) // 64 * 64
+    q = torch.randn(S, nh * d, generator=g); K = torch.randn(nh, cap, d, generator=g); V = torch.randn(nh, cap, d, generator=g)
+    o = ops.attention(q, K.to(ops.dev, ops.dtype), V.to(ops.dev, ops.dtype), nh, nh, d, n_ctx, False, 4)
+    assert torch.isfinite(o.float()).all()
+    res[f"{S}_{nh}_{d}_{n_ctx}"] = hashlib.sha256(o.float().cpu().numpy().tobytes()).hexdigest()
+print("RES " + json.dumps(res))
+'''
+    def run(**kw):
+        r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, MMD_ROOT=ROOT, **kw), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith('RES ')][0][4:])
+    ring, staged = run(), run(MMDUET_VIT_ATTN_RING='0')
+    assert len(ring) == 8 and ring == staged
 
 
 def test_pooling_modes(ops):
