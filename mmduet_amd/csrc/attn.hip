@@ -1278,7 +1278,7 @@ __global__ __launch_bounds__(256, 4) void attn_d72_ring_kernel(AttnP p) {
 
     for (int i = 0; i < ntile; ++i) {
         const int k0 = i * KT;
-        // tile i's own five blocks have landed once at most the younger tiles' are outstanding; the barrier publishes everybody's and retires the slot of tile i - 1
+        // this wave's five blocks of tile i have landed (nothing younger is in flight yet); the barrier publishes everybody's and retires the slot of tile i - 1
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (i + NSLOT - 1 < ntile) stage((i + NSLOT - 1) % NSLOT, k0 + (NSLOT - 1) * KT);
