@@ -99,7 +99,7 @@ def thread_cpu_times():
 def recorded_parity(args):
     """The second half of BASELINE.json's metric ("resp-head logit delta"): NOT measured by this run -- the recorded result of tests/test_gpu_fullsize.py
     (this workload through the product driver against the fp32 oracle on the GPU, same weights, same frames), copied to profiles/ when the test last ran on an MI355X."""
-    for path in ('profiles/r03_parity_full_size.json',):
+    for path in ('profiles/r04_parity_full_size.json', 'profiles/r03_parity_full_size.json'):
         try:
             rec = json.load(open(os.path.join(ROOT, path))).get(args.config)
             if not rec or rec.get('weights') != ('fp8' if args.weights == 'fp8' else 'bf16'):
@@ -111,6 +111,57 @@ def recorded_parity(args):
         except Exception:
             pass
     return None
+
+
+def measured_parity(args, model, tok, cfg, frames, query, forced, device):
+    """The second half of BASELINE.json's metric, MEASURED BY THIS RUN (after the timed region; checker only -- nothing here is timed): a prefix of the timed stream
+    (the first `frames_per_forward` frames: the system prompt, the query at t = 0, one full chunk and, for the default workload, the response pinned to frame 21 with the
+    replay of the frames behind it) goes through the product driver once more with the raw head logits recorded, and through oracle/stream_check.StreamOracle on the GPU
+    -- plain torch fp32 on the same bf16-rounded weights (regenerated from the seed), (A) fed this build's frame embeddings, (B) end to end from the uint8 frames with its
+    own PIL preprocess + fp32 tower, and once in bf16 (the reference's eager rounding points: the yardstick).  Same code as tests/test_gpu_fullsize.py::_check_stream."""
+    from oracle import duet_oracle as O
+    from oracle.stream_check import StreamOracle, head_logits, run_oracle_stream, dequantised_fp8
+    from mmduet_amd.weights import synthetic_weights
+    n = min(args.frames, max(1, args.frames_per_forward))
+    sub = argparse.Namespace(**{**vars(args), 'frames': n})
+    f_in = [f for f in forced if f <= n]
+    d = make_driver(sub, model, tok, 1.0, f_in)
+    d.record_head_logits = True
+    fr = frames[:n]
+    run_stream(d, fr, query)
+    torch.cuda.synchronize(device)
+    lg_h, ids_h, kv_h = head_logits(d), [list(x) for x in d.response_token_ids], len(d.past_key_values)
+    feats = d._vit_out.view(n, cfg.frame_num_tokens, -1).clone()
+    w16 = {name: t for name, t in synthetic_weights(cfg, seed=0, device=device, dtype=torch.bfloat16, scale='init02')}
+    w32 = dequantised_fp8(w16) if args.weights == 'fp8' else {k: v.float() for k, v in w16.items()}
+    if args.weights == 'fp8':
+        w16 = {k: v.to(torch.bfloat16) for k, v in w32.items()}
+    ocfg = O.OracleConfig()
+    out = {}
+
+    def oracle_run(w, dtype, **src):
+        a = driver_args(sub, 1.0)
+        a.bf16, a.overlap_vision = dtype == torch.bfloat16, False
+        o = StreamOracle(ocfg, w, device)
+        od = bench_driver_class()(a, model=o, tokenizer=tok)
+        od.forced_frames, od.eos_token_id, od.record_head_logits = frozenset(f_in), -1, True
+        run_oracle_stream(od, o, ids_h, query, **src)
+        return head_logits(od), o.tf, len(od.past_key_values)
+
+    t0 = time.perf_counter()
+    lg_32, tf32, kv_32 = oracle_run(w32, torch.float32, feats=feats)
+    lg_16, _, _ = oracle_run(w16, torch.bfloat16, feats=feats)
+    lg_e, _, _ = oracle_run(w32, torch.float32, frames=fr)
+    flat = [v for r in tf32 for v in r['agree']]
+    out = {'frames': n, 'response_frames': f_in, 'max_abs_vs_fp32_oracle': round((lg_h - lg_32).abs().max().item(), 4), 'mean_abs_vs_fp32_oracle': round((lg_h - lg_32).abs().mean().item(), 4),
+           'bf16_oracle_max_abs_vs_fp32': round((lg_16 - lg_32).abs().max().item(), 4), 'bf16_oracle_mean_abs_vs_fp32': round((lg_16 - lg_32).abs().mean().item(), 4),
+           'end_to_end_max_abs_vs_fp32_oracle': round((lg_h - lg_e).abs().max().item(), 4), 'end_to_end_mean_abs_vs_fp32_oracle': round((lg_h - lg_e).abs().mean().item(), 4),
+           'logit_scale': round(lg_32.abs().max().item(), 2), 'response_tokens_equal_fp32_argmax': f'{sum(flat)}/{len(flat)}' if flat else None,
+           'kv_len_equal': kv_h == kv_32, 'checker_seconds': round(time.perf_counter() - t0, 1),
+           'how': 'oracle/stream_check.StreamOracle on the GPU (torch fp32 kernels, same bf16-rounded weights) over a prefix of the timed stream, teacher-forced with the product ids; after the timed region'}
+    del w16, w32
+    torch.cuda.empty_cache()
+    return out
 
 
 def parse(argv=None):
@@ -129,6 +180,7 @@ def parse(argv=None):
     p.add_argument('--tiny', action='store_true', help='tiny model (plumbing check, not a valid measurement)')
     p.add_argument('--no-overlap', action='store_true', help='run the vision tower and the LLM steps on one stream')
     p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--no-parity-check', action='store_true', help='skip the post-timing oracle check of a stream prefix (resp_head_logit_delta.measured_in_run)')
     p.add_argument('--prof-stride', type=int, default=7, help='bracket every n-th launch of the dominant kernel class with HIP events')
     p.add_argument('--no-prof', action='store_true', help='do not bracket the dominant kernel with HIP events in the timed region')
     p.add_argument('--multi-stream', type=int, default=4, help='also measure S streams per GPU in shared forwards (reported under "multi_stream"; never the headline value; 0 = skip)')
@@ -604,6 +656,13 @@ def main():
         multi = dict(streams_per_gpu=args.multi_stream, frames_per_forward=args.multi_frames_per_forward, value=round(fps, 2), unit='frames/s (this GPU)',
                      ms_per_step=round(ms_step, 1), forwards_per_step=rounds, replayed_frames=replay, time_in_forwards_frac=round(frac, 3),
                      note='mmduet_amd.multistream: one LLM forward carries frame chunks and decode rows of all streams; per-stream results as single-stream')
+    parity = recorded_parity(args)
+    if rank == 0 and not (args.tiny or args.no_parity_check or args.phase == 'b' or args.layers):
+        try:
+            measured = measured_parity(args, model, tok, cfg, frames, query, forced, device)
+        except Exception as e:                               # the checker never blocks the line
+            measured = {'error': f'{type(e).__name__}: {e}'}
+        parity = {'measured_in_run': measured, 'recorded_full_stream': parity}
     if rank == 0:
         total_frames = world * S * args.steps * args.frames
         value = total_frames / dt
@@ -622,7 +681,7 @@ def main():
                        'kv_tokens_end': kv_end, 'weights': ('random init N(0,0.02), true shapes' if not args.tiny else 'tiny') + ('' if args.weights == 'bf16' else ', LLM matrices quantised to fp8 e4m3 per output channel'),
                        'parallelism': f'dp{world} ({S} stream(s) per GPU, one RCCL all-gather of the [{world},{S},{T}+1,2] score block per step, issued by libmmduet_hip (mmd_gather_block))',
                        'native_gather_check': native, 'tower_overlap': not args.no_overlap, 'tower_dtype': getattr(model, 'tower_dtype', None), 'phase': 'A+B' if args.phase == 'ab' else 'B only (frame embeddings pre-extracted to a feature file; LLM side alone)', 'layers_override': args.layers},
-            'verified': verified, 'resp_head_logit_delta': recorded_parity(args), 'roofline': roof, 'roofline_secondary': roof2, 'cpu_baseline': cpu, 'multi_stream': multi,
+            'verified': verified, 'resp_head_logit_delta': parity, 'roofline': roof, 'roofline_secondary': roof2, 'cpu_baseline': cpu, 'multi_stream': multi,
         }
         import ctypes
         ctypes.CDLL(None).fflush(None)          # RCCL's banner sits in C stdio's buffer when stdout is a pipe: push it out BEFORE the JSON line

@@ -126,6 +126,7 @@ int mmd_vision_pool_head(mmd_ctx* ctx, const void* feats, int B, void* out);
  * models/live_llava/video_head_live_llava_qwen.py:100-119 interpolates without antialiasing) -- same values, same arithmetic, rows nobody reads are not computed.  Callers
  * that want vision_encode's full [B, tokens, C] (offline feature extraction, data/utils.py:99-117) or the debug taps switch that off first. */
 int mmd_vit_set_full_tower(mmd_ctx* ctx, int on);
+int mmd_vit_get_full_tower(const mmd_ctx* ctx);            /* current setting (1 / 0): callers that flip it temporarily restore what they found */
 int mmd_vit_debug_tap(mmd_ctx* ctx, int stage, void* out, int64_t out_elems);
 /* replaces image_processor.preprocess (test/inference.py:203; LLaVA SigLipImageProcessor): uint8 [T,3,R,R] ->
  * PIL-bicubic resize to img x img (bit-exact with Pillow's 8-bit resampler), x/255, (x-.5)/.5 -> ctx dtype. */

@@ -14,7 +14,10 @@ data/utils.py:99-117) -- Phase A then comes from disk and only the LLM side runs
 `--evaluator_format true` writes debug_data in the deprecated shape `test/evaluate.py --func grounding|qvh_highlight` reads.
 Everything else (flags, JSONL output format, `--start_idx/--end_idx` sharding, skip-on-unreadable) follows the reference.
 `--streams_per_gpu S` runs S videos at a time through shared LLM forwards (mmduet_amd/multistream.py), same records.
-With torchrun, entries are sharded over the ranks (`i % world == rank`) and every rank writes `<output_fname>.rank<r>`.
+With torchrun, entries are sharded over the ranks (`i % world == rank`) and every rank writes `<output_fname>.rank<r>`; the per-frame head
+scores of all ranks are then met by ONE all-gather (mmduet_amd.distributed.gather_scores: RCCL over xGMI on the GPUs) and rank 0 writes them, keyed by
+question_id in dataset order, to `<output_fname>.scores.json` -- the reference's seam for this is N hand-launched `--start_idx/--end_idx` processes
+(test/inference.py:335-338) whose files the user concatenates.
 """
 import json, os, sys
 import numpy as np
@@ -25,7 +28,7 @@ def main(argv=None):
     from .arguments_live import parse_args
     from .inference import LiveInferForBenchmark
     from .results import result_record
-    from .distributed import init_distributed, shard_indices
+    from .distributed import init_distributed, shard_indices, shard_shape, gather_scores
     args = parse_args('test', argv)
     rank, world, local = init_distributed()
     if torch.cuda.is_available():
@@ -70,6 +73,11 @@ def main(argv=None):
             frames = frames[:args.max_num_frames]
         return frames, fps, duration, [{'role': 'system', 'content': args.system_prompt}] + conv
 
+    local_scores = {}          # dataset index -> [[informative, relevance] per frame] of the videos this rank ran
+
+    def keep_scores(i, debug_data):
+        local_scores[i] = [[d['informative_score'], d['relevance_score']] for d in debug_data]
+
     with open(out_name, 'w') as f_out:
         if args.streams_per_gpu > 1:
             # several videos share every LLM forward.  Clips are loaded when a slot takes them and every record is written (and flushed)
@@ -77,19 +85,21 @@ def main(argv=None):
             from .multistream import MultiStreamInfer
             ms = MultiStreamInfer(args, model=infer.model, tokenizer=infer.tokenizer, n_slots=args.streams_per_gpu)
 
-            def entry(ex):
+            def entry(i):
+                ex = data[i]
+
                 def make():
                     v = load(ex)
-                    return None if v is None else dict(frames=v[0], fps=v[1], conversation=v[3], ex=ex, duration=v[2])
+                    return None if v is None else dict(frames=v[0], fps=v[1], conversation=v[3], ex=ex, duration=v[2], index=i)
                 return make
 
             def on_result(n, video, res):
                 rec = result_record(video['ex']['question_id'], res['responses'], video['duration'], res['debug_data'], evaluator_format=args.evaluator_format)
                 f_out.write(json.dumps(rec) + '\n')
                 f_out.flush()
-            ms.run([entry(data[i]) for i in mine], on_result=on_result)
-            return
-        for n, i in enumerate(mine):
+                keep_scores(video['index'], res['debug_data'])
+            ms.run([entry(i) for i in mine], on_result=on_result)
+        for n, i in enumerate([] if args.streams_per_gpu > 1 else mine):
             ex = data[i]
             v = load(ex)
             if v is None:
@@ -105,8 +115,24 @@ def main(argv=None):
             responses = infer.inference()
             rec = result_record(ex['question_id'], responses, duration, infer.debug_data_list, evaluator_format=args.evaluator_format)
             f_out.write(json.dumps(rec) + '\n')
+            keep_scores(i, infer.debug_data_list)
             if n % 5 == 0:
                 f_out.flush()
+    if world > 1:
+        # the ONE collective of the path.  n_max is known without communication (deterministic assignment); the longest stream is not (frame counts come from
+        # the clips), so gather_scores precedes the block by its 16-byte shape exchange.  A skipped (unreadable) clip travels as a zero-length stream.
+        n_max, _ = shard_shape(len(data), world)
+        allsc, lens = gather_scores([torch.tensor(local_scores.get(i, []), dtype=torch.float32).view(-1, 2) for i in mine], n_max=n_max)
+        if rank == 0:
+            allsc, lens = allsc.cpu(), lens.cpu()
+            merged = {}
+            for i, ex in enumerate(data):
+                r, slot = i % world, i // world
+                merged[str(ex['question_id'])] = allsc[r, slot, :int(lens[r, slot])].tolist()
+            with open(f'{args.output_fname}.scores.json', 'w') as f:
+                json.dump(merged, f)
+        import torch.distributed as dist
+        dist.barrier()
 
 
 if __name__ == '__main__':

@@ -49,6 +49,7 @@ _SIGS = {
     'mmd_weight_bytes': (_I64, [_VP]),
     'mmd_vit_encode': (_I, [_VP, _VP, _I, _VP]),
     'mmd_vit_set_full_tower': (_I, [_VP, _I]),
+    'mmd_vit_get_full_tower': (_I, [_VP]),
     'mmd_vit_debug_tap': (_I, [_VP, _I, _VP, _I64]),
     'mmd_connector_pool': (_I, [_VP, _VP, _I, _VP]),
     'mmd_vit_encode_frames': (_I, [_VP, _VP, _I, _I, _VP]),

@@ -52,6 +52,8 @@ struct mmd_comm {
     int rank = 0, world = 1, device = 0;
     hipStream_t stream = nullptr;
     float* send = nullptr; float* recv = nullptr; size_t cap = 0;     // device staging, floats per rank
+    hipEvent_t order = nullptr;        // marks the end of the gathers issued on the previous stream (collectives of ONE communicator must not overlap)
+    bool issued = false;
     std::string err;
 };
 
@@ -89,6 +91,7 @@ extern "C" void mmd_comm_destroy(mmd_comm* c) {
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     if (c->comm) g_rccl.CommDestroy(c->comm);
+    if (c->order) hipEventDestroy(c->order);
     if (c->send) hipFree(c->send);
     if (c->recv) hipFree(c->recv);
     delete c;
@@ -98,7 +101,19 @@ extern "C" int mmd_comm_world(const mmd_comm* c) { return c ? c->world : -1; }
 // can librccl be bound at all?  (every rank asks BEFORE the collective mmd_comm_create, so that a rank without the library fails with the others instead of leaving them hanging)
 extern "C" int mmd_comm_probe(void) { if (!rccl_load()) { g_comm_error = g_rccl.err; return MMD_ENOENT; } return MMD_OK; }
 // the HIP stream the next gathers are issued on (the caller's current stream: the gather is then ordered behind the kernels that produced its input and ahead of its consumers)
-extern "C" int mmd_comm_set_stream(mmd_comm* c, void* hip_stream) { if (!c) return MMD_EINVAL; c->stream = (hipStream_t)hip_stream; return MMD_OK; }
+// Consecutive collectives of one communicator issued on DIFFERENT streams are not ordered with each other (RCCL leaves that undefined): when the stream changes,
+// the new one first waits for an event recorded behind the last gather on the old one.
+extern "C" int mmd_comm_set_stream(mmd_comm* c, void* hip_stream) {
+    if (!c) return MMD_EINVAL;
+    hipStream_t ns = (hipStream_t)hip_stream;
+    if (ns != c->stream && c->issued) {
+        hipSetDevice(c->device);
+        if (!c->order && hipEventCreateWithFlags(&c->order, hipEventDisableTiming) != hipSuccess) { c->err = "hipEventCreate failed"; return MMD_EHIP; }
+        if (hipEventRecord(c->order, c->stream) != hipSuccess || hipStreamWaitEvent(ns, c->order, 0) != hipSuccess) { c->err = "stream hand-over of the communicator failed"; return MMD_EHIP; }
+    }
+    c->stream = ns;
+    return MMD_OK;
+}
 // raw form: every rank contributes `n_floats` fp32 (device) -> all [world, n_floats] (device); ONE ncclAllGather, no staging (the padded [n_max, t_max + 1, 2]
 // block of several streams per rank, assembled by the caller)
 extern "C" int mmd_gather_block(mmd_comm* c, const float* block, int64_t n_floats, float* all) {
@@ -106,6 +121,7 @@ extern "C" int mmd_gather_block(mmd_comm* c, const float* block, int64_t n_float
     hipSetDevice(c->device);
     ncclResult_t r = g_rccl.AllGather(block, all, (size_t)n_floats, ncclFloat32, c->comm, c->stream);
     if (r != ncclSuccess) { c->err = std::string("ncclAllGather: ") + g_rccl.GetErrorString(r); return MMD_EHIP; }
+    c->issued = true;
     return MMD_OK;
 }
 
@@ -129,5 +145,6 @@ extern "C" int mmd_gather_scores(mmd_comm* c, const float* local, int T, int t_m
     if (e != hipSuccess) { c->err = std::string("staging: ") + hipGetErrorString(e); return MMD_EHIP; }
     ncclResult_t r = g_rccl.AllGather(c->send, all, per, ncclFloat32, c->comm, c->stream);
     if (r != ncclSuccess) { c->err = std::string("ncclAllGather: ") + g_rccl.GetErrorString(r); return MMD_EHIP; }
+    c->issued = true;
     return MMD_OK;
 }

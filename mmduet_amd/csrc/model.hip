@@ -91,6 +91,7 @@ struct mmd_ctx {
     int tower_ring_flags = -1, tower_ring_blocks = 0;   // MMDUET_TOWER_RING / MMDUET_TOWER_RING_BLOCKS: ring GEMM form of the tower (co-residency experiments)
     int hid_compact = 0;               // > 0: l_hid holds that many compact rows (in the order of the `need` list) instead of all S rows of the step
     bool full_tower = false;           // mmd_vit_set_full_tower(1): the last encoder layer runs on ALL tokens (feature extraction, debug taps); default: on the tokens the bilinear pool reads
+    bool last_sparse = false;          // the most recent vit_tower ran its last layer on the pooled rows only (v_h then holds no full output: the debug taps refuse)
     bool tower_compact = false;        // the tower's output of the current batch is the compact [B * (2 out)^2, C] block in v_col (set by vit_tower, consumed by connector_pool)
     bool full_projector = false;       // set while mmd_vit_debug_tap(stage 1) recomputes the projector over ALL tokens (the shipped path runs it on the tokens the bilinear pool reads)
     bool no_slab_norm = false;         // MMDUET_NO_SLAB_NORM=1: a chunk's split-K down_proj keeps splitk_reduce + a separate RMSNorm launch (A/B)
@@ -590,8 +591,10 @@ static int vit_tower(mmd_ctx* c, const void* px, int B, bool col_ready = false, 
     // callers that want the tower's full output (feature extraction, debug taps) switch it off with mmd_vit_set_full_tower.
     static const bool no_sparse = getenv("MMDUET_FULL_PROJECTOR") != nullptr;
     const int pout = (c->vit_grid + g.pool_stride - 1) / g.pool_stride, U = 4 * pout * pout;
+    // (the half forms of the kernels exist for M > 64 GEMMs and S >= 64 attention only: a compact block below that keeps the full last layer -- ADVICE r03)
     const bool sparse_last = for_pool && !no_sparse && !c->full_tower && !c->full_projector && g.pool_mode == MMD_POOL_BILINEAR && U < T && TS == T && !g.vit_post_layernorm &&
-                             g.vit_act != 1 && g.vit_layers > 0 && !g.vision_only;
+                             g.vit_act != 1 && g.vit_layers > 0 && !g.vision_only && (!g.tower_f16 || (U >= 64 && B * U > 64));
+    c->last_sparse = sparse_last;
     c->tower_compact = false;
     for (int i = 0; i < g.vit_layers; ++i) {
         VitLayer& L = c->VL[i];
@@ -767,10 +770,11 @@ extern "C" int mmd_vit_set_full_tower(mmd_ctx* c, int on) {
     c->full_tower = on != 0;
     return MMD_OK;
 }
+extern "C" int mmd_vit_get_full_tower(const mmd_ctx* c) { return c ? (c->full_tower ? 1 : 0) : MMD_EINVAL; }
 
 extern "C" int mmd_vit_debug_tap(mmd_ctx* c, int stage, void* out, int64_t out_elems) {
     NEED_FINAL(c);
-    if (!c->full_tower && !c->cfg.vision_only && c->cfg.pool_mode == MMD_POOL_BILINEAR && getenv("MMDUET_FULL_PROJECTOR") == nullptr)
+    if (c->last_sparse)          // only when the last encode really ran sparse (post_layernorm / class-token towers / U >= T never do): v_h holds no full output then
         FAIL(c, MMD_EINVAL, "mmd_vit_debug_tap needs mmd_vit_set_full_tower(ctx, 1) before the encode call (the default path computes the last layer for the pooled tokens only)");
     int64_t M = (int64_t)c->last_vit_B * c->vit_seq;
     int64_t n = M * (stage == 0 ? c->cfg.vit_hidden : c->cfg.hidden_size);
@@ -939,6 +943,7 @@ static int vmm_map_upto(mmd_ctx* c, mmd_stream* s, int64_t upto) {
         // a chunk is all-or-nothing: `mapped` advances only when every row has its pages, so on a failure (out of HBM near the limit this arena is built
         // for) the rows already mapped for THIS chunk are unmapped again -- a later kv_reserve then retries on clean addresses instead of failing for good
         auto undo = [&]() {
+            hipStreamSynchronize(c->stream);          // rows mapped earlier in this chunk have a zero-fill queued on the stream: let it finish before their pages go away
             while (s->handles.size() > done0) {
                 hipMemUnmap(s->maps.back().first, s->maps.back().second); hipMemRelease(s->handles.back());
                 s->maps.pop_back(); s->handles.pop_back();

@@ -131,8 +131,18 @@ class NativeScoreGather:
         h = C.c_void_p()
         st = stream if stream is not None else torch.cuda.current_stream(self.device).cuda_stream
         rc = self._lib.mmd_comm_create(C.c_void_p(ident.data_ptr()), self.rank, self.world, self.device.index or 0, C.c_void_p(st), C.byref(h))
-        if rc:
-            raise MmduetError(f'mmd_comm_create failed ({rc}): {self._lib.mmd_comm_last_error(None).decode()}')
+        why = '' if rc == 0 else f'mmd_comm_create failed ({rc}): {self._lib.mmd_comm_last_error(None).decode()}'
+        if self.world > 1:
+            # ncclCommInitRank can fail on SOME ranks only: agree once more, so that either every rank holds a communicator or every rank raises (a caller that
+            # falls back to torch.distributed then does so on all ranks together -- mixed transports would hang on mismatched collectives)
+            flag = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=self.device if dist.get_backend() == 'nccl' else 'cpu')
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                if rc == 0:
+                    self._lib.mmd_comm_destroy(h)
+                raise MmduetError(f'NativeScoreGather: communicator construction failed on at least one rank (rank {self.rank}: {why or "ok here"})')
+        elif rc:
+            raise MmduetError(why)
         self._h = h
 
     def _on_current_stream(self):

@@ -417,6 +417,7 @@ class VideoHeadLiveLlavaQwenForCausalLM:
         scratch = torch.empty(min(B, self.max_vit_batch) * self.tokens_per_frame, self.config.hidden_size, dtype=self.dtype, device=self.device)
         with self._lock:
             self._bind_stream()
+            was = int(lib().mmd_vit_get_full_tower(self._ctx))          # a caller's own set_full_tower(True) survives this call
             check(lib().mmd_vit_set_full_tower(self._ctx, 1), self._ctx, 'mmd_vit_set_full_tower')          # vision_encode's output is the tower over ALL tokens
             try:
                 for b0 in range(0, B, self.max_vit_batch):
@@ -424,7 +425,7 @@ class VideoHeadLiveLlavaQwenForCausalLM:
                     check(lib().mmd_vit_encode(self._ctx, _ptr(frames[b0:b1]), b1 - b0, _ptr(scratch)), self._ctx, 'mmd_vit_encode')
                     check(lib().mmd_vit_debug_tap(self._ctx, 0, _ptr(out[b0:b1]), (b1 - b0) * T * C), self._ctx, 'mmd_vit_debug_tap')
             finally:
-                check(lib().mmd_vit_set_full_tower(self._ctx, 0), self._ctx, 'mmd_vit_set_full_tower')
+                check(lib().mmd_vit_set_full_tower(self._ctx, 1 if was > 0 else 0), self._ctx, 'mmd_vit_set_full_tower')
         return out
 
     def set_full_tower(self, on: bool):

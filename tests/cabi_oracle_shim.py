@@ -204,3 +204,109 @@ class FakeLib:
         o = torch.cat([F.linear(r, c.w['informative_head.weight']), F.linear(r, c.w['relevance_head.weight'])], -1).float()
         _view(out, M * 4, torch.float32).view(M, 4).copy_(o)
         return 0
+
+    # ---- entry points of the PRODUCT driver's path (mmduet_amd.inference / multistream / __main__): tests/cli_shim_runner.py ----------
+    def mmd_set_tower_share(self, h, n):
+        return 0
+
+    def mmd_stream_reset(self, sh):
+        self._get(sh).len = 0
+        return 0
+
+    def mmd_vit_encode_frames(self, h, frames, B, R, out):
+        self._count('mmd_vit_encode_frames')
+        c = self._get(h)
+        fr = _view(frames, B * 3 * R * R, torch.uint8).view(B, 3, R, R)
+        e = O.visual_embed(c.w, c.cfg, siglip_preprocess(fr.numpy(), c.cfg.vit_image_size).to(c.dtype))
+        _view(out, e.numel(), c.dtype).view_as(e).copy_(e)
+        return 0
+
+    def _step(self, c, s, xin):
+        hid, cache = O.llm_forward(c.w, c.cfg, xin, s.prefix())
+        s.handle, s.len = cache, s.len + xin.shape[0]
+        return hid
+
+    def _heads(self, c, rows):
+        return torch.cat([F.linear(rows, c.w['informative_head.weight']), F.linear(rows, c.w['relevance_head.weight'])], -1).float()
+
+    def mmd_frame_step(self, h, sh, x, S, rows, n_rows, res):
+        self._count('mmd_frame_step')
+        c, s = self._get(h), self._get(sh)
+        H = c.cfg.hidden_size
+        hid = self._step(c, s, _view(x, S * H, c.dtype).view(S, H))
+        o = self._heads(c, hid[[int(rows[i]) for i in range(n_rows)]]).reshape(-1).tolist()
+        for i, v in enumerate(o):
+            res[i] = v
+        return 0
+
+    def mmd_frame_step_multi(self, h, streams, seg_rows, n_segs, x, head_rows, n_head, res, hid_rows, n_hid, hidden_out, logits_out):
+        self._count('mmd_frame_step_multi')
+        c = self._get(h)
+        H = c.cfg.hidden_size
+        total = sum(int(seg_rows[j]) for j in range(n_segs))
+        xin = _view(x, total * H, c.dtype).view(total, H)
+        hid, at = [], 0
+        for j in range(n_segs):
+            S = int(seg_rows[j])
+            hid.append(self._step(c, self._get(streams[j]), xin[at:at + S])); at += S
+        hid = torch.cat(hid)
+        if n_head:
+            o = self._heads(c, hid[[int(head_rows[i]) for i in range(n_head)]]).reshape(-1).tolist()
+            for i, v in enumerate(o):
+                res[i] = v
+        if n_hid:
+            rows = hid[[int(hid_rows[i]) for i in range(n_hid)]]
+            _view(hidden_out, n_hid * H, c.dtype).view(n_hid, H).copy_(rows)
+            if _addr(logits_out):
+                _view(logits_out, n_hid * c.cfg.vocab_size, torch.float32).view(n_hid, -1).copy_(F.linear(rows, c.w['lm_head.weight']).float())
+        return 0
+
+    def mmd_greedy_generate(self, h, sh, x, S, eos, pen, prev, n_prev_ref, cap, out_ids, max_new, n_out_ref):
+        """models/modeling_live.py:51-77: the last token is written, never fed; HF repetition penalty over `prev` (grown in place)."""
+        self._count('mmd_greedy_generate')
+        c, s = self._get(h), self._get(sh)
+        H = c.cfg.hidden_size
+        n_prev = n_prev_ref._obj
+        seen = [int(prev[i]) for i in range(n_prev.value)]
+        xin = _view(x, S * H, c.dtype).view(S, H)
+        n = 0
+        for n in range(max_new):
+            hid = self._step(c, s, xin)
+            scores = F.linear(hid[-1:], c.w['lm_head.weight']).float()[0]
+            if pen > 0 and seen:
+                idx = torch.as_tensor(seen, dtype=torch.long)
+                picked = scores[idx]
+                scores[idx] = torch.where(picked < 0, picked * pen, picked / pen)
+            tok = int(scores.argmax(-1))
+            if pen > 0 and tok != eos:
+                seen.append(tok)
+            out_ids[n] = tok
+            if tok == eos:
+                break
+            xin = c.w['model.embed_tokens.weight'][tok][None].to(c.dtype)
+        n_out_ref._obj.value = n + 1 if max_new > 0 else 0
+        if pen > 0:
+            assert len(seen) <= cap
+            for i, t in enumerate(seen):
+                prev[i] = t
+            n_prev.value = len(seen)
+        return 0
+
+    def mmd_kv_stash(self, sh, start, end):
+        self._count('mmd_kv_stash')
+        s = self._get(sh)
+        if not (0 <= start <= end <= s.len):
+            return -34
+        s.stash = (int(start), int(end), [k[:, start:end].clone() for k in s.handle.k], [v[:, start:end].clone() for v in s.handle.v])
+        return 0
+
+    def mmd_kv_unstash(self, sh):
+        self._count('mmd_kv_unstash')
+        s = self._get(sh)
+        st = getattr(s, 'stash', None)
+        if st is None or s.len != st[0]:
+            return -22
+        start, end, ks, vs = st
+        s.handle = O.KVHandle([torch.cat([k[:, :start], t], 1) for k, t in zip(s.handle.k, ks)], [torch.cat([v[:, :start], t], 1) for v, t in zip(s.handle.v, vs)])
+        s.len, s.stash = end, None
+        return 0

@@ -13,8 +13,11 @@ Compared: ALL per-frame head logits (4 per frame), the response token ids, the f
 tie-fragile, so the oracle is TEACHER-FORCED with the product's token ids (one forward over prompt + response) and every product token must be
 the oracle's arg-max or lie within 4 x the measured lm-logit error of it.
 
-Bound (as test_full_depth_stream_prefix_measured_deltas states it): max |ours - fp32 oracle| <= 2 x max |bf16 oracle - fp32 oracle| + 3e-2.
-Measured maxima are written to gpurun_out/parity_full_size.json (copied to profiles/r03_parity_full_size.json).
+Bounds: max |ours - fp32 oracle| <= 1.5 x max |bf16 oracle - fp32 oracle| + 2e-2 AND
+mean |ours - fp32 oracle| <= 1.15 x mean |bf16 oracle - fp32 oracle| + 2e-3 (the mean over all T x 4 head logits is the real evidence; the maximum of
+O(1000) bf16-rounded values is a noisy statistic).  Round 4 adds BASELINE configs[3]'s per-GPU workload (8 concurrent QVH streams in shared forwards,
+plus the 4-stream response-mode leg bench.py reports under `multi_stream`) and one fp32-MODE full-depth run that is held to the north-star 1e-3.
+Measured maxima are written to gpurun_out/parity_full_size.json (copied to profiles/r04_parity_full_size.json).
 Reference: test/inference.py:276-313 (the loop), models/modeling_live.py:51-77 (generation)."""
 import json, os, random, time
 import pytest
@@ -22,6 +25,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 from oracle import duet_oracle as O
+from oracle.stream_check import StreamOracle, head_logits, run_oracle_stream, dequantised_fp8
 from conftest import ROOT
 import bench as B
 
@@ -40,39 +44,7 @@ def _record(key, vals):
         pass
 
 
-class StreamOracle(O.OracleModel):
-    """The oracle behind the driver's duck-type, on the GPU: lm_head only on the rows that are read (the reference's all-position lm_head is 1.4 TF
-    of fp32 per chunk that nothing reads), responses teacher-forced with the product's token ids."""
-
-    def __init__(self, cfg, weights, device):
-        super().__init__(cfg, weights)
-        self.device = device
-        self.forced, self.resp, self.tf = [], 0, []
-
-    def __call__(self, inputs_embeds=None, past_key_values=None, logit_rows=1, **kw):
-        h, cache = O.llm_forward(self.w, self.cfg, inputs_embeds[0].to(self.dtype), past_key_values)
-        return O.OracleOutput(logits=O.linear(h[-logit_rows:], self.w['lm_head.weight']).float()[None],
-                              informative_logits=O.linear(h, self.w['informative_head.weight']).float()[None],
-                              relevance_logits=O.linear(h, self.w['relevance_head.weight']).float()[None], past_key_values=cache)
-
-    def greedy_generate(self, inputs_embeds, past_key_values, eos_token_id, max_new_tokens, repetition_penalty=None, generated_token_ids=None):
-        """models/modeling_live.py:51-77 with the token choice given: prompt + ids[:-1] in ONE causal forward (the last token is written, never fed,
-        :68-75); row i of the logits is what the loop's step i would have seen."""
-        assert repetition_penalty is None
-        ids = list(self.forced[self.resp]); self.resp += 1
-        x = inputs_embeds.reshape(1, -1, self.cfg.hidden_size).to(self.dtype)
-        if len(ids) > 1:
-            x = torch.cat([x, self._embed(torch.tensor([ids[:-1]], device=self.device))], 1)
-        out = self(inputs_embeds=x, past_key_values=past_key_values, logit_rows=len(ids))
-        lg = out.logits[0]
-        t = torch.tensor(ids, device=self.device)
-        top2 = lg.topk(2, dim=-1).values
-        self.tf.append(dict(deficit=(top2[:, 0] - lg.gather(1, t[:, None])[:, 0]).tolist(), agree=(lg.argmax(-1) == t).tolist(),
-                            top2_margin=(top2[:, 0] - top2[:, 1]).tolist()))
-        return ids, out.past_key_values
-
-
-def _build_product(weights, frames):
+def _build_product(weights, frames, max_step_tokens=39 * 49 + 192):
     """bench.build() with the weight list kept for the oracles."""
     from mmduet_amd.configuration_live import VideoHeadLiveLlavaQwenConfig
     from mmduet_amd.modeling_live import VideoHeadLiveLlavaQwenForCausalLM
@@ -82,7 +54,7 @@ def _build_product(weights, frames):
     cfg = VideoHeadLiveLlavaQwenConfig(frame_num_tokens=49, frame_resolution=384, v_placeholder='<image>')
     if weights == 'fp8':
         cfg.weight_dtype = 'fp8_e4m3'
-    model = VideoHeadLiveLlavaQwenForCausalLM(cfg, torch_dtype=torch.bfloat16, device=dev, max_vit_batch=35, max_step_tokens=39 * 49 + 192,
+    model = VideoHeadLiveLlavaQwenForCausalLM(cfg, torch_dtype=torch.bfloat16, device=dev, max_vit_batch=35, max_step_tokens=max_step_tokens,
                                               kv_initial_tokens=frames * 49 + 4096)
     tok = build_live_tokenizer_and_update_config('synthetic:bench', cfg)
     w = {}
@@ -93,26 +65,8 @@ def _build_product(weights, frames):
     return model, tok, w
 
 
-LIN = ('q_proj', 'k_proj', 'v_proj', 'o_proj', 'gate_proj', 'up_proj', 'down_proj')
-
-
-def _dequantised(w):
-    """The values the fp8 build computes with: per output channel scale = amax / 448, q = e4m3fn(W / scale) (bit-exact with the HIP quantiser,
-    tests/test_gpu_fp8.py::test_quantiser_is_bit_exact_with_torch_e4m3fn), W' = q x scale -- decoder matrices only."""
-    out = {}
-    for k, v in w.items():
-        if k.startswith('model.layers.') and k.endswith('.weight') and any(f'.{l}.' in k for l in LIN):
-            vf = v.float()
-            amax = vf.abs().amax(dim=1)
-            scale = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
-            out[k] = (vf / scale[:, None]).to(torch.float8_e4m3fn).float() * scale[:, None]
-        else:
-            out[k] = v.float()
-    return out
-
-
-def _logits(d):
-    return torch.tensor([x['head_logits'] for x in d.debug_data_list], dtype=torch.float64)
+_logits = head_logits
+_dequantised = dequantised_fp8
 
 
 def _oracle_driver(args, oracle, tok, forced, dtype):
@@ -127,19 +81,75 @@ def _oracle_driver(args, oracle, tok, forced, dtype):
 
 
 def _run_oracle(args, oracle, tok, forced, dtype, ids, frames=None, feats=None):
-    oracle.forced, oracle.resp, oracle.tf = ids, 0, []
     d = _oracle_driver(args, oracle, tok, forced, dtype)
-    d.reset()
-    if feats is not None:
-        d.input_feature_stream(feats)
-    else:
-        d.input_video_stream(frames.cpu())
-    d.input_query_stream([{'role': 'user', 'content': QUERY, 'time': 0.0}])
-    t0 = time.perf_counter()
-    d.inference()
-    if torch.cuda.is_available():
-        torch.cuda.synchronize()
-    return d, time.perf_counter() - t0
+    return d, run_oracle_stream(d, oracle, ids, QUERY, frames=frames, feats=feats)
+
+
+MAX_K, MAX_ABS = 1.5, 2e-2            # max  |ours - fp32| <= MAX_K  x max  |bf16 oracle - fp32| + MAX_ABS
+MEAN_K, MEAN_ABS = 1.15, 2e-3         # mean |ours - fp32| <= MEAN_K x mean |bf16 oracle - fp32| + MEAN_ABS
+
+
+def _check_stream(key, args, model, tok, w32, w16, forced, frames, feats, lg_h, ids_h, kv_h, cache_h, meta, e2e, e2e_bf16=False):
+    """One product stream (head logits lg_h [T,4], response ids ids_h, final KV length kv_h / handle cache_h) against the oracles; records under `key`, asserts the bar."""
+    dev = model.device
+    T = lg_h.shape[0]
+    res = dict(meta)
+    # ---- (A) LLM side isolated: oracles on this build's frame embeddings ----
+    cfg = O.OracleConfig()
+    o32 = StreamOracle(cfg, w32, dev)
+    d32, t32 = _run_oracle(args, o32, tok, forced, torch.float32, ids_h, feats=feats)
+    lg_32, tf32, kv_32 = _logits(d32), o32.tf, len(d32.past_key_values)
+    # lm-logit error of the product at the end of the stream (one more step from the final context, generation prompt)
+    E = None
+    if ids_h:
+        gen = d32._added_stream_generation_ids
+        lo = model(inputs_embeds=model.get_input_embeddings()(gen).view(1, -1, 3584), past_key_values=cache_h).logits[0, -1].float()
+        l32 = o32(inputs_embeds=o32.get_input_embeddings()(gen).view(1, -1, 3584), past_key_values=d32.past_key_values).logits[0, -1].float()
+        E = (lo - l32).abs().max().item()
+    del o32, d32
+    o16 = StreamOracle(cfg, w16, dev)
+    d16, t16 = _run_oracle(args, o16, tok, forced, torch.bfloat16, ids_h, feats=feats)
+    lg_16, tf16 = _logits(d16), o16.tf
+    del o16, d16
+    d_ours, d_ref = (lg_h - lg_32).abs().max().item(), (lg_16 - lg_32).abs().max().item()
+    m_ours, m_ref = (lg_h - lg_32).abs().mean().item(), (lg_16 - lg_32).abs().mean().item()
+    per_frame = (lg_h - lg_32).abs().amax(1)
+    res['llm_side'] = dict(ours_vs_fp32=d_ours, bf16_oracle_vs_fp32=d_ref, ours_vs_bf16_oracle=(lg_h - lg_16).abs().max().item(),
+                           ours_vs_fp32_mean=m_ours, bf16_oracle_vs_fp32_mean=m_ref,
+                           worst_frame=int(per_frame.argmax()), last_50_frames_max=per_frame[-50:].max().item(), logit_scale=lg_32.abs().max().item(),
+                           fp32_oracle_seconds=round(t32, 1), bf16_oracle_seconds=round(t16, 1))
+    flat = lambda tf, k: [v for r in tf for v in r[k]]
+    if ids_h:
+        res['tokens'] = dict(n=len(flat(tf32, 'agree')), equal_fp32_argmax=sum(flat(tf32, 'agree')), equal_bf16_oracle_argmax=sum(flat(tf16, 'agree')),
+                             max_deficit_vs_fp32=max(flat(tf32, 'deficit')), lm_logit_err_at_stream_end=E, lm_logit_scale=l32.abs().max().item(),
+                             min_fp32_top2_margin=min(flat(tf32, 'top2_margin')))
+    res['kv_len'] = dict(ours=kv_h, oracle=kv_32)
+    # ---- (B) end to end: the fp32 oracle's own preprocess + tower on the uint8 frames ----
+    if e2e:
+        o32 = StreamOracle(cfg, w32, dev)
+        de, te = _run_oracle(args, o32, tok, forced, torch.float32, ids_h, frames=frames)
+        lg_e = _logits(de)
+        res['end_to_end'] = dict(ours_vs_fp32=(lg_h - lg_e).abs().max().item(), ours_vs_fp32_mean=(lg_h - lg_e).abs().mean().item(), fp32_oracle_seconds=round(te, 1))
+        del o32, de
+        if e2e_bf16:
+            o16 = StreamOracle(cfg, w16, dev)
+            de16, _ = _run_oracle(args, o16, tok, forced, torch.bfloat16, ids_h, frames=frames)
+            res['end_to_end']['bf16_oracle_vs_fp32'] = (_logits(de16) - lg_e).abs().max().item()
+            res['end_to_end']['bf16_oracle_vs_fp32_mean'] = (_logits(de16) - lg_e).abs().mean().item()
+            del o16, de16
+    res['bounds'] = dict(max=f'{MAX_K} x bf16 oracle + {MAX_ABS}', mean=f'{MEAN_K} x bf16 oracle + {MEAN_ABS}')
+    _record(key, res)
+    torch.cuda.empty_cache()
+    # ---- the bar ----
+    assert kv_h == kv_32, res['kv_len']
+    assert d_ours <= MAX_K * d_ref + MAX_ABS, res['llm_side']
+    assert m_ours <= MEAN_K * m_ref + MEAN_ABS, res['llm_side']
+    if ids_h:
+        assert res['tokens']['max_deficit_vs_fp32'] <= 4 * E + 1e-3, res['tokens']
+    if e2e and 'bf16_oracle_vs_fp32' in res['end_to_end']:
+        assert res['end_to_end']['ours_vs_fp32'] <= MAX_K * res['end_to_end']['bf16_oracle_vs_fp32'] + MAX_ABS, res['end_to_end']
+        assert res['end_to_end']['ours_vs_fp32_mean'] <= MEAN_K * res['end_to_end']['bf16_oracle_vs_fp32_mean'] + MEAN_ABS, res['end_to_end']
+    return res
 
 
 def _case(cfgname, model, tok, w32, w16, e2e, e2e_bf16=False):
@@ -161,62 +171,70 @@ def _case(cfgname, model, tok, w32, w16, e2e, e2e_bf16=False):
     assert lg_h.shape == (T, 4) and torch.isfinite(lg_h).all()
     assert n_resp == len(forced) == len(ids_h) and all(len(x) == args.max_new_tokens for x in ids_h)
     feats = d._vit_out.view(T, 49, -1).clone()
-    res = dict(config=cfgname, frames=T, frames_per_forward=args.frames_per_forward, responses=len(ids_h), response_frames=forced, kv_tokens_end=kv_h,
-               llm_forwards=d.forward_calls, replayed_frames=d.replayed_frames, product_seconds=round(t_prod, 2), weights=args.weights)
-    # ---- (A) LLM side isolated: oracles on this build's frame embeddings ----
-    cfg = O.OracleConfig()
-    o32 = StreamOracle(cfg, w32, dev)
-    d32, t32 = _run_oracle(args, o32, tok, forced, torch.float32, ids_h, feats=feats)
-    lg_32, tf32, kv_32 = _logits(d32), o32.tf, len(d32.past_key_values)
-    # lm-logit error of the product at the end of the stream (one more step from the final context, generation prompt)
-    gen = d._added_stream_generation_ids
-    lo = model(inputs_embeds=model.get_input_embeddings()(gen).view(1, -1, 3584), past_key_values=d.past_key_values).logits[0, -1].float()
-    l32 = o32(inputs_embeds=o32.get_input_embeddings()(gen).view(1, -1, 3584), past_key_values=d32.past_key_values).logits[0, -1].float()
-    E = (lo - l32).abs().max().item()
-    del o32, d32
-    o16 = StreamOracle(cfg, w16, dev)
-    d16, t16 = _run_oracle(args, o16, tok, forced, torch.bfloat16, ids_h, feats=feats)
-    lg_16, tf16 = _logits(d16), o16.tf
-    del o16, d16
-    d_ours, d_ref = (lg_h - lg_32).abs().max().item(), (lg_16 - lg_32).abs().max().item()
-    per_frame = (lg_h - lg_32).abs().amax(1)
-    res['llm_side'] = dict(ours_vs_fp32=d_ours, bf16_oracle_vs_fp32=d_ref, ours_vs_bf16_oracle=(lg_h - lg_16).abs().max().item(),
-                           ours_vs_fp32_mean=(lg_h - lg_32).abs().mean().item(), bf16_oracle_vs_fp32_mean=(lg_16 - lg_32).abs().mean().item(),
-                           worst_frame=int(per_frame.argmax()), last_50_frames_max=per_frame[-50:].max().item(), logit_scale=lg_32.abs().max().item(),
-                           fp32_oracle_seconds=round(t32, 1), bf16_oracle_seconds=round(t16, 1))
-    flat = lambda tf, k: [v for r in tf for v in r[k]]
-    if ids_h:
-        res['tokens'] = dict(n=len(flat(tf32, 'agree')), equal_fp32_argmax=sum(flat(tf32, 'agree')), equal_bf16_oracle_argmax=sum(flat(tf16, 'agree')),
-                             max_deficit_vs_fp32=max(flat(tf32, 'deficit')), lm_logit_err_at_stream_end=E, lm_logit_scale=l32.abs().max().item(),
-                             min_fp32_top2_margin=min(flat(tf32, 'top2_margin')))
-    res['kv_len'] = dict(ours=kv_h, oracle=kv_32)
-    # ---- (B) end to end: the fp32 oracle's own preprocess + tower on the uint8 frames ----
-    if e2e:
-        o32 = StreamOracle(cfg, w32, dev)
-        de, te = _run_oracle(args, o32, tok, forced, torch.float32, ids_h, frames=frames)
-        lg_e = _logits(de)
-        res['end_to_end'] = dict(ours_vs_fp32=(lg_h - lg_e).abs().max().item(), ours_vs_fp32_mean=(lg_h - lg_e).abs().mean().item(), fp32_oracle_seconds=round(te, 1))
-        del o32, de
-        if e2e_bf16:
-            o16 = StreamOracle(cfg, w16, dev)
-            de16, _ = _run_oracle(args, o16, tok, forced, torch.bfloat16, ids_h, frames=frames)
-            res['end_to_end']['bf16_oracle_vs_fp32'] = (_logits(de16) - lg_e).abs().max().item()
-            del o16, de16
-    _record(cfgname, res)
-    torch.cuda.empty_cache()
-    # ---- the bar ----
-    assert kv_h == kv_32, res['kv_len']
-    assert d_ours <= 2 * d_ref + 3e-2, res['llm_side']
-    if ids_h:
-        assert res['tokens']['max_deficit_vs_fp32'] <= 4 * E + 1e-3, res['tokens']
-    if e2e and 'bf16_oracle_vs_fp32' in res['end_to_end']:
-        assert res['end_to_end']['ours_vs_fp32'] <= 2 * res['end_to_end']['bf16_oracle_vs_fp32'] + 3e-2, res['end_to_end']
-    return res
+    meta = dict(config=cfgname, frames=T, frames_per_forward=args.frames_per_forward, responses=len(ids_h), response_frames=forced, kv_tokens_end=kv_h,
+                llm_forwards=d.forward_calls, replayed_frames=d.replayed_frames, product_seconds=round(t_prod, 2), weights=args.weights)
+    return _check_stream(cfgname, args, model, tok, w32, w16, forced, frames, feats, lg_h, ids_h, kv_h, d.past_key_values, meta, e2e, e2e_bf16)
+
+
+def _multi_case(key, cfgname, n_streams, k, model, tok, w32, w16, n_e2e):
+    """`n_streams` concurrent streams through mmduet_amd.multistream.MultiStreamInfer exactly as bench.py's MultiRunner configures it (same driver class, same flags,
+    per-stream response frames from random.Random(s)) -- except that every stream gets its OWN frames (seed 1 + s; stream 0 = bench.py's rank-0 frames) so that rows
+    of different streams mixed up inside a shared forward cannot cancel out.  Each stream is then checked like a single stream (_check_stream)."""
+    from mmduet_amd.multistream import MultiStreamInfer
+    dev = model.device
+    args = B.parse(['--config', cfgname, '--multi-stream', '0', '--frames-per-forward', str(k)])
+    T = args.frames
+    sink = {}
+
+    class Rec(B.bench_driver_class()):
+        def inference(self):
+            r = super().inference()
+            sink[self.sink_key] = (self._vit_out.view(-1, 49, self._vit_out.shape[-1]).clone(), self)
+            return r
+
+    videos, forced_all, frames_all = [], [], []
+    for s in range(n_streams):
+        fr = torch.randint(0, 256, (T, 3, 336, 336), dtype=torch.uint8, generator=torch.Generator().manual_seed(1 + s)).to(dev)
+        forced = sorted(random.Random(s).sample(range(1, T + 1), args.responses)) if args.responses > 0 else []
+        frames_all.append(fr); forced_all.append(forced)
+        videos.append(dict(frames=fr, conversation=[{'role': 'user', 'content': QUERY, 'time': 0.0}],
+                           driver_attrs=dict(forced_frames=frozenset(forced), eos_token_id=-1, record_head_logits=True, sink_key=s)))
+    ms = MultiStreamInfer(B.driver_args(args, 1.0, k), model=model, tokenizer=tok, n_slots=n_streams, driver_cls=Rec)
+    t0 = time.perf_counter()
+    results = ms.run(videos)
+    torch.cuda.synchronize()
+    t_prod = time.perf_counter() - t0
+    single_forwards = sum(r['forward_calls'] + sum(len(g) for g in r['response_token_ids']) for r in results)
+    assert ms.rounds < single_forwards, (ms.rounds, single_forwards)          # the forwards really were shared
+    out = []
+    for s, r in enumerate(results):
+        lg_h = torch.tensor([x['head_logits'] for x in r['debug_data']], dtype=torch.float64)
+        ids_h = [list(x) for x in r['response_token_ids']]
+        assert lg_h.shape == (T, 4) and torch.isfinite(lg_h).all()
+        assert len(ids_h) == len(forced_all[s]) and all(len(x) == args.max_new_tokens for x in ids_h)
+        feats, drv = sink[s]
+        meta = dict(config=cfgname, stream=s, streams_per_gpu=n_streams, frames=T, frames_per_forward=k, responses=len(ids_h), response_frames=forced_all[s],
+                    kv_tokens_end=r['final_kv_len'], llm_forwards=r['forward_calls'], replayed_frames=r['replayed_frames'], shared_forwards_all_streams=ms.rounds,
+                    product_seconds_all_streams=round(t_prod, 2), weights=args.weights)
+        out.append(_check_stream(f'{key}_stream{s}', args, model, tok, w32, w16, forced_all[s], frames_all[s], feats, lg_h, ids_h, r['final_kv_len'],
+                                 drv.past_key_values, meta, e2e=s < n_e2e))
+    # distinct frames -> distinct scores: two streams never share a result
+    for a in range(n_streams):
+        for b in range(a + 1, n_streams):
+            assert results[a]['debug_data'][5]['head_logits'] != results[b]['debug_data'][5]['head_logits']
+    _record(key, dict(streams=n_streams, frames_per_forward=k, frames=T, shared_forwards=ms.rounds, forwards_if_run_one_by_one=single_forwards,
+                      worst_max_ours_vs_fp32=max(o['llm_side']['ours_vs_fp32'] for o in out), worst_max_bf16_oracle_vs_fp32=max(o['llm_side']['bf16_oracle_vs_fp32'] for o in out),
+                      worst_mean_ours_vs_fp32=max(o['llm_side']['ours_vs_fp32_mean'] for o in out), worst_mean_bf16_oracle_vs_fp32=max(o['llm_side']['bf16_oracle_vs_fp32_mean'] for o in out),
+                      product_seconds=round(t_prod, 2)))
+    return out
+
+
+MULTI_STEP_TOKENS = 8 * (30 * 49 + 192)        # bench.build() for `--config qvh --streams-per-gpu 8` (covers 4 x (13 x 49 + 192) of the multi_stream leg)
 
 
 @pytest.fixture(scope='module')
 def bf16_build():
-    model, tok, w = _build_product('bf16', 600)
+    model, tok, w = _build_product('bf16', 600, max_step_tokens=MULTI_STEP_TOKENS)
     w32 = {k: v.float() for k, v in w.items()}
     yield model, tok, w32, w
     del model, w, w32
@@ -237,6 +255,23 @@ def test_config3_ground600_full_size(bf16_build):
     assert r['responses'] == 0 and r['kv_tokens_end'] >= 600 * 49
 
 
+def test_config4_qvh_multistream_full_size(bf16_build):
+    """BASELINE configs[3] per GPU: 8 concurrent 150-frame QVHighlights-style grounding streams in SHARED forwards (MultiStreamInfer over
+    mmd_frame_step_multi, k = 30: `bench.py --config qvh --streams-per-gpu 8`), 7B, full depth, bf16 -- every stream against the fp32 / bf16 oracles on the GPU
+    (all 8 LLM-side, the first 2 also end to end from the uint8 frames)."""
+    model, tok, w32, w16 = bf16_build
+    out = _multi_case('qvh_8streams', 'qvh', 8, 30, model, tok, w32, w16, n_e2e=2)
+    assert len(out) == 8 and all(o['responses'] == 0 and o['kv_tokens_end'] >= 150 * 49 for o in out)
+
+
+def test_multistream_response_leg_full_size(bf16_build):
+    """The `multi_stream` leg of the driver's BENCH line: 4 concurrent 300-frame streams, k = 13, every stream answering 4 x 32 tokens at its own seeded frames
+    (decode rows of a talking stream ride in the other streams' chunk forwards) -- per stream: all head logits, the response ids (teacher-forced oracle), KV length."""
+    model, tok, w32, w16 = bf16_build
+    out = _multi_case('stream300_4streams_k13', 'stream300', 4, 13, model, tok, w32, w16, n_e2e=1)
+    assert len(out) == 4 and all(o['responses'] == 4 for o in out)
+
+
 def test_config5_youcook2_fp8_full_size():
     """BASELINE configs[4] per GPU: 600 frames, running-sum rule, assistant turns removed (KV stash instead of replay), 12 responses, fp8 e4m3 weights;
     the oracles compute with the DEQUANTISED weights (the values the fp8 kernels use)."""
@@ -247,4 +282,59 @@ def test_config5_youcook2_fp8_full_size():
     r = _case('youcook2', model, tok, w32, w16, e2e=False)
     assert r['responses'] == 12 and r['replayed_frames'] == 0
     del model, w32, w16
+    torch.cuda.empty_cache()
+
+
+def test_fp32_mode_full_depth_30_frames_meets_1e3():
+    """The north-star tolerance at DEPTH: the fp32 build of the FULL model (26 tower + 28 decoder layers, vocab 152 064, true widths; 30 GB of
+    fp32 weights) runs a configs[0]-like stream -- 30 uint8 336-px frames, query at t = 0, one 8-token response pinned to frame 17 -- through the product driver, once
+    with the reference's own schedule (one frame per forward) and once as k = 26 chunks, against the fp32 oracle END TO END (its own PIL preprocess + tower).
+    Bar: every head logit within 1e-3 (BASELINE.json north_star: "logits within 1e-3 of reference"); response ids equal the oracle's free-running greedy ids."""
+    from mmduet_amd.configuration_live import VideoHeadLiveLlavaQwenConfig
+    from mmduet_amd.modeling_live import VideoHeadLiveLlavaQwenForCausalLM
+    from mmduet_amd.tokenization_live import build_live_tokenizer_and_update_config
+    from mmduet_amd.weights import synthetic_weights
+    dev = torch.device('cuda', 0)
+    T = 30
+    cfg = VideoHeadLiveLlavaQwenConfig(frame_num_tokens=49, frame_resolution=384, v_placeholder='<image>')
+    model = VideoHeadLiveLlavaQwenForCausalLM(cfg, torch_dtype=torch.float32, device=dev, max_vit_batch=8, max_step_tokens=26 * 49 + 192, kv_initial_tokens=T * 49 + 4096)
+    tok = build_live_tokenizer_and_update_config('synthetic:bench', cfg)
+    w = {}
+    for name, t in synthetic_weights(cfg, seed=0, device=dev, dtype=torch.float32, scale='init02'):
+        model.load_tensor(name, t)
+        w[name] = t
+    model.finalize()
+    frames = torch.randint(0, 256, (T, 3, 336, 336), dtype=torch.uint8, generator=torch.Generator().manual_seed(1)).to(dev)
+    forced = [17]
+    res = {}
+    oracle_ids = None
+    for k in (1, 26):
+        args = B.parse(['--config', 'stream300', '--multi-stream', '0', '--frames', str(T), '--responses', '1', '--frames-per-forward', str(k), '--max-new-tokens', '8'])
+        a = B.driver_args(args, 1.0)
+        a.bf16 = False
+        d = B.bench_driver_class()(a, model=model, tokenizer=tok)
+        d.forced_frames, d.eos_token_id, d.record_head_logits = frozenset(forced), -1, True
+        t0 = time.perf_counter()
+        B.run_stream(d, frames, QUERY)
+        torch.cuda.synchronize()
+        t_prod = time.perf_counter() - t0
+        lg_h, ids_h, kv_h = _logits(d), [list(x) for x in d.response_token_ids], len(d.past_key_values)
+        # the oracle: free-running greedy first (ids must come out equal), then the same run is the logit reference
+        o32 = O.OracleModel(O.OracleConfig(), w)
+        do = _oracle_driver(args, o32, tok, forced, torch.float32)
+        do.reset(); do.input_video_stream(frames.cpu()); do.input_query_stream([{'role': 'user', 'content': QUERY, 'time': 0.0}])
+        t0 = time.perf_counter(); do.inference(); torch.cuda.synchronize(); t_or = time.perf_counter() - t0
+        lg_o, ids_o, kv_o = _logits(do), [list(x) for x in do.response_token_ids], len(do.past_key_values)
+        err = (lg_h - lg_o).abs()
+        res[f'k{k}'] = dict(head_logit_max_abs=err.max().item(), head_logit_mean_abs=err.mean().item(), logit_scale=lg_o.abs().max().item(), ids_ours=ids_h, ids_oracle=ids_o,
+                            kv_len=dict(ours=kv_h, oracle=kv_o), product_seconds=round(t_prod, 2), oracle_seconds=round(t_or, 2), replayed_frames=d.replayed_frames)
+        del o32, do
+        torch.cuda.empty_cache()
+    res.update(frames=T, response_frames=forced, depth='26 tower + 28 decoder layers', bound=1e-3)
+    _record('fp32_mode_full_depth', res)
+    for k in ('k1', 'k26'):
+        assert res[k]['head_logit_max_abs'] <= 1e-3, res[k]
+        assert res[k]['kv_len']['ours'] == res[k]['kv_len']['oracle'], res[k]
+        assert res[k]['ids_ours'] == res[k]['ids_oracle'], res[k]
+    del model, w
     torch.cuda.empty_cache()

@@ -343,3 +343,58 @@ def test_kv_stash_is_dropped_when_its_context_goes_away():
     h = m(inputs_embeds=x).past_key_values
     assert lib().mmd_kv_stash(h.arena.h, 12, 24) == 0
     assert lib().mmd_kv_unstash(h.arena.h) != 0                   # len is 24, the stash continues 12
+
+
+@pytest.mark.parametrize('grid,B', [(12, 1), (12, 3), (16, 1), (16, 5)])
+def test_fp16_tower_small_grids_fall_back_to_the_full_last_layer(grid, B):
+    """the half-precision forms of the kernels exist for GEMMs with M > 64 and attention with S >= 64 only, so the sparse last tower layer
+    (U = (2 out)^2 query rows per frame) must not be taken when B * U <= 64 or U < 64 -- grid 12 / stride 4 (U = 36) and grid 16 / stride 4 at B = 1 (B * U = 64)
+    failed with an opaque EHIP.  The encode must work, equal the full-tower path bit for bit, and track the oracle to the bf16 bound."""
+    from oracle import duet_oracle as O
+    from mmduet_amd.configuration_live import VideoHeadLiveLlavaQwenConfig
+    from mmduet_amd.modeling_live import VideoHeadLiveLlavaQwenForCausalLM
+    from mmduet_amd.weights import synthetic_weights
+    img = grid * 14
+    out = -(-grid // 4)
+    pcfg = VideoHeadLiveLlavaQwenConfig(vocab_size=256, hidden_size=128, intermediate_size=256, num_hidden_layers=1, num_attention_heads=4, num_key_value_heads=2,
+                                        vit_hidden_size=64, vit_intermediate_size=128, vit_num_hidden_layers=3, vit_layers_removed=1, vit_num_attention_heads=4,
+                                        vit_image_size=img, vit_patch_size=14, video_pooling_stride=4, frame_num_tokens=out * out, frame_resolution=img, v_placeholder='<image>')
+    m = VideoHeadLiveLlavaQwenForCausalLM(pcfg, torch_dtype=torch.bfloat16, max_vit_batch=8, max_step_tokens=256, kv_initial_tokens=512)
+    assert m.tower_dtype == 'fp16'
+    w = {}
+    for name, t in synthetic_weights(pcfg, seed=7, device=m.device, dtype=torch.bfloat16, scale='unit'):
+        m.load_tensor(name, t); w[name] = t.float()
+    m.finalize()
+    ocfg = O.OracleConfig(vocab_size=256, hidden_size=128, intermediate_size=256, num_hidden_layers=1, num_attention_heads=4, num_key_value_heads=2, vit_hidden_size=64,
+                          vit_intermediate_size=128, vit_layers=2, vit_heads=4, vit_image_size=img, vit_patch_size=14, video_pooling_stride=4, frame_num_tokens=out * out, frame_resolution=img)
+    px = torch.randn(B, 3, img, img, generator=torch.Generator().manual_seed(grid + B)).to(torch.bfloat16).cuda()
+    ve = m.visual_embed(px)
+    assert ve.shape == (B * out * out, 128) and torch.isfinite(ve.float()).all()
+    m.set_full_tower(True)
+    full = m.visual_embed(px)
+    tap = m.vit_debug_tap(0, B)                         # legal now: the last encode ran the full last layer
+    m.set_full_tower(False)
+    assert tap.shape == (B * grid * grid, 64)
+    ref = O.visual_embed(w, ocfg, px.float())
+    scale = ref.abs().max().item()
+    assert (ve.float() - ref).abs().max().item() <= 4e-2 * max(1.0, scale)
+    assert (full.float() - ref).abs().max().item() <= 4e-2 * max(1.0, scale)
+    if 4 * out * out < 64 or B * 4 * out * out <= 64:    # the guarded cases: both calls ran the SAME (full) schedule
+        assert torch.equal(ve, full)
+
+
+def test_tower_features_keeps_a_callers_full_tower_setting(f32):
+    """tower_features() flips mmd_vit_set_full_tower for its own encode and must restore what it FOUND, not 0; and the debug tap refuses only when the
+    last encode really ran the sparse last layer."""
+    m = f32[1]
+    from mmduet_amd._lib import lib
+    cfg = m.config
+    px = torch.randn(2, 3, cfg.vit_image_size, cfg.vit_image_size, generator=torch.Generator().manual_seed(3)).cuda()
+    m.set_full_tower(True)
+    m.tower_features(px)
+    assert lib().mmd_vit_get_full_tower(m._ctx) == 1
+    m.visual_embed(px)
+    m.vit_debug_tap(0, 2)                                # still legal
+    m.set_full_tower(False)
+    m.tower_features(px)
+    assert lib().mmd_vit_get_full_tower(m._ctx) == 0
