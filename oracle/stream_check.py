@@ -40,6 +40,24 @@ class StreamOracle(O.OracleModel):
         return ids, out.past_key_values
 
 
+class FreeRunningOracle(StreamOracle):
+    """The same oracle choosing its own tokens (models/modeling_live.py:51-77, no repetition penalty): for runs whose arithmetic is exact enough that the ids must come out
+    EQUAL (the fp32-mode build)."""
+
+    def greedy_generate(self, inputs_embeds, past_key_values, eos_token_id, max_new_tokens, repetition_penalty=None, generated_token_ids=None):
+        assert repetition_penalty is None
+        x, cache, ids = inputs_embeds.reshape(1, -1, self.cfg.hidden_size).to(self.dtype), past_key_values, []
+        for _ in range(max_new_tokens):
+            out = self(inputs_embeds=x, past_key_values=cache)
+            cache = out.past_key_values
+            tok = int(out.logits[0, -1].argmax(-1))
+            ids.append(tok)
+            if tok == eos_token_id:
+                break
+            x = self._embed(torch.tensor([[tok]], device=self.device)).to(self.dtype)          # (the last token is written, never fed)
+        return ids, cache
+
+
 def head_logits(driver):
     """[T, 4] float64 of a driver run with record_head_logits = True."""
     return torch.tensor([x['head_logits'] for x in driver.debug_data_list], dtype=torch.float64)
@@ -65,16 +83,25 @@ def run_oracle_stream(driver, oracle, forced_ids, query, frames=None, feats=None
 LINEAR = ('q_proj', 'k_proj', 'v_proj', 'o_proj', 'gate_proj', 'up_proj', 'down_proj')
 
 
+def quantise_e4m3_rows(v):
+    """Per output channel: scale = amax / 448, q = e4m3fn(W / scale) with IEEE fp32 divisions (the scheme tests/test_gpu_fp8.py::test_quantiser_is_bit_exact_with_torch_e4m3fn
+    pins the HIP quantiser to, on the CPU).  torch's fp32 division ON THE GPU is not correctly rounded (measured on MI355X, tools/probes/fp8_cast_probe.py: W / scale differs in
+    the last ulp, which flips 0.09 % of the codes -- every exact tie -- by a whole quantisation step), so both divisions are taken in double and rounded to single: for a
+    quotient that IS the correctly rounded fp32 result (53 >= 2 x 24 + 2 bits), on any device."""
+    vf = v.float()
+    amax = vf.abs().amax(dim=1)
+    scale = torch.where(amax > 0, (amax.double() / 448.0).float(), torch.ones_like(amax))
+    q = (vf.double() / scale.double()[:, None]).float().to(torch.float8_e4m3fn)
+    return q, scale
+
+
 def dequantised_fp8(w):
-    """The values the fp8 build computes with: per output channel scale = amax / 448, q = e4m3fn(W / scale) (bit-exact with the HIP quantiser,
-    tests/test_gpu_fp8.py::test_quantiser_is_bit_exact_with_torch_e4m3fn), W' = q x scale -- decoder matrices only.  fp32 tensors."""
+    """The values the fp8 build computes with: W' = q x scale of the decoder matrices (quantise_e4m3_rows).  fp32 tensors."""
     out = {}
     for k, v in w.items():
         if k.startswith('model.layers.') and k.endswith('.weight') and any(f'.{l}.' in k for l in LINEAR):
-            vf = v.float()
-            amax = vf.abs().amax(dim=1)
-            scale = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
-            out[k] = (vf / scale[:, None]).to(torch.float8_e4m3fn).float() * scale[:, None]
+            q, scale = quantise_e4m3_rows(v)
+            out[k] = q.float() * scale[:, None]
         else:
             out[k] = v.float()
     return out

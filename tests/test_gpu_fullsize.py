@@ -25,7 +25,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 from oracle import duet_oracle as O
-from oracle.stream_check import StreamOracle, head_logits, run_oracle_stream, dequantised_fp8
+from oracle.stream_check import StreamOracle, FreeRunningOracle, head_logits, run_oracle_stream, dequantised_fp8
 from conftest import ROOT
 import bench as B
 
@@ -320,7 +320,7 @@ def test_fp32_mode_full_depth_30_frames_meets_1e3():
         t_prod = time.perf_counter() - t0
         lg_h, ids_h, kv_h = _logits(d), [list(x) for x in d.response_token_ids], len(d.past_key_values)
         # the oracle: free-running greedy first (ids must come out equal), then the same run is the logit reference
-        o32 = O.OracleModel(O.OracleConfig(), w)
+        o32 = FreeRunningOracle(O.OracleConfig(), w, dev)
         do = _oracle_driver(args, o32, tok, forced, torch.float32)
         do.reset(); do.input_video_stream(frames.cpu()); do.input_query_stream([{'role': 'user', 'content': QUERY, 'time': 0.0}])
         t0 = time.perf_counter(); do.inference(); torch.cuda.synchronize(); t_or = time.perf_counter() - t0
