@@ -101,7 +101,8 @@ struct StepState { long long n_ctx; long long cap; void* K; void* V; int n_prev;
 // ---- epilogues of the GEMM family ------------------------------------------------------------------------------
 enum { EPI_NONE = 0, EPI_GELU_TANH = 1, EPI_GELU_ERF = 2, EPI_RESID = 3, EPI_SWIGLU = 4 };
 enum { GEMM_AUTO = 0, GEMM_GENERIC = 1, GEMM_SKINNY = 2, GEMM_LARGE = 3, GEMM_BIG = 4, GEMM_SLAB = 5, GEMM_RING256 = 6, GEMM_RING256_SPLIT = 7,
-       GEMM_RINGX = 16 /* + 1: 4-wave 256x128 blocks, + 2: 32x32x16 MFMA, + 4: split K */ };
+       GEMM_RINGX = 16 /* + 1: 4-wave 256x128 blocks, + 2: 32x32x16 MFMA, + 4: split K */,
+       GEMM_RINGW = 200 /* gemm_ringw_kernel (W operand straight to registers): + 0 / 1 = (3,3) / (4,2) ring slots, W buffers; + 4: split K */ };
 
 // Decode chain of the weight-streaming GEMV (M <= 16, bf16): the residual add + RMSNorm between two GEMVs costs a launch and a cold, dependent
 // load chain of its own (5.5 us + a kernel boundary, twice per layer at decode).  Instead

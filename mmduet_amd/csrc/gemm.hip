@@ -14,6 +14,7 @@
 #include <type_traits>
 
 #include "gemm_ring.h"
+#include "gemm_ringw.h"
 
 template <typename T> struct Frag;
 template <> struct Frag<bf16_t> { using type = bf16x8_t; static constexpr int KSTEP = 32; };
@@ -929,6 +930,15 @@ static void launch_big(const GemmP& p, const GemmArgs& a, hipStream_t st) {
 }
 
 
+// the ring kernels' masked output lanes need somewhere harmless to store (the store COUNT per wave must not depend on the tile): one 8 KB buffer per device
+static void* ring_dump_slot() {
+    static void* dump_slot[64] = {};
+    int dev = 0; hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64) return nullptr;
+    if (!dump_slot[dev] && hipMalloc(&dump_slot[dev], 8192) != hipSuccess) return nullptr;
+    return dump_slot[dev];
+}
+
 template <int WN, bool M32, int NS, bool EARLY, bool F16 = false>
 static hipError_t launch_ringx_t(const GemmP& p, const GemmArgs& a, hipStream_t st, int splits, bool stagger = true) {
     if (F16) splits = 1;
@@ -952,13 +962,8 @@ static hipError_t launch_ringx_t(const GemmP& p, const GemmArgs& a, hipStream_t 
     }
     const dim3 block(WN * 128);
     GemmP q = p;
-    {                      // the kernel's masked output lanes need somewhere harmless to store (see PST in the kernel): one 8 KB buffer per device
-        static void* dump_slot[64] = {};
-        int dev = 0; hipGetDevice(&dev);
-        if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-        if (!dump_slot[dev] && hipMalloc(&dump_slot[dev], 8192) != hipSuccess) return hipErrorOutOfMemory;
-        q.dump = dump_slot[dev];
-    }
+    q.dump = ring_dump_slot();
+    if (!q.dump) return hipErrorOutOfMemory;
     // start-up stagger of the second-slot blocks in ~4 us units: about half a tile (K/32 steps of ~0.75 us) -- see the kernel
     q.kper = (!stagger || splits > 1) ? 0 : ((a.K / 32) * 10) / 100 + 1;
     if constexpr (F16) {
@@ -1015,6 +1020,57 @@ static hipError_t launch_ringx(int flags, const GemmP& p, const GemmArgs& a, hip
     }
 }
 
+// gemm_ringw_kernel (W fragments straight from L2 into registers, X-only LDS ring): which = 0 (3 slots, 3 W buffers), 1 (4 slots, 2 buffers)
+template <int NS, int NB, bool F16>
+static hipError_t launch_ringw_t(const GemmP& p, const GemmArgs& a, hipStream_t st, int splits) {
+    if (F16) splits = 1;
+    while (splits > 1 && (a.epi == EPI_SWIGLU || !a.splitk_ws || (size_t)splits * a.M * a.N * sizeof(float) > a.splitk_ws_bytes)) --splits;
+    const int tiles = cdiv(a.N, 256) * cdiv(a.M, 256);
+    const int cap = a.ring_max_blocks > 0 && a.ring_max_blocks < 256 ? a.ring_max_blocks : 256;
+    dim3 grid(splits > 1 || tiles <= cap ? tiles : cap, 1, splits);
+    set_plan(a, GEMM_K_RING256, tiles, splits, (int)grid.x * splits);
+    const size_t smem = (size_t)NS * 256 * 32 * sizeof(bf16_t) + 16 * 1024;         // X ring + two 1 KB transposition slots per wave
+    const int KT = a.K >> 5;
+    const dim3 block(512);
+    GemmP q = p;
+    q.dump = ring_dump_slot();
+    if (!q.dump) return hipErrorOutOfMemory;
+    static const int direct_stores = getenv("MMDUET_RINGW_DIRECT_STORES") ? atoi(getenv("MMDUET_RINGW_DIRECT_STORES")) : 0;          // A/B switches
+    static const int dephase = getenv("MMDUET_RINGW_DEPHASE") ? atoi(getenv("MMDUET_RINGW_DEPHASE")) : 0;          // (measured: no difference once the stores are lane-adjacent)
+    q.flags = direct_stores ? 1 : 0;
+    // blocks that own one tile fewer start ~half a tile late (a K step ~ 0.8 us, a sleep unit ~ 4 us)
+    q.kper = (dephase && splits == 1 && tiles > (int)grid.x) ? (int)((a.K / 32) * 0.8 * 0.5 / 4.0 * dephase + 0.5) : 0;
+    if (smem > 65536) {
+        static bool attr_set[64] = {};
+        int adev = 0; hipGetDevice(&adev);
+        if (adev >= 0 && adev < 64 && !attr_set[adev]) {
+#define RW_ATTR(E) hipFuncSetAttribute((const void*)gemm_ringw_kernel<E, NS, NB, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            RW_ATTR(EPI_NONE) RW_ATTR(EPI_GELU_TANH) RW_ATTR(EPI_RESID)
+            if constexpr (!F16) { RW_ATTR(EPI_GELU_ERF) RW_ATTR(EPI_SWIGLU) }
+#undef RW_ATTR
+            attr_set[adev] = true;
+        }
+    }
+    switch (a.epi) {
+        case EPI_GELU_TANH: hipLaunchKernelGGL((gemm_ringw_kernel<EPI_GELU_TANH, NS, NB, F16>), grid, block, smem, st, q, KT); break;
+        case EPI_RESID: hipLaunchKernelGGL((gemm_ringw_kernel<EPI_RESID, NS, NB, F16>), grid, block, smem, st, q, KT); break;
+        case EPI_NONE: hipLaunchKernelGGL((gemm_ringw_kernel<EPI_NONE, NS, NB, F16>), grid, block, smem, st, q, KT); break;
+        case EPI_GELU_ERF: if constexpr (!F16) { hipLaunchKernelGGL((gemm_ringw_kernel<EPI_GELU_ERF, NS, NB, false>), grid, block, smem, st, q, KT); break; } else return hipErrorInvalidValue;
+        case EPI_SWIGLU: if constexpr (!F16) { hipLaunchKernelGGL((gemm_ringw_kernel<EPI_SWIGLU, NS, NB, false>), grid, block, smem, st, q, KT); break; } else return hipErrorInvalidValue;
+        default: return hipErrorInvalidValue;
+    }
+    if (splits > 1) {
+        if (a.ring_slabs_out) { *a.ring_slabs_out = splits; return hipGetLastError(); }
+        long long work = (long long)a.M * ((a.N + 3) / 4);
+        hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), dim3(cdiv(work, 256)), dim3(256), 0, st, p, splits);
+    }
+    return hipGetLastError();
+}
+static hipError_t launch_ringw(int which, const GemmP& p, const GemmArgs& a, hipStream_t st, int splits = 1) {
+    if (a.f16) return which == 1 ? launch_ringw_t<4, 2, true>(p, a, st, 1) : launch_ringw_t<3, 3, true>(p, a, st, 1);
+    return which == 1 ? launch_ringw_t<4, 2, false>(p, a, st, splits) : launch_ringw_t<3, 3, false>(p, a, st, splits);
+}
+
 // the ring GEMM addresses its operands as uniform base + 32-bit byte offset
 static bool ring_size_ok(const GemmArgs& a) { return (long long)a.M * a.ldx * 2 < (1ll << 32) && (long long)a.N * a.K * 2 < (1ll << 32); }
 // enough 256^2 tiles for the persistent ring: >= 400 (1.6 block waves of the 256 CUs), or close to whole waves from 0.75 of one up (4096^2: 256 tiles = one
@@ -1037,7 +1093,7 @@ static hipError_t launch_t(const GemmArgs& a, hipStream_t st, int* kind_out) {
     GemmP p;
     p.X = a.X; p.W = a.W; p.bias = a.bias; p.R = a.R; p.Y = a.Y; p.ws = a.splitk_ws; p.wscale = a.wscale;
     p.ldx = a.ldx; p.ldw = a.ldw; p.ldr = a.ldr; p.ldy = a.ldy;
-    p.M = a.M; p.N = a.N; p.K = a.K; p.epi = a.epi; p.out_f32 = a.out_f32; p.slabs = a.slabs_out ? 1 : 0; p.dump = nullptr;
+    p.M = a.M; p.N = a.N; p.K = a.K; p.epi = a.epi; p.out_f32 = a.out_f32; p.slabs = a.slabs_out ? 1 : 0; p.dump = nullptr; p.flags = 0; p.kper = 0;
     p.vec = (sizeof(T) == 2 && (a.ldx % 8) == 0 && (a.ldw % 8) == 0 && ((uintptr_t)a.X % 16) == 0 && ((uintptr_t)a.W % 16) == 0) ? 1 : 0;
     if (a.ring_slabs_out) *a.ring_slabs_out = 0;
     if (a.M <= 0 || a.N <= 0) return hipSuccess;
@@ -1052,6 +1108,11 @@ static hipError_t launch_t(const GemmArgs& a, hipStream_t st, int* kind_out) {
             if (!big_packed_ok(MMD_BF16, a, 16) || (a.N % 32) != 0 || !ring_size_ok(a)) return hipErrorInvalidValue;
             p.W = a.Wp;
             if (kind_out) *kind_out = MMD_K_GEMM_TILE;
+            // gemm_ringw_kernel (W operand straight to registers, lane-adjacent output stores) is 5-7 % faster than the ring on the tower's short-K shapes in isolation
+            // (qkv 188 -> 175 us, o 67 -> 63, fc1 265 -> 252: profiles/r04_ringw_ab.json) and loses 5-9 % where W is streamed from HBM or K is long (fc2, gate_up, 8192^3).
+            // Inside the model the stream is +-0.5 % either way (profiles/r04_gemm_experiments.md): it stays OPT-IN (MMDUET_RINGW=1), the shipped tower runs the ring.
+            static const bool use_ringw = getenv("MMDUET_RINGW") != nullptr && atoi(getenv("MMDUET_RINGW")) != 0;
+            if (variant == GEMM_AUTO && use_ringw && a.ring_flags == 16 && !a.wscale && a.K <= 2048 && (long long)a.N * a.K * 2 <= (48ll << 20)) return launch_ringw(0, p, a, st);
             return launch_ringx(a.ring_flags, p, a, st);
         }
         // long K with under one block wave of 256^2 tiles (down_proj of a chunk): split K across grid.z so ~one block per CU runs a
@@ -1089,7 +1150,16 @@ static hipError_t launch_t(const GemmArgs& a, hipStream_t st, int* kind_out) {
             return variant == 96 ? launch_ringx_dbg<1>(p, a, st) : (variant == 97 ? launch_ringx_dbg<2>(p, a, st) : launch_ringx_dbg<3>(p, a, st));
         }
 #endif
-        if (variant >= GEMM_RINGX && variant < GEMM_RINGX + 256) {          // forced ring variants (A/B and parity of every instantiation)
+        if (variant >= GEMM_RINGW && variant < GEMM_RINGW + 8) {          // forced gemm_ringw instantiations: + 0 / 1 = (3,3) / (4,2) slots, W buffers; + 4: split K
+            if (!big_packed_ok(MMD_BF16, a, 16) || (a.N % 32) != 0 || !ring_size_ok(a) || a.wscale) return hipErrorInvalidValue;          // (no per-channel weight scale in this kernel: its shapes are the tower's)
+            const int w = (variant - GEMM_RINGW) & 3;
+            int sp = 1;
+            if ((variant - GEMM_RINGW) & 4) { sp = 256 / (cdiv(a.M, 256) * cdiv(a.N, 256)); if (sp < 2) sp = 2; while (sp > 2 && a.K / sp < 1024) --sp; }
+            p.W = a.Wp;
+            if (kind_out) *kind_out = MMD_K_GEMM_TILE;
+            return launch_ringw(w == 1 ? 1 : 0, p, a, st, sp);
+        }
+        if (variant >= GEMM_RINGX && variant < GEMM_RINGX + 128) {          // forced ring variants (A/B and parity of every instantiation)
             if (!big_packed_ok(MMD_BF16, a, 16) || (a.N % 32) != 0 || !ring_size_ok(a)) return hipErrorInvalidValue;
             const int flags = variant - GEMM_RINGX;
             int sp = 1;

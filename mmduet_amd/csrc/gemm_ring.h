@@ -13,6 +13,7 @@ struct GemmP {
     int M, N, K, epi, out_f32, kper, vec;
     int slabs;         // skinny kernel: always leave fp32 slabs in ws (the consumer kernel reduces them)
     void* dump;        // ring kernel: 8 KB nobody reads -- masked output lanes store here (a per-device buffer of the launcher, never the split-K workspace)
+    int flags;         // gemm_ringw_kernel: bit 0 = output stores straight from the accumulator layout (A/B switch of the lane-adjacent epilogue)
 };
 
 // guard-free epilogue of the big-tile kernel: N % BN == 0, ldy/ldr % 4 == 0 (dispatch conditions), one 8-byte access

@@ -544,3 +544,62 @@ def test_bench_launches_its_own_ranks_nccl():
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
     assert line['n_gpus'] == 2 and line['rccl_ranks'] == 2 and line['config']['native_gather_check'] == 'ok'
+
+
+# ---- gemm_ringw_kernel: W fragments straight from L2 into registers, X-only LDS ring (round 4) ------------------------------------------------------
+RINGW = {200: '3 slots / 3 W buffers', 201: '4 slots / 2 W buffers'}
+
+
+@pytest.mark.parametrize('variant', sorted(RINGW))
+@pytest.mark.parametrize('name,M,N,K,epi', [('vit_fc1', 25515, 4352, 1152, 'gelu_tanh'), ('vit_o', 25515, 1152, 1152, 'resid'), ('gate_up_tail', 1303, 37888, 3584, 'swiglu'),
+                                            ('ragged', 3000, 1184, 704, 'none'), ('k64', 700, 512, 64, 'none'), ('k128', 513, 256, 128, 'resid'), ('k192', 300, 288, 192, 'none'), ('k256', 300, 288, 256, 'none'), ('k320', 257, 64, 320, 'none')])
+def test_ringw_instantiations_match_fp32_and_the_shipped_ring(ops, variant, name, M, N, K, epi):
+    """gemm_ringw_kernel<EPI, NS, NB> (hand-counted vmcnt over inline-asm W loads + LDS-DMA X pieces) at production shapes, M / N tails and tiles of 2 .. 10 K slices
+    (prologue / tail paths): fp32 math to the bf16 bound, and the SAME BITS as the shipped ring (same products, same accumulation order per output element)."""
+    dev = ops.dev
+    g = torch.Generator(device=dev).manual_seed(N + K)
+    X = (torch.randn(M, K, generator=g, device=dev) * 0.7).to(torch.bfloat16)
+    W = (torch.randn(N, K, generator=g, device=dev) / math.sqrt(K)).to(torch.bfloat16)
+    b = (0.1 * torch.randn(N, generator=g, device=dev)).to(torch.bfloat16)
+    Xf = X.float()
+    if epi == 'swiglu':
+        gate, up = W[:N // 2], W[N // 2:]
+        Wi = torch.stack([gate.view(-1, 16, K), up.view(-1, 16, K)], 1).reshape(N, K).contiguous()
+        Y = ops.gemm(X, Wi, None, epi=epi, variant=variant); plan = _plan(ops)
+        Y0 = ops.gemm(X, Wi, None, epi=epi, variant=32)
+        ref = F.silu((Xf @ gate.float().T).to(torch.bfloat16).float()).to(torch.bfloat16).float() * (Xf @ up.float().T).to(torch.bfloat16).float()
+    elif epi == 'resid':
+        R = torch.randn(M, N, generator=g, device=dev).to(torch.bfloat16)
+        Y = ops.gemm(X, W, b, R=R, epi=epi, variant=variant); plan = _plan(ops)
+        Y0 = ops.gemm(X, W, b, R=R, epi=epi, variant=32)
+        ref = F.linear(Xf, W.float(), b.float()).to(torch.bfloat16).float() + R.float()
+    else:
+        Y = ops.gemm(X, W, b, epi=epi, variant=variant); plan = _plan(ops)
+        Y0 = ops.gemm(X, W, b, epi=epi, variant=32)
+        lin = F.linear(Xf, W.float(), b.float())
+        ref = O.gelu_tanh(lin.to(torch.bfloat16).float()) if epi == 'gelu_tanh' else lin
+    err = _rel_err(Y, ref)
+    assert torch.isfinite(Y.float()).all() and err <= 2.4e-2, (variant, name, err, plan)
+    assert plan['kernel'] == 6, plan
+    assert torch.equal(Y, Y0), (variant, name, (Y.float() - Y0.float()).abs().max().item())
+
+
+@pytest.mark.parametrize('variant', sorted(RINGW))
+def test_ringw_repeats_bit_identical_beside_a_copy_stream(ops, variant):
+    """Race screen of the hand-counted waits: a W fragment consumed before its load landed, or an X slot refilled early, shows as a rare differing tile -- repeat the
+    launch beside a copy stream that perturbs the memory system; every repeat must give the same bits (persistent multi-tile shape and a split-K launch)."""
+    dev = ops.dev
+    g = torch.Generator(device=dev).manual_seed(variant)
+    noise = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
+    side = torch.cuda.Stream()
+    for (M, N, K, v) in ((25515, 1152, 1152, variant), (1274, 3584, 18944, variant + 4)):
+        X = (torch.randn(M, K, generator=g, device=dev) * 0.7).to(torch.bfloat16)
+        W = (torch.randn(N, K, generator=g, device=dev) / math.sqrt(K)).to(torch.bfloat16)
+        first = ops.gemm(X, W, variant=v).clone()
+        assert _rel_err(first, Xf := X.float() @ W.float().T) <= 1.2e-2
+        for r in range(40):
+            if r % 3 == 0:
+                with torch.cuda.stream(side):
+                    noise[:128 << 20].copy_(noise[128 << 20:], non_blocking=True)
+            assert torch.equal(ops.gemm(X, W, variant=v), first), (v, r)
+    torch.cuda.synchronize()

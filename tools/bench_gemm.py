@@ -72,10 +72,11 @@ if __name__ == '__main__':
     if which == 'ab':
         # interleaved A/B (guide rule 24): python tools/bench_gemm.py ab <variant,variant,...> [rounds] [out.json]; every round runs every variant on the same operands
         import statistics
-        names = {0: 'auto', 4: 'big', 32: 'rx-8w-early', 33: 'rx-4w-early', 40: 'rx-8w-ns4-early', 92: 'DBG-ns4-half-barriers', 93: 'rx-fine', 99: 'DBG-no-epilogue', 98: 'DBG-no-dma', 7: 'ring-splitK', 48: 'rx-8w-early-splitK'}
+        names = {200: 'ringw-3s3b', 201: 'ringw-4s2b', 202: 'ringw-4s3b', 204: 'ringw-3s3b-splitK', 0: 'auto', 4: 'big', 32: 'rx-8w-early', 33: 'rx-4w-early', 40: 'rx-8w-ns4-early', 92: 'DBG-ns4-half-barriers', 93: 'rx-fine', 99: 'DBG-no-epilogue', 98: 'DBG-no-dma', 7: 'ring-splitK', 48: 'rx-8w-early-splitK'}
         vs = [int(v) for v in sys.argv[2].split(',')]
         rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 7
-        shapes = [(25515, 'vit_qkv', 3456, 1152, 'none'), (25515, 'vit_o_none', 1152, 1152, 'none'), (25515, 'proj2', 3584, 3584, 'none'), (1274, 'gate_up_none', 37888, 3584, 'none'),
+        shapes = [(25515, 'vit_qkv', 3456, 1152, 'none'), (25515, 'vit_o_none', 1152, 1152, 'none'), (25515, 'vit_fc1', 4352, 1152, 'gelu_tanh'), (25515, 'vit_fc2', 1152, 4352, 'resid'), (25515, 'proj2', 3584, 3584, 'none'),
+                  (1274, 'gate_up_none', 37888, 3584, 'none'), (1274, 'gate_up', 37888, 3584, 'swiglu'), (1274, 'down', 3584, 18944, 'resid'),
                   (1274, 'qkv', 4608, 3584, 'none'), (4096, 'sq4096', 4096, 4096, 'none'), (8192, 'sq8192', 8192, 8192, 'none')]
         if os.environ.get('AB_SHAPES'): shapes = [sh for sh in shapes if sh[1] in os.environ['AB_SHAPES'].split(',')]
         rows = []
