@@ -229,12 +229,15 @@ int mmd_prof_reset(mmd_ctx* ctx);
 /* ---- raw operator entry points (parity tests call the kernels through these) ------------------------------------ */
 /* Y[M,N] = epilogue(X[M,K] . W[N,K]^T + bias).  epi: 0 none, 1 gelu(tanh), 2 gelu(erf), 3 add residual R[M,N],
  * 4 SwiGLU (W rows interleaved gate/up in blocks of 16 -> Y[M,N/2]).  out_f32 != 0 writes fp32. variant: 0 auto,
- * 1 generic tile, 2 skinny/split-K, 3 large tile, 4 DMA 128-row tile, 5 skinny slabs, 6 256x256 ring. */
+ * 1 generic tile, 2 skinny/split-K, 3 large tile, 4 DMA 128-row tile, 5 skinny slabs, 6 256x256 ring, 8 streaming kernel (32 < M <= 256; SwiGLU only in this form). */
 int mmd_op_gemm(mmd_ctx* ctx, const void* X, const void* W, const void* bias, const void* R, void* Y, int M, int N, int K,
                 int epi, int out_f32, int variant);
 /* what the dispatcher chose for the most recent GEMM of this context: out4 = {kernel (0 tile64, 1 tile128, 2 skinny, 3 gemv16, 4 big64,
  * 5 big128, 6 ring256), output tiles, K splits, blocks launched} */
 int mmd_op_gemm_last_plan(mmd_ctx* ctx, int* out4);
+/* the weight-streaming GEMMs in slab mode (what the fused LLM schedule launches for M <= 256): `*splits_out` fp32 partial slabs [splits][M][N] of X . W^T in slabs_out
+ * (device, room for max_splits slabs); variant 2 = the dispatcher's choice by M (gemv16 / skinny / stream), 8 = gemm_stream_kernel */
+int mmd_op_gemm_slabs(mmd_ctx* ctx, const void* X, const void* W, int M, int N, int K, int variant, float* slabs_out, int max_splits, int* splits_out);
 /* fp8 weight path, raw form: mmd_op_quantize_fp8 replaces W [N,K] (bf16, row-major, device) by bf16(q), q = rne_e4m3(W / scale[n]),
  * scale[n] = amax_n / 448, and writes the fp8 bytes q8 [N,K] and scale [N] (fp32).  mmd_op_gemm_w8 = mmd_op_gemm on such a matrix:
  * Y = epilogue((X . q^T) * scale + bias); M <= 64 streams the fp8 copy, larger M the bf16(q) copy (bit-identical values). */

@@ -94,6 +94,7 @@ _SIGS = {
     'mmd_op_gemm': (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _I]),
     'mmd_op_gemm_bench': (_I, [_VP, _I, _I, _I, _I, _I, _I, C.POINTER(_F), _VP, _VP]),
     'mmd_op_gemm_last_plan': (_I, [_VP, C.POINTER(_I)]),
+    'mmd_op_gemm_slabs': (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _VP, _I, C.POINTER(_I)]),
     'mmd_op_quantize_fp8': (_I, [_VP, _VP, _I, _I, _VP, _VP]),
     'mmd_op_gemm_w8': (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _I]),
     'mmd_op_rmsnorm': (_I, [_VP, _VP, _VP, _VP, _I, _I, _F]),

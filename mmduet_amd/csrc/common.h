@@ -102,6 +102,7 @@ struct StepState { long long n_ctx; long long cap; void* K; void* V; int n_prev;
 enum { EPI_NONE = 0, EPI_GELU_TANH = 1, EPI_GELU_ERF = 2, EPI_RESID = 3, EPI_SWIGLU = 4 };
 enum { GEMM_AUTO = 0, GEMM_GENERIC = 1, GEMM_SKINNY = 2, GEMM_LARGE = 3, GEMM_BIG = 4, GEMM_SLAB = 5, GEMM_RING256 = 6, GEMM_RING256_SPLIT = 7,
        GEMM_RINGX = 16 /* + 1: 4-wave 256x128 blocks, + 2: 32x32x16 MFMA, + 4: split K */,
+       GEMM_STREAM = 8 /* gemm_stream_kernel (32 < M <= 256, slabs or SwiGLU) */,
        GEMM_RINGW = 200 /* gemm_ringw_kernel (W operand straight to registers): + 0 / 1 = (3,3) / (4,2) ring slots, W buffers; + 4: split K */ };
 
 // Decode chain of the weight-streaming GEMV (M <= 16, bf16): the residual add + RMSNorm between two GEMVs costs a launch and a cold, dependent
@@ -142,7 +143,7 @@ struct GemmArgs {
     int f16 = 0;                                // operands, bias, residual and output are IEEE half (launch_gemm(MMD_F16, ...): the fp16 vision tower; ring / big kernels only)
 };
 // which kernel the dispatcher chose (mmd_op_gemm_last_plan; parity tests assert the production kernel really ran)
-enum { GEMM_K_TILE64 = 0, GEMM_K_TILE128 = 1, GEMM_K_SKINNY = 2, GEMM_K_GEMV16 = 3, GEMM_K_BIG64 = 4, GEMM_K_BIG128 = 5, GEMM_K_RING256 = 6, GEMM_K_RING128X2 = 7 };
+enum { GEMM_K_TILE64 = 0, GEMM_K_TILE128 = 1, GEMM_K_SKINNY = 2, GEMM_K_GEMV16 = 3, GEMM_K_BIG64 = 4, GEMM_K_BIG128 = 5, GEMM_K_RING256 = 6, GEMM_K_RING128X2 = 7, GEMM_K_STREAM = 8 };
 bool gemm_can_slab(int dtype, const GemmArgs& a);
 
 // launchers (dtype = mmd_dtype).  All return hipError_t of the launch.

@@ -666,6 +666,193 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_gemv16_kernel(GemmP p, int KT
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// gemm_stream_kernel<MT, NT, WK, KS, NB>: the weight-streaming GEMM of the 16 < M <= 256 regime (round 4) -- the reference's own
+// per-frame schedule (M = 49 + prefix, test/inference.py:221-246), the demo path (demo/liveinfer.py:69-105), short chunks and the remainders behind a response.
+// Up to M = 256 a forward is bound by the 466 MB of weights a layer streams (16 MFMAs per 1 KB weight tile fill the CU's four SIMDs only at M = 256), yet
+// gemm_skinny_kernel reads 3.3-4.6 TB/s at M = 49 and 64 < M <= 256 fell to the 128-row tile kernel (2.4-3.0 x the weight-stream time).  Measured causes
+// (profiles/r04_step49_kernels_before.txt): X staged through registers behind the weight loads (waiting for X = vmcnt(0): nothing stays in flight across the step
+// barrier), one step of lookahead, and 296 four-wave blocks for gate_up -- most CUs hold 4 waves x 8 KB in flight, below what 25 GB/s per CU needs.
+//
+//   * block = 4 x WK waves: wave (wn, wk) owns NT n-tiles (16 columns each) and the k-tiles wk * KS .. of every step (the block's K range advances KSB = WK * KS
+//     k-tiles per step); all MT m-tiles (M <= 16 MT rows).  The WK partial sums meet in LDS once at the end.
+//   * W: packed fragment tiles straight into registers by inline-asm non-temporal loads, LA = NB - 1 steps ahead through NB register buffers (NT * KS KB per wave
+//     and step): LA * NT * KS KB in flight per wave at all times.
+//   * X: the step's [16 MT rows][32 KSB k] slab by LDS-DMA into an NB-slot ring, in the ring GEMM's piece format (16 rows x 64 B pieces, 16-byte chunk XOR-swizzled:
+//     conflict-free b128 fragment reads), issued LA steps ahead like W; every wave reads the fragments of its own k-tiles at use.
+//   * ONE hand-counted `s_waitcnt vmcnt((LA - 1) * (NT * KS + XP))` + raw s_barrier per step (W (s) and X (s) were both issued in step s - LA; the LA - 1 steps behind
+//     them stay in flight); hipcc sees none of the W loads (inline asm) and never waits for them.
+//   * epilogue: fp32 slabs for the fused consumers (reduce + bias + RoPE + append / reduce + residual + RMSNorm), or the SwiGLU / plain epilogues in place.
+// ------------------------------------------------------------------------------------------------------------------
+template <int N_, typename F> __device__ __forceinline__ void stream_static_for(F&& f) {
+    if constexpr (N_ > 0) { stream_static_for<N_ - 1>(f); f(std::integral_constant<int, N_ - 1>{}); }
+}
+
+template <int MT, int NT, int WK, int KS, int NB, int DBG = 0, int WN = 4>          // DBG (timing only, wrong results): 1 = W stream alone (no X DMA, no MFMA), 2 = no W loads
+__global__ __launch_bounds__(64 * WN * WK) void gemm_stream_kernel(GemmP p, int KT, int kt_per_block) {
+    constexpr int NWAVE = WN * WK, KSB = WK * KS;
+    constexpr int XPIECES = MT * KSB;                        // 1 KB pieces of the step's X slab
+    constexpr int XP = DBG == 1 ? 0 : (XPIECES + NWAVE - 1) / NWAVE;       // LDS-DMAs per wave and step: the SAME count for every wave (the hand-counted waits need that): where the
+                                                                           // pieces do not divide evenly, the surplus DMAs re-load pieces 0.. (same bytes to the same place)
+    constexpr int NWL = DBG == 2 ? 0 : NT * KS;              // W loads per wave and step
+    constexpr int LA = NB - 1;
+    constexpr int ISSUE = NWL + XP;
+    constexpr int VM_STEP = (LA - 1) * ISSUE;
+    constexpr int XSLOT = XPIECES * 512;                     // elements per ring slot
+    static_assert(VM_STEP <= 63, "vmcnt is a 6-bit counter");
+    extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lq = lane >> 4;
+    const int wn = wave % WN, wk = wave / WN;
+    const int ntiles = p.N >> 4;
+    const int nt0 = (blockIdx.x * WN + wn) * NT;          // (a wave whose n-tiles lie beyond N streams the last tile again and stores nothing)
+    const int kt_beg = blockIdx.y * kt_per_block;
+    const int kt_end = min(KT, kt_beg + kt_per_block);
+    const int nsteps = (kt_end - kt_beg) / KSB;              // (dispatch condition: every block's K range is a whole number of steps)
+    const bf16_t* X = (const bf16_t*)p.X;
+    const bf16_t* Wp = (const bf16_t*)p.W;
+
+    // X piece pi = (m-tile pi / KSB, k-tile pi % KSB of the step): lane -> row srow, 16-byte chunk spos ^ sswz (the ring GEMM's piece image)
+    const int srow = lane >> 2, spos = lane & 3;
+    const int sswz = (0x1230 >> (((srow >> 2) & 3) * 4)) & 3;
+    unsigned xo[XP + 1];
+#pragma unroll
+    for (int j = 0; j < XP; ++j) {
+        const int pi = (wave + NWAVE * j) % XPIECES;
+        int row = (pi / KSB) * 16 + srow; row = row < p.M ? row : p.M - 1;
+        xo[j] = (unsigned)(row * (int)p.ldx + (pi % KSB) * 32 + ((spos ^ sswz) * 8)) * 2u;
+    }
+    long long wo[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) { int nt = nt0 + j; nt = nt < ntiles ? nt : ntiles - 1; wo[j] = ((long long)nt * KT + kt_beg + wk * KS) * 1024; }
+    const unsigned wlane = lane * 16;
+    auto dma_x = [&](int slot, int step, int j) {
+        const char* ub = (const char*)X + ((long long)kt_beg + (long long)step * KSB) * 64;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ub + xo[j]),
+                                         (__attribute__((address_space(3))) void*)(lds + slot * XSLOT + ((wave + NWAVE * j) % XPIECES) * 512), 16, 0, 0);
+    };
+    auto load_w = [&](bf16x8_t& dst, int j, int ks, int step) {
+        const unsigned long long ua = (unsigned long long)(uintptr_t)((const char*)Wp + wo[j] + ((long long)step * KSB + ks) * 1024);
+        // (under SGPR pressure hipcc parks uniform values in VGPR lanes; an asm "s" operand cannot take them back -- readfirstlane can)
+        const unsigned long long ub = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(ua >> 32)) << 32) |
+                                      (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)ua);          // (the builtin returns int: widen as UNSIGNED)
+        asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(dst) : "v"(wlane), "s"(ub) : "memory");
+    };
+    const int rswz = (0x1230 >> (((lr >> 2) & 3) * 4)) & 3;
+    const int aoff = lr * 32 + ((lq ^ rswz) * 8);
+
+    f32x4_t acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0, 0, 0, 0};
+    bf16x8_t wb[NB][NT][KS];
+
+    auto issue = [&](int step, auto buf_c) {          // everything step `step` needs, into register buffer / ring slot `buf`
+        constexpr int buf = decltype(buf_c)::value;
+        if constexpr (DBG != 2) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) load_w(wb[buf][j][ks], j, ks, step);
+        }
+#pragma unroll
+        for (int j = 0; j < XP; ++j) dma_x(buf, step, j);
+    };
+    // prologue: steps 0 .. LA - 1
+    stream_static_for<LA>([&](auto uc) { constexpr int u = decltype(uc)::value; if (u < nsteps) issue(u, std::integral_constant<int, u>{}); });
+
+    auto step = [&](int s, auto buf_c, bool steady) {
+        constexpr int cur = decltype(buf_c)::value, nxt = (cur + LA) % NB;
+        if (steady) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(VM_STEP) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // tail: the steps behind this one issued less than a full set
+        MMD_BAR();
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + LA < nsteps) issue(s + LA, std::integral_constant<int, nxt>{});
+        __builtin_amdgcn_sched_barrier(0);
+        const bf16_t* xs = lds + cur * XSLOT;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int ktl = wk * KS + ks;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                if constexpr (DBG == 1) {          // keep the W registers live without the matrix pipe
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) if (i == 0) { const u32x4_t w4 = __builtin_bit_cast(u32x4_t, wb[cur][j][ks]); asm volatile("" :: "v"(w4[0]), "v"(w4[1]), "v"(w4[2]), "v"(w4[3])); }
+                    continue;
+                }
+                const bf16x8_t xf = *reinterpret_cast<const bf16x8_t*>(xs + (i * KSB + ktl) * 512 + aoff);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[cur][j][ks], xf, acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+    int s = 0;
+    for (; s + NB + LA <= nsteps; s += NB)          // steady periods: every step of the period and the LA - 1 steps behind each issue a full set
+        stream_static_for<NB>([&](auto uc) { constexpr int u = decltype(uc)::value; step(s + u, std::integral_constant<int, u>{}, true); });
+    for (; s < nsteps; )
+        stream_static_for<NB>([&](auto uc) { constexpr int u = decltype(uc)::value; if (s < nsteps) { step(s, std::integral_constant<int, u>{}, s + LA < nsteps); ++s; } });
+
+    // the WK partial sums of a column group meet in LDS (the ring is dead: every wave has read its last slot behind the barrier below)
+    if constexpr (WK > 1) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(lds);
+        if (wk > 0) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) *reinterpret_cast<f32x4_t*>(red + ((((wk - 1) * WN + wn) * MT + i) * NT + j) * 256 + lane * 4) = acc[i][j];
+        }
+        __syncthreads();
+        if (wk > 0) return;
+#pragma unroll
+        for (int w2 = 0; w2 < WK - 1; ++w2)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] += *reinterpret_cast<const f32x4_t*>(red + (((w2 * WN + wn) * MT + i) * NT + j) * 256 + lane * 4);
+    }
+    if (gridDim.y > 1 || p.slabs) {
+        float* ws = p.ws + (long long)blockIdx.y * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int m = i * 16 + lr, n = (nt0 + j) * 16 + lq * 4;
+                if (m < p.M && nt0 + j < ntiles) {
+                    f32x4_t v = acc[i][j];
+                    if (p.slabs && p.wscale) v *= *reinterpret_cast<const f32x4_t*>(p.wscale + n);
+                    *reinterpret_cast<f32x4_t*>(ws + (long long)m * p.N + n) = v;
+                }
+            }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int m = i * 16 + lr;
+        if (p.epi == EPI_SWIGLU) {
+            if constexpr (NT >= 2) {
+#pragma unroll
+                for (int j = 0; j < NT; j += 2) {
+                    if (nt0 + j + 1 < ntiles) {
+                        float g[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                        float u[4] = {acc[i][j + 1][0], acc[i][j + 1][1], acc[i][j + 1][2], acc[i][j + 1][3]};
+                        store4_swiglu<bf16_t>(p, m, (nt0 + j) * 16 + lq * 4, g, u);
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                if (nt0 + j < ntiles) {
+                    float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                    store4<bf16_t>(p, m, (nt0 + j) * 16 + lq * 4, v);
+                }
+            }
+        }
+    }
+}
+
 static inline void set_plan(const GemmArgs& a, int kernel, int tiles, int splits, int blocks) {
     if (a.plan_out) { a.plan_out[0] = kernel; a.plan_out[1] = tiles; a.plan_out[2] = splits; a.plan_out[3] = blocks; }
 }
@@ -705,6 +892,95 @@ static void launch_gemv16(const GemmP& p, const GemmArgs& a, hipStream_t st) {
     if (a.Wp8) { if (two) { if (chain) GEMV16_GO(2, true, true); else GEMV16_GO(2, true, false); } else { if (chain) GEMV16_GO(1, true, true); else GEMV16_GO(1, true, false); } }
     else       { if (two) { if (chain) GEMV16_GO(2, false, true); else GEMV16_GO(2, false, false); } else { if (chain) GEMV16_GO(1, false, true); else GEMV16_GO(1, false, false); } }
 #undef GEMV16_GO
+}
+
+// gemm_stream_kernel: 32 < M <= 256, packed bf16 weights, slab output (fused consumers) or the SwiGLU epilogue.  K must be a whole number of steps.
+static bool stream_ok(int dtype, const GemmArgs& a) {
+    static const bool off = getenv("MMDUET_NO_STREAM") != nullptr;
+    if (off || dtype != MMD_BF16 || a.f16 || !a.Wp || a.M <= 32 || a.M > 256 || (a.N % 16) != 0 || (a.ldx % 8) != 0 || ((uintptr_t)a.X % 16) != 0 || a.out_f32) return false;
+    if (a.Wp8 && a.M <= 64) return false;                                  // fp8 builds keep the 1-byte skinny kernel where it exists
+    if ((long long)a.M * a.ldx * 2 >= (1ll << 32)) return false;            // X addressed as base + 32-bit offset
+    const int ksb = a.M <= 128 ? 4 : 2;          // k-tiles per step of the instantiation that serves this M
+    if ((a.K % (ksb * 32)) != 0) return false;
+    if (a.epi == EPI_SWIGLU) return (a.N % 32) == 0 && !a.slabs_out && a.M <= 128;
+    if ((a.N >> 4) >= 4096 && a.M > 128) return false;
+    if (a.slabs_out) return a.splitk_ws != nullptr && a.epi == EPI_NONE;
+    // epilogue in place (unfused schedule, several streams per forward): the same K split into the workspace, then the serial slab reduce applies bias / residual / activation --
+    // slab for slab what the fused consumers do, so both schedules produce the same bits
+    return a.splitk_ws != nullptr && (a.N % 4) == 0 && (a.ldy % 4) == 0 && (a.epi != EPI_RESID || (a.ldr % 4) == 0);
+}
+template <int MT, int NT, int WK, int KS, int NB, int DBG = 0, int WN = 4>
+static hipError_t launch_stream_t(const GemmP& p, const GemmArgs& a, hipStream_t st, int want_split = 0) {
+    constexpr int KSB = WK * KS;
+    const int KT = a.K >> 5, ntiles = a.N >> 4;
+    const int bx = cdiv(ntiles, WN * NT);
+    int ksplit = 1;
+    if (a.slabs_out || (a.epi != EPI_SWIGLU && a.splitk_ws)) {
+        ksplit = want_split > 0 ? want_split : cdiv(288, bx);                                            // ~ one block per CU and a bit: every CU streams
+        const int maxs = KT / (KSB * 6); if (ksplit > maxs) ksplit = maxs;  // >= 6 steps per block (the pipeline is NB - 1 steps deep)
+        if (ksplit > 16) ksplit = 16; if (ksplit < 1) ksplit = 1;
+        while (ksplit > 1 && (size_t)ksplit * a.M * a.N * sizeof(float) > a.splitk_ws_bytes) --ksplit;
+    }
+    const int ktper = (int)round_up(cdiv(KT, ksplit), KSB);
+    ksplit = cdiv(KT, ktper);
+    if (a.slabs_out) *a.slabs_out = ksplit;
+    set_plan(a, GEMM_K_STREAM, ntiles, ksplit, bx * ksplit);
+    constexpr size_t ring = (size_t)NB * MT * KSB * 1024, red = (size_t)(WK - 1) * WN * MT * NT * 1024;
+    constexpr size_t smem = ring > red ? ring : red;
+    static bool attr_set[64] = {};
+    int adev = 0; hipGetDevice(&adev);
+    if (smem > 65536 && adev >= 0 && adev < 64 && !attr_set[adev]) {
+        hipFuncSetAttribute((const void*)gemm_stream_kernel<MT, NT, WK, KS, NB, DBG, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_set[adev] = true;
+    }
+    hipLaunchKernelGGL((gemm_stream_kernel<MT, NT, WK, KS, NB, DBG, WN>), dim3(bx, ksplit), dim3(64 * WN * WK), smem, st, p, KT, ktper);
+    if (!a.slabs_out && ksplit > 1) {          // epilogue in place: the serial slab reduce (slab 0, 1, 2, ... -- the fused consumers' order)
+        long long work = (long long)a.M * ((a.N + 3) / 4);
+        hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), dim3(cdiv(work, 256)), dim3(256), 0, st, p, ksplit);
+    }
+    return hipGetLastError();
+}
+// Decomposition of a streaming GEMM over the 256 CUs.  A CU streams ~25 GB/s whatever runs on it, so the launch is as long as its busiest CU: 296 four-wave blocks
+// (gate_up at WN = 4) take two block rounds for 1.16 rounds of work -- 63 us where 237 five-pair blocks take 46 (tools/bench_gemm.py stream, profiles/r04_stream_sweep.txt).
+// Pick the column-group width WN (n-tile slots per block = waves) and the K split that minimise   rounds x (W bytes + 0.5 X bytes per block) + slab bytes / 256
+// under: whole K steps per block, >= 6 steps per block when K is split (the pipeline is NB - 1 steps deep), slabs within the workspace.
+struct StreamPlan { int wn, ksplit; };
+static StreamPlan stream_plan(const GemmArgs& a, int NT, int MT, int KSB, bool can_split) {
+    const int KT = a.K >> 5, ntiles = a.N >> 4;
+    StreamPlan best{4, 1}; double best_cost = 1e30;
+    for (int wn = 4; wn <= 8; ++wn) {
+        const int bx = cdiv(ntiles, wn * NT);
+        for (int ks = 1; ks <= (can_split ? 16 : 1); ++ks) {
+            const int ktper = (int)round_up(cdiv(KT, ks), KSB);
+            if (cdiv(KT, ktper) != ks) continue;                                            // (this split count rounds to another one)
+            if (ks > 1 && ktper < 6 * KSB) break;
+            if (ks > 1 && (size_t)ks * a.M * a.N * sizeof(float) > a.splitk_ws_bytes) break;
+            const int rounds = cdiv((long long)bx * ks, 256);
+            const double wb = (double)wn * NT * ktper * 1024, xb = (double)MT * 16 * ktper * 64;
+            const double slab = can_split ? (double)ks * a.M * a.N * 8.0 / 256.0 : 0.0;
+            const double cost = rounds * (wb + 0.5 * xb) + slab;
+            if (cost < best_cost * 0.999) { best_cost = cost; best = StreamPlan{wn, ks}; }
+        }
+    }
+    return best;
+}
+template <int MT, int NT, int WK, int KS, int NB>
+static hipError_t launch_stream_wn(const GemmP& p, const GemmArgs& a, hipStream_t st) {
+    const StreamPlan pl = stream_plan(a, NT, MT, WK * KS, a.slabs_out != nullptr || (a.epi != EPI_SWIGLU && a.splitk_ws != nullptr));
+    switch (pl.wn) {
+        case 5: return launch_stream_t<MT, NT, WK, KS, NB, 0, 5>(p, a, st, pl.ksplit);
+        case 6: return launch_stream_t<MT, NT, WK, KS, NB, 0, 6>(p, a, st, pl.ksplit);
+        case 7: return launch_stream_t<MT, NT, WK, KS, NB, 0, 7>(p, a, st, pl.ksplit);
+        case 8: return launch_stream_t<MT, NT, WK, KS, NB, 0, 8>(p, a, st, pl.ksplit);
+        default: return launch_stream_t<MT, NT, WK, KS, NB, 0, 4>(p, a, st, pl.ksplit);
+    }
+}
+static hipError_t launch_stream(const GemmP& p, const GemmArgs& a, hipStream_t st) {
+    const bool two = a.epi == EPI_SWIGLU || (a.N >> 4) >= 4096;
+    if (a.M <= 64) return two ? launch_stream_wn<4, 2, 1, 4, 3>(p, a, st) : launch_stream_wn<4, 1, 1, 4, 3>(p, a, st);
+    if (a.M <= 128) return two ? launch_stream_wn<8, 2, 1, 2, 4>(p, a, st) : launch_stream_wn<8, 1, 1, 4, 3>(p, a, st);
+    if (two) return hipErrorInvalidValue;          // (16 m-tiles x 2 n-tiles of accumulators do not fit beside the W buffers without scratch: stream_ok keeps such shapes out)
+    return launch_stream_wn<16, 1, 1, 2, 4>(p, a, st);
 }
 
 template <int MT>
@@ -1102,6 +1378,33 @@ static hipError_t launch_t(const GemmArgs& a, hipStream_t st, int* kind_out) {
     bool large = (variant == GEMM_LARGE) || (variant == GEMM_AUTO && a.M >= 256 && a.N >= 128);
     if (kind_out) *kind_out = skinny ? MMD_K_GEMM_SKINNY : MMD_K_GEMM_TILE;
     if constexpr (sizeof(T) == 2) {
+        // the weight-streaming regime above the GEMV's 16 rows: per-frame steps, short chunks (gemm_stream_kernel); slab consumers or the SwiGLU epilogue
+        if ((variant == GEMM_AUTO || variant == GEMM_SKINNY || variant == GEMM_STREAM) && stream_ok(MMD_BF16, a)) {
+            p.W = a.Wp;
+            if (kind_out) *kind_out = MMD_K_GEMM_SKINNY;
+            return launch_stream(p, a, st);
+        }
+        if (variant == GEMM_STREAM) return hipErrorInvalidValue;
+#ifdef MMDUET_DEBUG_VARIANTS          // tools/bench_gemm.py stream: configuration sweep of gemm_stream_kernel at M <= 64 (`make DEBUG_VARIANTS=1`; never in the shipped library)
+        if (variant >= 300 && variant < 340 && a.M <= 64 && a.Wp) {
+            p.W = a.Wp; p.slabs = a.epi == EPI_SWIGLU ? 0 : 1;
+            GemmArgs b = a; int dummy = 0; if (a.epi != EPI_SWIGLU) { b.slabs_out = &dummy; b.epi = EPI_NONE; p.epi = EPI_NONE; }
+            const bool two = a.epi == EPI_SWIGLU;
+#define SCFG(id, WK_, KS_, NB_, DBG_) case id: return two ? launch_stream_t<4, 2, WK_, KS_, NB_, DBG_>(p, b, st) : launch_stream_t<4, 1, WK_, KS_, NB_, DBG_>(p, b, st);
+            switch (variant - 300) {
+                SCFG(0, 2, 2, 4, 0) SCFG(1, 1, 4, 3, 0) SCFG(2, 4, 1, 4, 0) SCFG(3, 2, 4, 3, 0) SCFG(4, 1, 4, 4, 0) SCFG(5, 4, 2, 3, 0) SCFG(7, 2, 2, 6, 0)
+                SCFG(10, 2, 2, 4, 1) SCFG(11, 1, 4, 3, 1) SCFG(12, 2, 2, 4, 2) SCFG(13, 1, 4, 3, 2)
+                // balanced decompositions: 5 pairs per block (gate_up: 237 blocks), 7 n-tiles x 8 K chunks (down / o: 256 blocks)
+                case 20: return two ? launch_stream_t<4, 2, 2, 2, 4, 0, 5>(p, b, st) : launch_stream_t<4, 1, 2, 2, 4, 0, 7>(p, b, st, 8);
+                case 21: return two ? launch_stream_t<4, 2, 3, 2, 3, 0, 5>(p, b, st) : launch_stream_t<4, 1, 2, 2, 4, 0, 7>(p, b, st, 4);
+                case 22: return two ? launch_stream_t<4, 2, 2, 2, 4, 1, 5>(p, b, st) : launch_stream_t<4, 1, 2, 2, 4, 1, 7>(p, b, st, 8);
+                case 23: return two ? launch_stream_t<4, 2, 1, 4, 3, 0, 5>(p, b, st) : launch_stream_t<4, 1, 1, 4, 3, 0, 7>(p, b, st, 8);
+                case 24: return two ? launch_stream_t<4, 2, 2, 2, 4, 0, 8>(p, b, st) : launch_stream_t<4, 1, 2, 2, 4, 0, 7>(p, b, st, 16);
+                default: return hipErrorInvalidValue;
+            }
+#undef SCFG
+        }
+#endif
         // 256^2 tiles pay once there are ~1.5 block waves of them (every ViT / projector GEMM, gate_up of a >= 600-row chunk)
         if (variant == GEMM_RING256 || (variant == GEMM_AUTO && a.M >= 512 && (a.N % 32) == 0 && big_packed_ok(MMD_BF16, a, 16) && ring_size_ok(a) &&
                                         ring_tiles_ok((long long)cdiv(a.M, 256) * cdiv(a.N, 256)) && !getenv("MMDUET_NO_RING256"))) {
@@ -1247,7 +1550,11 @@ static hipError_t launch_t(const GemmArgs& a, hipStream_t st, int* kind_out) {
     return hipGetLastError();
 }
 
-bool gemm_can_slab(int dtype, const GemmArgs& a) { return skinny_packed_ok(dtype, a) && a.splitk_ws != nullptr && a.epi != EPI_SWIGLU; }
+bool gemm_can_slab(int dtype, const GemmArgs& a) {
+    if (skinny_packed_ok(dtype, a) && a.splitk_ws != nullptr && a.epi != EPI_SWIGLU) return true;
+    int dummy = 0; GemmArgs b = a; b.slabs_out = &dummy; b.epi = EPI_NONE;
+    return stream_ok(dtype, b);          // 64 < M <= 256: gemm_stream_kernel leaves slabs too
+}
 
 hipError_t launch_gemm(int dtype, const GemmArgs& a, hipStream_t st, int* kind_out) {
     if (dtype == MMD_F16) { GemmArgs h = a; h.f16 = 1; return launch_t<bf16_t>(h, st, kind_out); }          // 2-byte storage either way; the kernels' F16 forms read the bits as IEEE half

@@ -177,7 +177,7 @@ static int gemm(mmd_ctx* c, const void* X, int64_t ldx, const void* W, int64_t l
     a.splitk_ws = tower ? c->v_splitk_ws : c->splitk_ws; a.splitk_ws_bytes = tower ? c->v_splitk_bytes : c->splitk_bytes;
     a.plan_out = c->last_plan;
     if (tower && c->tower_ring_flags >= 0) { a.ring_flags = c->tower_ring_flags; a.ring_max_blocks = c->tower_ring_blocks; }
-    int kind = (variant == GEMM_SKINNY || (variant != GEMM_BIG && variant != GEMM_RING256 && variant != GEMM_RING256_SPLIT && variant < GEMM_RINGX && variant != GEMM_LARGE && variant != GEMM_GENERIC && M <= 64)) ? MMD_K_GEMM_SKINNY : MMD_K_GEMM_TILE;
+    int kind = (variant == GEMM_SKINNY || (variant != GEMM_BIG && variant != GEMM_RING256 && variant != GEMM_RING256_SPLIT && variant < GEMM_RINGX && variant != GEMM_LARGE && variant != GEMM_GENERIC && (M <= 64 || (M <= 256 && epi == EPI_SWIGLU)))) ? MMD_K_GEMM_SKINNY : MMD_K_GEMM_TILE;          // (64 < M <= 256: gate_up runs on the streaming kernel)
     double e = (double)es(c);
     double bytes = (double)M * K * e + (double)N * K * ((Wp8 && M <= 64) ? 1.0 : e) + (double)M * (epi == EPI_SWIGLU ? N / 2 : N) * (out_f32 ? 4.0 : e);
     ProfScope ps(c, kind, bytes, 2.0 * M * N * K);
@@ -1168,11 +1168,11 @@ static int llm_step_segs(mmd_ctx* c, const StepSeg* segs, int nseg, const void* 
     if (embeds != c->l_h) HIPCHK(c, hipMemcpyAsync(c->l_h, embeds, (size_t)S * H * e, hipMemcpyDeviceToDevice, st));
     const size_t layer_elems = kv_layer_elems(c, s->cap);
 
-    // Fused schedule for the weight-streaming regime (S <= 64, packed bf16 weights): the skinny GEMMs leave fp32 split-K
+    // Fused schedule for the weight-streaming regime (S <= 256, packed bf16 weights): the skinny / streaming GEMMs leave fp32 split-K
     // slabs and the NEXT operator consumes them (reduce + bias + RoPE + KV append; reduce + residual + RMSNorm):
     // 9 launches per layer instead of 12, identical rounding points.
     bool fused = false;
-    if (nseg == 1 && dt == MMD_BF16 && S <= 64 && H <= 4096 && (H & 3) == 0 && !c->no_fuse) {
+    if (nseg == 1 && dt == MMD_BF16 && S <= 256 && H <= 4096 && (H & 3) == 0 && !c->no_fuse) {          // (S > 64: gemm_stream_kernel's slabs -- gemm_can_slab says whether the shapes qualify)
         GemmArgs probe; memset(&probe, 0, sizeof(probe));
         probe.X = c->l_xn; probe.ldx = H; probe.Wp = c->L[0].wqkv_p; probe.M = S; probe.N = c->qkv_w; probe.K = H; probe.epi = EPI_NONE;
         probe.splitk_ws = c->splitk_ws; probe.splitk_ws_bytes = c->splitk_bytes;
@@ -1549,10 +1549,28 @@ extern "C" int mmd_op_gemm(mmd_ctx* c, const void* X, const void* W, const void*
     int NO = epi == EPI_SWIGLU ? N / 2 : N;
     void* Wp = nullptr;
     // the model holds every matrix in both layouts (or packed only): give the dispatcher the same choice, variant 0 included
-    if (variant == GEMM_AUTO || variant == GEMM_SKINNY || variant == GEMM_BIG || variant == GEMM_RING256 || variant == GEMM_RING256_SPLIT || variant >= GEMM_RINGX) { int rc = make_packed(c, W, N, K, &Wp); if (rc) return rc; }
+    if (variant == GEMM_AUTO || variant == GEMM_SKINNY || variant == GEMM_BIG || variant == GEMM_RING256 || variant == GEMM_RING256_SPLIT || variant == GEMM_STREAM || variant >= GEMM_RINGX) { int rc = make_packed(c, W, N, K, &Wp); if (rc) return rc; }
     int rc = gemm(c, X, K, W, K, bias, R, NO, Y, NO, M, N, K, epi, out_f32, variant, Wp);
     if (Wp) { hipStreamSynchronize(c->stream); dev_free(c, Wp); }
     return rc;
+}
+// the weight-streaming kernels in slab mode (what the fused LLM schedule launches): X [M,K] . W [N,K]^T as `*splits_out` fp32 partial slabs [splits][M][N] in
+// slabs_out (device, room for max_splits); variant GEMM_SKINNY (auto by M: gemv16 / skinny / stream) or GEMM_STREAM
+extern "C" int mmd_op_gemm_slabs(mmd_ctx* c, const void* X, const void* W, int M, int N, int K, int variant, float* slabs_out, int max_splits, int* splits_out) {
+    if (!c || !X || !W || !slabs_out || !splits_out || max_splits < 1) return MMD_EINVAL;
+    hipSetDevice(c->device);
+    void* Wp = nullptr;
+    int rc = make_packed(c, W, N, K, &Wp); if (rc) return rc;
+    GemmArgs g; memset(&g, 0, sizeof(g));
+    int splits = 0;
+    g.X = X; g.ldx = K; g.Wp = Wp; g.M = M; g.N = N; g.K = K; g.epi = EPI_NONE; g.variant = variant;
+    g.splitk_ws = slabs_out; g.splitk_ws_bytes = (size_t)max_splits * M * N * sizeof(float); g.slabs_out = &splits; g.plan_out = c->last_plan;
+    hipError_t e = launch_gemm(c->cfg.dtype, g, c->stream, nullptr);
+    hipStreamSynchronize(c->stream);
+    dev_free(c, Wp);
+    if (e != hipSuccess) FAIL(c, MMD_EHIP, "slab GEMM launch failed: %s", hipGetErrorString(e));
+    *splits_out = splits;
+    return MMD_OK;
 }
 extern "C" int mmd_op_quantize_fp8(mmd_ctx* c, void* W, int N, int K, uint8_t* q8_out, float* scale_out) {
     if (!c || !W || !q8_out || !scale_out) return MMD_EINVAL;

@@ -28,6 +28,17 @@ class RawOps:
         torch.cuda.synchronize()
         return Y
 
+    def gemm_slabs(self, X, W, variant=2, max_splits=16):
+        """-> (sum of the fp32 partial slabs [M, N], number of slabs)"""
+        M, K = X.shape; N = W.shape[0]
+        Xd, Wd = self.t(X), self.t(W)
+        slabs = torch.zeros(max_splits, M, N, device=self.dev, dtype=torch.float32)
+        n = C.c_int(0)
+        self.m._bind_stream()
+        check(lib().mmd_op_gemm_slabs(self.ctx, _ptr(Xd), _ptr(Wd), M, N, K, variant, _ptr(slabs), max_splits, C.byref(n)), self.ctx, 'gemm_slabs')
+        torch.cuda.synchronize()
+        return slabs[:max(1, n.value)].sum(0), n.value
+
     def rmsnorm(self, x, w, eps):
         xd, wd = self.t(x), self.t(w)
         y = torch.empty_like(xd); self.m._bind_stream()

@@ -259,3 +259,72 @@ def test_preprocess_bit_exact_with_pillow(ops):
             assert torch.equal(pv.cpu(), ref), (pv.cpu() - ref).abs().max()
         else:
             assert torch.equal(pv.cpu(), ref.to(torch.bfloat16))
+
+
+# ---- gemm_stream_kernel: the weight-streaming GEMM of the 32 < M <= 256 regime (round 4) --------------------------------------------------------------
+@pytest.mark.parametrize('M', [33, 49, 53, 64, 75, 98, 128, 147, 196, 245, 256])
+@pytest.mark.parametrize('N,K', [(4608, 3584), (3584, 3584), (3584, 18944), (160, 256), (1152, 384)])
+def test_stream_gemm_slabs_equal_fp32_math(M, N, K):
+    """Slab mode (the fused LLM schedule's qkv / o_proj / down_proj at per-frame and short-chunk sizes): the fp32 partial slabs of gemm_stream_kernel must SUM to
+    X . W^T in fp32 arithmetic -- tolerance 2e-5 x |ref|max x sqrt(K / 3584) (accumulation order only: the products are exact, nothing is rounded to bf16 here).
+    Covers every instantiation (M <= 64 / 128 / 256), K splits with a shorter last block, n-tile tails (N = 160: 10 n-tiles over 4-wave groups) and rows beyond M."""
+    import math
+    from rawops import RawOps
+    ops = RawOps(torch.bfloat16)
+    g = torch.Generator(device=ops.dev).manual_seed(M * 7 + N + K)
+    X = (torch.randn(M, K, generator=g, device=ops.dev) * 0.7).to(torch.bfloat16)
+    W = (torch.randn(N, K, generator=g, device=ops.dev) / math.sqrt(K)).to(torch.bfloat16)
+    Y, n = ops.gemm_slabs(X, W, variant=8)
+    import ctypes as C
+    from mmduet_amd._lib import lib
+    plan = (C.c_int * 4)(); lib().mmd_op_gemm_last_plan(ops.ctx, plan)
+    assert plan[0] == 8, list(plan)                         # GEMM_K_STREAM really ran
+    ref = X.double() @ W.double().T
+    err = (Y.double() - ref).abs().max().item() / max(1.0, ref.abs().max().item())
+    assert n >= 1 and err <= 2e-5 * max(1.0, math.sqrt(K / 3584)), (M, N, K, n, err)
+
+
+@pytest.mark.parametrize('M', [33, 49, 64, 98, 128])
+def test_stream_gemm_swiglu_matches_fp32_and_is_deterministic(M):
+    """gate_up at the true width through gemm_stream_kernel's SwiGLU epilogue (no K split): bf16 bound against fp32 math, identical bits on repetition."""
+    import math
+    import torch.nn.functional as F
+    from rawops import RawOps
+    ops = RawOps(torch.bfloat16)
+    N, K = 37888, 3584
+    g = torch.Generator(device=ops.dev).manual_seed(M)
+    X = (torch.randn(M, K, generator=g, device=ops.dev) * 0.7).to(torch.bfloat16)
+    W = (torch.randn(N, K, generator=g, device=ops.dev) / math.sqrt(K)).to(torch.bfloat16)
+    gate, up = W[:N // 2], W[N // 2:]
+    Wi = torch.stack([gate.view(-1, 16, K), up.view(-1, 16, K)], 1).reshape(N, K).contiguous()
+    Y = ops.gemm(X, Wi, None, epi='swiglu', variant=8)
+    Xf = X.float()
+    ref = F.silu((Xf @ gate.float().T).to(torch.bfloat16).float()).to(torch.bfloat16).float() * (Xf @ up.float().T).to(torch.bfloat16).float()
+    err = (Y.float() - ref).abs().max().item() / max(1.0, ref.abs().max().item())
+    assert err <= 2.4e-2, err
+    assert torch.equal(Y, ops.gemm(X, Wi, None, epi='swiglu', variant=8))
+
+
+@pytest.mark.parametrize('M', [49, 75, 130, 256])
+@pytest.mark.parametrize('N,K,epi', [(4608, 3584, 'none'), (3584, 18944, 'resid'), (1152, 1152, 'gelu_tanh')])
+def test_stream_gemm_with_the_epilogue_in_place(M, N, K, epi):
+    """The unfused form (several streams per forward, MMDUET_NO_FUSE): gemm_stream_kernel's slabs + the serial reduce with bias / residual / activation -- the bf16 bound
+    against fp32 math, and the dispatcher really took the streaming kernel."""
+    import math, ctypes as C
+    import torch.nn.functional as F
+    from oracle import duet_oracle as O
+    from rawops import RawOps
+    from mmduet_amd._lib import lib
+    ops = RawOps(torch.bfloat16)
+    g = torch.Generator(device=ops.dev).manual_seed(M + N)
+    X = (torch.randn(M, K, generator=g, device=ops.dev) * 0.7).to(torch.bfloat16)
+    W = (torch.randn(N, K, generator=g, device=ops.dev) / math.sqrt(K)).to(torch.bfloat16)
+    b = (0.1 * torch.randn(N, generator=g, device=ops.dev)).to(torch.bfloat16)
+    R = torch.randn(M, N, generator=g, device=ops.dev).to(torch.bfloat16) if epi == 'resid' else None
+    Y = ops.gemm(X, W, b, R=R, epi=epi, variant=0)
+    plan = (C.c_int * 4)(); lib().mmd_op_gemm_last_plan(ops.ctx, plan)
+    assert plan[0] == 8, list(plan)
+    lin = F.linear(X.float(), W.float(), b.float())
+    ref = lin.to(torch.bfloat16).float() + R.float() if epi == 'resid' else (O.gelu_tanh(lin.to(torch.bfloat16).float()) if epi == 'gelu_tanh' else lin)
+    err = (Y.float() - ref).abs().max().item() / max(1.0, ref.abs().max().item())
+    assert err <= 2.4e-2, err

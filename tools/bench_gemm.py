@@ -133,6 +133,22 @@ if __name__ == '__main__':
         if len(sys.argv) > 2:
             json.dump(dict(note='tools/bench_gemm.py llm: weight-streaming kernels, random operands; GB/s = algorithmic bytes (weights at their stored width + activations) / time', rows=rows),
                       open(sys.argv[2], 'w'), indent=1)
+    if which == 'stream':      # gemm_stream_kernel configuration sweep (DEBUG_VARIANTS build): python tools/bench_gemm.py stream [M]
+        import statistics
+        M = int(sys.argv[2]) if len(sys.argv) > 2 else 49
+        cfgs = {2: 'skinny (shipped r03)', 300: 'WK2 KS2 NB4', 301: 'WK1 KS4 NB3', 302: 'WK4 KS1 NB4', 303: 'WK2 KS4 NB3', 304: 'WK1 KS4 NB4', 305: 'WK4 KS2 NB3', 307: 'WK2 KS2 NB6',
+                320: 'WN5 / WN7x8 WK2 KS2 NB4', 321: 'WN5 WK3 / WN7x4', 322: 'DBG W only WN5 / WN7x8', 323: 'WN5 / WN7x8 WK1 KS4 NB3', 324: 'WN8 / WN7x16',
+                310: 'DBG W only WK2', 311: 'DBG W only WK1', 312: 'DBG no W WK2', 313: 'DBG no W WK1'}
+        for name, N, K, epi in LLM[:4]:
+            t = {v: [] for v in cfgs}
+            for r in range(5):
+                for v in cfgs:
+                    vv = v if v != 2 else (2 if epi == 'swiglu' else 5)
+                    try: t[v].append(run(ops, M, N, K, epi, vv, iters=8))
+                    except Exception as e: t[v].append(float('nan'))
+            for v, nm in cfgs.items():
+                med = statistics.median(t[v]); gb = N * K * 2 / 1e9
+                print(f'STREAM M={M:4d} {name:8s} {nm:22s} median {med*1e3:8.1f} us   {gb/med*1e3:7.0f} GB/s of weights   {run.plan if v == 300 else ""}', flush=True)
     if which == 'square':       # the guide's reference shapes (4096^3, 8192^3): where does the ring stand against its 256^2 8-phase template (1.33 / 1.47 PF, random operands)?
         for n in (2048, 4096, 8192):
             for variant, vn in ((32, 'rx-8w-early'), (40, 'rx-8w-ns4-early'), (4, 'big')):
