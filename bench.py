@@ -181,7 +181,8 @@ def parse(argv=None):
     p.add_argument('--no-overlap', action='store_true', help='run the vision tower and the LLM steps on one stream')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-parity-check', action='store_true', help='skip the post-timing oracle check of a stream prefix (resp_head_logit_delta.measured_in_run)')
-    p.add_argument('--prof-stride', type=int, default=7, help='bracket every n-th launch of the dominant kernel class with HIP events')
+    p.add_argument('--prof-stride', type=int, default=31, help='bracket every n-th launch of the dominant kernel class with HIP events inside the timed region (round 4: 7 -> 31 -- the event pairs, not the kernels, '
+                   'kept a runtime thread 75 %% busy: 0.65 CPU s per 0.85 s step and -2 %% frames/s, profiles/r04_host_thread_probe.txt)')
     p.add_argument('--no-prof', action='store_true', help='do not bracket the dominant kernel with HIP events in the timed region')
     p.add_argument('--multi-stream', type=int, default=4, help='also measure S streams per GPU in shared forwards (reported under "multi_stream"; never the headline value; 0 = skip)')
     p.add_argument('--multi-frames-per-forward', type=int, default=13)
