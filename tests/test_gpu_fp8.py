@@ -257,7 +257,7 @@ def test_fp8_model_at_7b_width_chunk_and_decode_rows():
     try:
         import json, os
         from conftest import ROOT
-        path = os.path.join(ROOT, 'gpurun_out', 'parity_r03.json')
+        path = os.path.join(ROOT, 'gpurun_out', 'parity_r04.json')
         cur = json.load(open(path)) if os.path.exists(path) else {}
         cur['fp8_true_width_2_layers'] = dict(chunk_vs_fp32=e_chunk, per_frame_vs_fp32=e_per, chunk_vs_per_frame=e_cp, decode_rows_head_vs_fp32=e_dec, decode_rows_lm_vs_fp32=e_lm,
                                               lm_scale=r.logits.abs().max().item())

@@ -26,7 +26,7 @@ def _record(key, **vals):
     try:
         d = os.path.join(ROOT, 'gpurun_out')
         os.makedirs(d, exist_ok=True)
-        path = os.path.join(d, 'parity_r03.json')
+        path = os.path.join(d, 'parity_r04.json')
         cur = json.load(open(path)) if os.path.exists(path) else {}
         cur[key] = RESULTS[key]
         json.dump(cur, open(path, 'w'), indent=1, sort_keys=True)
