@@ -1222,7 +1222,9 @@ static hipError_t launch_ringx_t(const GemmP& p, const GemmArgs& a, hipStream_t 
     constexpr int BN = 64 * WN;
     const int tiles = cdiv(a.N, BN) * cdiv(a.M, 256);
     const int slots = (WN == 2 && NS == 3) ? 512 : 256;                      // resident blocks: two 4-wave blocks per CU (72 KB rings), else one
-    const int cap = a.ring_max_blocks > 0 && a.ring_max_blocks < slots ? a.ring_max_blocks : slots;
+    // ring_max_blocks: > 0 caps the persistent grid (tower share); < 0 (overlap experiments, MMDUET_TOWER_RING_BLOCKS=-1): NON-persistent, one tile per block, so that the
+    // dispatcher can place another stream's blocks at every tile end
+    const int cap = a.ring_max_blocks < 0 ? tiles : (a.ring_max_blocks > 0 && a.ring_max_blocks < slots ? a.ring_max_blocks : slots);
     dim3 grid(splits > 1 || tiles <= cap ? tiles : cap, 1, splits);
     set_plan(a, WN == 2 ? GEMM_K_RING128X2 : GEMM_K_RING256, tiles, splits, (int)grid.x * splits);
     const int KT = a.K >> 5;

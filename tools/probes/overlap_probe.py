@@ -8,7 +8,7 @@ import bench
 
 def main():
     nb = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-    args = bench.parse(['--frames', '300'])
+    args = bench.parse(['--frames', '300', '--tower-dtype', os.environ.get('OVERLAP_TOWER_DTYPE', 'auto')])
     dev = torch.device('cuda:0')
     model, tok, cfg = bench.build(args, dev)
     from mmduet_amd.modeling_live import fast_greedy_generate
@@ -25,8 +25,17 @@ def main():
     side = torch.cuda.Stream(device=dev, priority=lo)
     vout = torch.empty(35 * 49, H, dtype=torch.bfloat16, device=dev)
 
+    # OVERLAP_DECODE_PRIO=-1: the decode loop runs on a HIGH-priority stream (torch's default stream and the tower's `lo` are both priority 0)
+    dprio = os.environ.get('OVERLAP_DECODE_PRIO')
+    dstream = torch.cuda.Stream(device=dev, priority=int(dprio)) if dprio is not None else None
+
     def decode():
-        fast_greedy_generate(model=model, inputs_embeds=prompt, past_key_values=cache, eos_token_id=-1, inplace_output_ids=out_ids)
+        if dstream is None:
+            fast_greedy_generate(model=model, inputs_embeds=prompt, past_key_values=cache, eos_token_id=-1, inplace_output_ids=out_ids)
+            return
+        dstream.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(dstream):
+            fast_greedy_generate(model=model, inputs_embeds=prompt, past_key_values=cache, eos_token_id=-1, inplace_output_ids=out_ids)
 
     def tower(n):
         with torch.cuda.stream(side):
