@@ -827,30 +827,34 @@ __global__ __launch_bounds__(64 * WN * WK) void gemm_stream_kernel(GemmP p, int 
             }
         return;
     }
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        const int m = i * 16 + lr;
-        if (p.epi == EPI_SWIGLU) {
-            if constexpr (NT >= 2) {
+    // (the row loops below are compile-time recursions, not `#pragma unroll`: at MT = 16 the unrolled epilogue passes hipcc's pragma-unroll size limit, the loop stays rolled and `acc` moves to scratch for the whole kernel)
+    if (p.epi == EPI_SWIGLU) {
+        if constexpr (NT >= 2) {
+            stream_static_for<MT>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                const int m = i * 16 + lr;
 #pragma unroll
                 for (int j = 0; j < NT; j += 2) {
-                    if (nt0 + j + 1 < ntiles) {
-                        float g[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                        float u[4] = {acc[i][j + 1][0], acc[i][j + 1][1], acc[i][j + 1][2], acc[i][j + 1][3]};
-                        store4_swiglu<bf16_t>(p, m, (nt0 + j) * 16 + lq * 4, g, u);
+                    if (m < p.M && nt0 + j + 1 < ntiles) {
+                        const int n_gate = (nt0 + j) * 16 + lq * 4;
+                        *reinterpret_cast<s16x4_t*>((bf16_t*)p.Y + (long long)m * p.ldy + (n_gate >> 5) * 16 + (n_gate & 15)) = big_value_swiglu(acc[i][j], acc[i][j + 1], p.wscale, n_gate);
                     }
                 }
-            }
-        } else {
+            });
+        }
+        return;
+    }
+    stream_static_for<MT>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const int m = i * 16 + lr;
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                if (nt0 + j < ntiles) {
-                    float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                    store4<bf16_t>(p, m, (nt0 + j) * 16 + lq * 4, v);
-                }
+        for (int j = 0; j < NT; ++j) {
+            if (nt0 + j < ntiles) {
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                store4<bf16_t>(p, m, (nt0 + j) * 16 + lq * 4, v);
             }
         }
-    }
+    });
 }
 
 static inline void set_plan(const GemmArgs& a, int kernel, int tiles, int splits, int blocks) {
@@ -902,8 +906,7 @@ static bool stream_ok(int dtype, const GemmArgs& a) {
     if ((long long)a.M * a.ldx * 2 >= (1ll << 32)) return false;            // X addressed as base + 32-bit offset
     const int ksb = a.M <= 128 ? 4 : 2;          // k-tiles per step of the instantiation that serves this M
     if ((a.K % (ksb * 32)) != 0) return false;
-    if (a.epi == EPI_SWIGLU) return (a.N % 32) == 0 && !a.slabs_out && a.M <= 128;
-    if ((a.N >> 4) >= 4096 && a.M > 128) return false;
+    if (a.epi == EPI_SWIGLU) return (a.N % 32) == 0 && !a.slabs_out;
     if (a.slabs_out) return a.splitk_ws != nullptr && a.epi == EPI_NONE;
     // epilogue in place (unfused schedule, several streams per forward): the same K split into the workspace, then the serial slab reduce applies bias / residual / activation --
     // slab for slab what the fused consumers do, so both schedules produce the same bits
@@ -979,8 +982,7 @@ static hipError_t launch_stream(const GemmP& p, const GemmArgs& a, hipStream_t s
     const bool two = a.epi == EPI_SWIGLU || (a.N >> 4) >= 4096;
     if (a.M <= 64) return two ? launch_stream_wn<4, 2, 1, 4, 3>(p, a, st) : launch_stream_wn<4, 1, 1, 4, 3>(p, a, st);
     if (a.M <= 128) return two ? launch_stream_wn<8, 2, 1, 2, 4>(p, a, st) : launch_stream_wn<8, 1, 1, 4, 3>(p, a, st);
-    if (two) return hipErrorInvalidValue;          // (16 m-tiles x 2 n-tiles of accumulators do not fit beside the W buffers without scratch: stream_ok keeps such shapes out)
-    return launch_stream_wn<16, 1, 1, 2, 4>(p, a, st);
+    return two ? launch_stream_wn<16, 2, 1, 1, 4>(p, a, st) : launch_stream_wn<16, 1, 1, 2, 4>(p, a, st);
 }
 
 template <int MT>

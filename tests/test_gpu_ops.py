@@ -284,7 +284,7 @@ def test_stream_gemm_slabs_equal_fp32_math(M, N, K):
     assert n >= 1 and err <= 2e-5 * max(1.0, math.sqrt(K / 3584)), (M, N, K, n, err)
 
 
-@pytest.mark.parametrize('M', [33, 49, 64, 98, 128])
+@pytest.mark.parametrize('M', [33, 49, 64, 98, 128, 147, 196, 256])
 def test_stream_gemm_swiglu_matches_fp32_and_is_deterministic(M):
     """gate_up at the true width through gemm_stream_kernel's SwiGLU epilogue (no K split): bf16 bound against fp32 math, identical bits on repetition."""
     import math
