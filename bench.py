@@ -28,7 +28,7 @@ import torch
 
 HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_BF16_PEAK_TF = 2500.0      # dense bf16 MFMA peak
-PMC_TRAFFIC = ('profiles/r03_pmc_traffic.json', 'profiles/r02_pmc_traffic.json', 'profiles/r01_pmc_traffic.json')      # newest first
+PMC_TRAFFIC = ('profiles/r04_pmc_traffic.json', 'profiles/r03_pmc_traffic.json', 'profiles/r02_pmc_traffic.json', 'profiles/r01_pmc_traffic.json')      # newest first
 
 CONFIGS = {
     # name: (frames, responses, frames_per_forward, streams_per_gpu, workload text)
@@ -188,7 +188,7 @@ def parse(argv=None):
     p.add_argument('--multi-frames-per-forward', type=int, default=13)
     p.add_argument('--weights', choices=['bf16', 'fp8'], default=None, help='fp8 = e4m3 per-output-channel scaled LLM weights (BASELINE configs[4]); reported with dtype fp8, never the bf16 headline')
     p.add_argument('--phase', choices=['ab', 'b'], default='ab', help="'b': Phase B alone -- the frame embeddings come from a feature file written before the timed region (mmduet_amd/features.py); LLM-only frames/s, never the headline")
-    p.add_argument('--tower-dtype', choices=['auto', 'bf16', 'fp16'], default='auto', help="vision tower arithmetic: fp16 = the reference's torch.cuda.amp.autocast() tower (models/modeling_live.py:28), bf16 = the model dtype; auto = the product default")
+    p.add_argument('--tower-dtype', choices=['auto', 'bf16', 'fp16', 'fp16_resid16'], default='auto', help="vision tower arithmetic: fp16 = the reference's torch.cuda.amp.autocast() tower (models/modeling_live.py:28), bf16 = the model dtype; auto = the product default")
     p.add_argument('--host-sync', choices=['auto', 'spin', 'yield', 'blocking'], default='auto', help='how this rank waits for the GPU (hipSetDeviceFlags before the first HIP call): blocking frees the host core a spinning wait burns -- matters when 8 ranks share 16 cores')
     p.add_argument('--layers', type=int, default=None, help='debug: override LLM layer count (INVALID as a measurement)')
     a = p.parse_args(argv)

@@ -61,9 +61,10 @@ typedef struct mmd_config {
     int32_t vit_pre_layernorm;    /* CLIP: pre_layrnorm after the embeddings */
     int32_t vit_act;              /* 0 gelu_pytorch_tanh (SigLIP), 1 quick_gelu (CLIP) */
     int32_t vit_pool_head;        /* SigLIP: SiglipMultiheadAttentionPoolingHead present (pooler_output, used when frame_token_cls) */
-    int32_t tower_f16;            /* 1: the LLaVA SigLIP tower computes in IEEE half (fp16 weights / activations, fp32 accumulate, LayerNorm / softmax statistics in
-                                     fp32) and hands bf16 features to the projector -- the reference runs the tower under torch.cuda.amp.autocast()
-                                     (models/modeling_live.py:28).  bf16 contexts only; 0 = tower in the context dtype */
+    int32_t tower_f16;            /* 1: the LLaVA SigLIP tower as under torch.cuda.amp.autocast() (models/modeling_live.py:28): fp16 linears / attention matmuls
+                                     with fp32 accumulate, LayerNorm / softmax in fp32, and the hidden state between them in FP32 (`fp32 + fp16` promotes), bf16
+                                     features to the projector.  2: the same with the residual stream rounded to fp16 after every sublayer (the round-3 form,
+                                     ~2 % faster tower).  bf16 contexts only; 0 = tower in the context dtype */
 } mmd_config;
 
 typedef struct mmd_ctx mmd_ctx;

@@ -155,6 +155,8 @@ hipError_t launch_quantize_fp8_rows(void* W_bf16, int N, int K, uint8_t* q8_rowm
 hipError_t launch_pack_w8(const uint8_t* q8_rowmajor, int N, int K, void* out, hipStream_t st);
 hipError_t launch_rmsnorm(int dtype, const void* x, const void* w, void* y, int M, int H, float eps, hipStream_t st);
 hipError_t launch_layernorm(int dtype, const void* x, const void* w, const void* b, void* y, int M, int H, float eps, hipStream_t st);
+hipError_t launch_resid32_layernorm(const void* y16, float* h32, const void* pos16, int period, const void* ln_w, const void* ln_b, void* out16, void* outbf,
+                                    int M, int H, float eps, hipStream_t st);          // the autocast tower's fp32 residual stream (ops.hip)
 // fused consumers of skinny-GEMM slabs (ops.hip)
 hipError_t launch_slab_resid_rmsnorm(const float* slabs, int splits, int M, int H, const void* resid_in, void* h_out, const void* norm_w, float eps,
                                      void* xn_out, hipStream_t st, const float* wscale = nullptr);

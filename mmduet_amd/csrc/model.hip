@@ -63,6 +63,7 @@ struct mmd_ctx {
     float* inv_freq = nullptr; bool inv_freq_user = false;
     // workspaces
     void *v_col = 0, *v_h = 0, *v_xn = 0, *v_qkv = 0, *v_attn = 0, *v_mlp = 0, *v_p1 = 0, *v_p2 = 0;
+    float* v_h32 = 0; int64_t v_h32_rows = 0;          // tower_f16 == 1: the autocast tower's fp32 residual stream [Mv + compact rows of the sparse last layer, C]
     void *l_h = 0, *l_xn = 0, *l_qkv = 0, *l_q = 0, *l_attn = 0, *l_act = 0, *l_hid = 0;
     float* splitk_ws = 0; size_t splitk_bytes = 0;
     float* attn_ws = 0; size_t attn_bytes = 0;
@@ -196,6 +197,8 @@ extern "C" int mmd_create(const mmd_config* cfg, int device, mmd_ctx** out) {
     if (cfg->tower_f16 && (cfg->dtype != MMD_BF16 || cfg->vision_only || cfg->vit_class_token || cfg->vit_pre_layernorm || cfg->vit_act != 0 || cfg->vit_pool_head ||
                            (cfg->vit_hidden % 64) != 0 || ((cfg->vit_hidden / cfg->vit_heads) % 8) != 0)) {
         g_create_error = "tower_f16 needs a bf16 context and the LLaVA SigLIP tower form (no class token / pre-LN / pooling head, hidden % 64 == 0, head_dim % 8 == 0)"; return MMD_EINVAL; }
+    if (cfg->tower_f16 < 0 || cfg->tower_f16 > 2 || (cfg->tower_f16 == 1 && (cfg->vit_post_layernorm || cfg->vit_hidden > 2048))) {
+        g_create_error = "tower_f16: 0 | 1 (autocast: fp32 residual stream; no post_layernorm, hidden <= 2048) | 2 (fp16 residual stream)"; return MMD_EINVAL; }
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) { g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e); return MMD_EHIP; }
     mmd_ctx* c = new mmd_ctx();
@@ -532,6 +535,10 @@ static int alloc_workspaces(mmd_ctx* c) {
     int rc;
 #define WS(ptr, bytes) rc = dev_alloc(c, (void**)&(ptr), (bytes)); if (rc) return rc;
     WS(c->v_col, (size_t)Mv * c->vit_kpad * e); WS(c->v_h, (size_t)Mv * C * e); WS(c->v_xn, (size_t)Mv * C * e);
+    if (g.tower_f16 == 1) {
+        const int pout_ = (c->vit_grid + g.pool_stride - 1) / g.pool_stride;
+        c->v_h32_rows = Mv; WS(c->v_h32, (size_t)(Mv + (int64_t)g.max_vit_batch * 4 * pout_ * pout_) * C * sizeof(float));
+    }
     WS(c->v_qkv, (size_t)Mv * 3 * C * e); WS(c->v_attn, (size_t)Mv * C * e); WS(c->v_mlp, (size_t)Mv * c->vit_ipad * e);
     if (g.vit_class_token) { WS(c->v_patch, (size_t)Mv * C * e); }
     c->v_splitk_bytes = (size_t)32 << 20; WS(c->v_splitk_ws, c->v_splitk_bytes);
@@ -578,9 +585,17 @@ static int vit_tower(mmd_ctx* c, const void* px, int B, bool col_ready = false, 
     if (B > g.max_vit_batch) FAIL(c, MMD_ERANGE, "vit batch %d exceeds max_vit_batch %d", B, g.max_vit_batch);
     const int C = g.vit_hidden, T = c->vit_tokens, TS = c->vit_seq, M = B * TS, hd = C / g.vit_heads;
     if (!col_ready) { ProfScope ps(c, MMD_K_OTHER, 0, 0); HIPCHK(c, launch_im2col(g.tower_f16 ? MMD_F16 + 1 : dt, px, B, g.vit_image, g.vit_patch, c->vit_grid, c->vit_kpad, c->v_col, st)); }
-    void* patch_out = g.vit_class_token ? c->v_patch : c->v_h;
+    // tower_f16 == 1: the residual stream is fp32, as under autocast (`fp16 + model-dtype` and `fp32 + fp16` promote; LayerNorm returns fp32): the linears write their
+    // fp16 result (bias inside, one rounding) to v_xn and resid32_layernorm_kernel folds it into v_h32 and emits the next linear's input.  2: fp16 residual stream
+    // (the round-3 form: the sum is rounded to fp16 after every sublayer)
+    const bool r32 = g.tower_f16 == 1;
+    void* patch_out = g.vit_class_token ? c->v_patch : (r32 ? c->v_xn : c->v_h);
     int rc = gemm(c, c->v_col, c->vit_kpad, c->patch_w, c->vit_kpad, c->patch_b, nullptr, 0, patch_out, C, B * T, C, c->vit_kpad, EPI_NONE, 0, GEMM_AUTO, c->patch_w_p, true); if (rc) return rc;
-    if (g.vit_class_token) {
+    if (r32) {          // h32 = float(patch fp16) + float(position table); layer 0's LayerNorm 1 in the same pass
+        ProfScope ps(c, MMD_K_NORM_ROPE, 12.0 * M * C, 0);
+        if (g.vit_layers > 0) { HIPCHK(c, launch_resid32_layernorm(c->v_xn, c->v_h32, c->pos_emb, T, c->VL[0].ln1w, c->VL[0].ln1b, c->v_xn, nullptr, M, C, g.vit_ln_eps, st)); }
+        else { HIPCHK(c, launch_resid32_layernorm(c->v_xn, c->v_h32, c->pos_emb, T, nullptr, nullptr, nullptr, c->v_h, M, C, g.vit_ln_eps, st)); }
+    } else if (g.vit_class_token) {
         ProfScope ps(c, MMD_K_OTHER, 0, 0); HIPCHK(c, launch_assemble_cls(dt, c->v_patch, c->cls_emb, c->pos_emb, B, T, C, c->v_h, st));
     } else {
         ProfScope ps(c, MMD_K_OTHER, 0, 0); HIPCHK(c, launch_add_rows(dt, c->v_h, c->pos_emb, M, C, T, st));
@@ -598,14 +613,15 @@ static int vit_tower(mmd_ctx* c, const void* px, int B, bool col_ready = false, 
     c->tower_compact = false;
     for (int i = 0; i < g.vit_layers; ++i) {
         VitLayer& L = c->VL[i];
-        { ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * M * C * es(c), 0); HIPCHK(c, launch_layernorm(dt, c->v_h, L.ln1w, L.ln1b, c->v_xn, M, C, g.vit_ln_eps, st)); }
+        if (!r32) { ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * M * C * es(c), 0); HIPCHK(c, launch_layernorm(dt, c->v_h, L.ln1w, L.ln1b, c->v_xn, M, C, g.vit_ln_eps, st)); }
         rc = gemm(c, c->v_xn, C, L.wqkv, C, L.bqkv, nullptr, 0, c->v_qkv, 3 * C, M, 3 * C, C, EPI_NONE, 0, GEMM_AUTO, L.wqkv_p, true); if (rc) return rc;
         if (sparse_last && i + 1 == g.vit_layers) {
             const int Mc = B * U;
             void* qc = c->v_mlp; void* hc = c->v_col;          // compact queries / residual stream (v_mlp is free until fc1, the im2col matrix is dead since the patch GEMM)
             { ProfScope ps(c, MMD_K_OTHER, 0, 0);
               HIPCHK(c, launch_gather_pool_rows(dt == MMD_F32 ? MMD_F32 : MMD_BF16, c->v_qkv, qc, B, c->vit_grid, C, pout, st, 3 * C));
-              HIPCHK(c, launch_gather_pool_rows(dt == MMD_F32 ? MMD_F32 : MMD_BF16, c->v_h, hc, B, c->vit_grid, C, pout, st, C)); }
+              if (r32) { HIPCHK(c, launch_gather_pool_rows(MMD_F32, c->v_h32, c->v_h32 + c->v_h32_rows * C, B, c->vit_grid, C, pout, st, C)); }
+              else { HIPCHK(c, launch_gather_pool_rows(dt == MMD_F32 ? MMD_F32 : MMD_BF16, c->v_h, hc, B, c->vit_grid, C, pout, st, C)); } }
             {
                 AttnArgs a; memset(&a, 0, sizeof(a));
                 a.q = qc; a.ldq = C; a.K = (char*)c->v_qkv + (size_t)C * es(c); a.V = (char*)c->v_qkv + (size_t)2 * C * es(c);
@@ -615,6 +631,17 @@ static int vit_tower(mmd_ctx* c, const void* px, int B, bool col_ready = false, 
                 a.ws = c->v_attn_ws; a.ws_bytes = c->v_attn_bytes; a.variant = 0;
                 ProfScope ps(c, MMD_K_ATTN_VIT, 2.0 * (M + Mc) * C * es(c), 4.0 * B * (double)U * TS * C);
                 HIPCHK(c, launch_attention(dt, a, st));
+            }
+            if (r32) {
+                float* hc32 = c->v_h32 + c->v_h32_rows * C;
+                rc = gemm(c, c->v_attn, C, L.wo, C, L.bo, nullptr, 0, c->v_xn, C, Mc, C, C, EPI_NONE, 0, GEMM_AUTO, L.wo_p, true); if (rc) return rc;
+                { ProfScope ps(c, MMD_K_NORM_ROPE, 12.0 * Mc * C, 0); HIPCHK(c, launch_resid32_layernorm(c->v_xn, hc32, nullptr, 1, L.ln2w, L.ln2b, c->v_xn, nullptr, Mc, C, g.vit_ln_eps, st)); }
+                rc = gemm(c, c->v_xn, C, L.w1, C, L.b1, nullptr, 0, c->v_mlp, c->vit_ipad, Mc, c->vit_ipad, C, EPI_GELU_TANH, 0, GEMM_AUTO, L.w1_p, true); if (rc) return rc;
+                rc = gemm(c, c->v_mlp, c->vit_ipad, L.w2, c->vit_ipad, L.b2, nullptr, 0, c->v_xn, C, Mc, C, c->vit_ipad, EPI_NONE, 0, GEMM_AUTO, L.w2_p, true); if (rc) return rc;
+                { ProfScope ps(c, MMD_K_NORM_ROPE, 8.0 * Mc * C, 0); HIPCHK(c, launch_resid32_layernorm(c->v_xn, hc32, nullptr, 1, nullptr, nullptr, nullptr, hc, Mc, C, g.vit_ln_eps, st)); }          // -> bf16 features
+                c->tower_compact = true;
+                c->last_vit_B = B;
+                return MMD_OK;
             }
             rc = gemm(c, c->v_attn, C, L.wo, C, L.bo, hc, C, hc, C, Mc, C, C, EPI_RESID, 0, GEMM_AUTO, L.wo_p, true); if (rc) return rc;
             { ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * Mc * C * es(c), 0); HIPCHK(c, launch_layernorm(dt, hc, L.ln2w, L.ln2b, c->v_xn, Mc, C, g.vit_ln_eps, st)); }
@@ -635,6 +662,16 @@ static int vit_tower(mmd_ctx* c, const void* px, int B, bool col_ready = false, 
             ProfScope ps(c, MMD_K_ATTN_VIT, 4.0 * M * C * es(c), 4.0 * B * (double)TS * TS * C);
             HIPCHK(c, launch_attention(dt, a, st));
         }
+        if (r32) {
+            rc = gemm(c, c->v_attn, C, L.wo, C, L.bo, nullptr, 0, c->v_xn, C, M, C, C, EPI_NONE, 0, GEMM_AUTO, L.wo_p, true); if (rc) return rc;
+            { ProfScope ps(c, MMD_K_NORM_ROPE, 12.0 * M * C, 0); HIPCHK(c, launch_resid32_layernorm(c->v_xn, c->v_h32, nullptr, 1, L.ln2w, L.ln2b, c->v_xn, nullptr, M, C, g.vit_ln_eps, st)); }
+            rc = gemm(c, c->v_xn, C, L.w1, C, L.b1, nullptr, 0, c->v_mlp, c->vit_ipad, M, c->vit_ipad, C, EPI_GELU_TANH, 0, GEMM_AUTO, L.w1_p, true); if (rc) return rc;
+            rc = gemm(c, c->v_mlp, c->vit_ipad, L.w2, c->vit_ipad, L.b2, nullptr, 0, c->v_xn, C, M, C, c->vit_ipad, EPI_NONE, 0, GEMM_AUTO, L.w2_p, true); if (rc) return rc;
+            ProfScope ps(c, MMD_K_NORM_ROPE, 12.0 * M * C, 0);
+            if (i + 1 < g.vit_layers) { HIPCHK(c, launch_resid32_layernorm(c->v_xn, c->v_h32, nullptr, 1, c->VL[i + 1].ln1w, c->VL[i + 1].ln1b, c->v_xn, nullptr, M, C, g.vit_ln_eps, st)); }
+            else { HIPCHK(c, launch_resid32_layernorm(c->v_xn, c->v_h32, nullptr, 1, nullptr, nullptr, nullptr, c->v_h, M, C, g.vit_ln_eps, st)); }          // hidden_states[-1].to(bf16)
+            continue;
+        }
         rc = gemm(c, c->v_attn, C, L.wo, C, L.bo, c->v_h, C, c->v_h, C, M, C, C, EPI_RESID, 0, GEMM_AUTO, L.wo_p, true); if (rc) return rc;
         { ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * M * C * es(c), 0); HIPCHK(c, launch_layernorm(dt, c->v_h, L.ln2w, L.ln2b, c->v_xn, M, C, g.vit_ln_eps, st)); }
         if (g.vit_act == 1) {      // CLIP quick_gelu: plain fc1, then x * sigmoid(1.702 x) on the storage-rounded output (secondary path: not fused)
@@ -646,7 +683,7 @@ static int vit_tower(mmd_ctx* c, const void* px, int B, bool col_ready = false, 
         rc = gemm(c, c->v_mlp, c->vit_ipad, L.w2, c->vit_ipad, L.b2, c->v_h, C, c->v_h, C, M, C, c->vit_ipad, EPI_RESID, 0, GEMM_AUTO, L.w2_p, true); if (rc) return rc;
     }
     if (g.vit_post_layernorm) { HIPCHK(c, launch_layernorm(dt, c->v_h, c->post_w, c->post_b, c->v_h, M, C, g.vit_ln_eps, st)); }
-    if (g.tower_f16) { ProfScope ps(c, MMD_K_OTHER, 0, 0); HIPCHK(c, launch_convert(c->v_h, MMD_F16, c->v_h, MMD_BF16, (int64_t)M * C, st)); }          // in place, elementwise
+    if (g.tower_f16 && !r32) { ProfScope ps(c, MMD_K_OTHER, 0, 0); HIPCHK(c, launch_convert(c->v_h, MMD_F16, c->v_h, MMD_BF16, (int64_t)M * C, st)); }          // in place, elementwise
     c->last_vit_B = B;
     return MMD_OK;
 }

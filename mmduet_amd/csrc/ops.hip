@@ -153,6 +153,84 @@ hipError_t launch_layernorm(int dtype, const void* x, const void* w, const void*
     return hipGetLastError();
 }
 
+// The fp16 (autocast) tower's residual stream in fp32 -- models/modeling_live.py:28 runs the tower under torch.cuda.amp.autocast(): every linear returns
+// fp16 (bias inside the op), LayerNorm is on the fp32 list, and `hidden + sublayer_out` promotes to fp32, so the hidden state between the fp16 matmuls
+// is fp32.  One wave per row, the row in registers:
+//     h32[row] = (pos ? float(pos[row % period]) : h32[row]) + float(y16[row])            (patch embeddings + position table, or residual + sublayer)
+//     out16[row] = fp16(LayerNorm(h32[row]) * w + b)        when ln_w is given            (the next linear's input)
+//     outbf[row] = bf16(h32[row])                           when outbf is given           (the tower's result: hidden_states[-1].to(images.dtype))
+// y16 and out16 may be the same buffer (a row is read whole before it is written).
+__global__ __launch_bounds__(256) void resid32_layernorm_kernel(const f16_t* __restrict__ y, float* __restrict__ h, const f16_t* __restrict__ pos, int period,
+                                                                const f16_t* __restrict__ w, const f16_t* __restrict__ b, f16_t* out16, bf16_t* __restrict__ outbf,
+                                                                int M, int H, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const f16_t* yr = y + (long long)row * H;
+    float* hr = h + (long long)row * H;
+    const f16_t* pr = pos ? pos + (long long)(row % period) * H : nullptr;
+    float v[4][8];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = lane * 8 + j * 512;
+        if (c < H) {
+            const s16x8_t raw = *reinterpret_cast<const s16x8_t*>(yr + c);
+            if (pr) {
+                const s16x8_t pw = *reinterpret_cast<const s16x8_t*>(pr + c);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[j][e] = h2f((uint16_t)pw[e]) + h2f((uint16_t)raw[e]);
+            } else {
+                const f32x4_t a0 = *reinterpret_cast<const f32x4_t*>(hr + c), a1 = *reinterpret_cast<const f32x4_t*>(hr + c + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[j][e] = a0[e] + h2f((uint16_t)raw[e]); v[j][e + 4] = a1[e] + h2f((uint16_t)raw[e + 4]); }
+            }
+            if (!outbf) {
+                *reinterpret_cast<f32x4_t*>(hr + c) = f32x4_t{v[j][0], v[j][1], v[j][2], v[j][3]};
+                *reinterpret_cast<f32x4_t*>(hr + c + 4) = f32x4_t{v[j][4], v[j][5], v[j][6], v[j][7]};
+            } else {
+                s16x8_t o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (short)f2bf(v[j][e]);
+                *reinterpret_cast<s16x8_t*>(outbf + (long long)row * H + c) = o;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += v[j][e];
+        }
+    }
+    if (!w) return;
+    const float mu = wave_sum(s) / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = lane * 8 + j * 512;
+        if (c < H) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float dlt = v[j][e] - mu; q += dlt * dlt; }
+        }
+    }
+    const float inv = rsqrtf(wave_sum(q) / (float)H + eps);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = lane * 8 + j * 512;
+        if (c < H) {
+            const s16x8_t g = *reinterpret_cast<const s16x8_t*>(w + c), bb = *reinterpret_cast<const s16x8_t*>(b + c);
+            s16x8_t o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (short)f2h((v[j][e] - mu) * inv * h2f((uint16_t)g[e]) + h2f((uint16_t)bb[e]));
+            *reinterpret_cast<s16x8_t*>(out16 + (long long)row * H + c) = o;
+        }
+    }
+}
+
+hipError_t launch_resid32_layernorm(const void* y16, float* h32, const void* pos16, int period, const void* ln_w, const void* ln_b, void* out16, void* outbf,
+                                    int M, int H, float eps, hipStream_t st) {
+    if (M <= 0) return hipSuccess;
+    if ((H & 7) || H > 2048) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(resid32_layernorm_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, (const f16_t*)y16, h32, (const f16_t*)pos16, period, (const f16_t*)ln_w, (const f16_t*)ln_b,
+                       (f16_t*)out16, (bf16_t*)outbf, M, H, eps);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Fused consumers of the skinny GEMM's split-K slabs (bf16 model path).  They replace, with identical rounding points,
 //   splitk_reduce (+bias, +residual)  ->  RMSNorm          (after o_proj / down_proj)

@@ -22,6 +22,8 @@ $B --weights fp8 --steps 3 --warmup 1 --multi-stream 0 --no-cpu-baseline > $O/${
 $B --phase b --steps 3 --warmup 1 --multi-stream 0 --no-cpu-baseline > $O/${tag}_bench_phase_b.json 2>> $O/${tag}_bench.err
 $B --tower-dtype bf16 --steps 3 --warmup 1 --multi-stream 0 --no-cpu-baseline > $O/${tag}_bench_tower_bf16.json 2>> $O/${tag}_bench.err
 $B --config native336 --steps 3 > $O/${tag}_bench_native336.json 2>> $O/${tag}_bench.err
+$B --frames-per-forward 1 --steps 2 --warmup 1 --multi-stream 0 --no-cpu-baseline > $O/${tag}_bench_fpf1.json 2>> $O/${tag}_bench.err
+$B --steps 5 --warmup 1 --no-prof --multi-stream 0 --no-cpu-baseline > $O/${tag}_bench_noprof.json 2>> $O/${tag}_bench.err
 P="python3 $R/bench.py --steps 1 --warmup 0 --no-prof --no-overlap --multi-stream 0 --no-cpu-baseline"
 rm -rf $O/prof_$tag
 rocprofv3 --kernel-trace -d $O/prof_$tag -o trace -- $P > $O/${tag}_prof.log 2>&1
