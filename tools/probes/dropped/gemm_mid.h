@@ -171,9 +171,8 @@ static inline bool mid_ok(int dtype, const GemmArgs& a) {
            (a.ldy % 8) == 0 && ((uintptr_t)a.Y % 16) == 0 && (a.epi == EPI_NONE || (a.epi == EPI_RESID && (a.ldr % 4) == 0 && ((uintptr_t)a.R % 8) == 0)) &&
            (a.bias == nullptr || ((uintptr_t)a.bias % 8) == 0) && !a.slabs_out && !a.chain;
 }
-template <int TNW>
+template <int TNW, int NS = 5>
 static hipError_t launch_mid_t(const GemmP& p, const GemmArgs& a, const MidPlan& pl, hipStream_t st) {
-    constexpr int NS = 5;
     const size_t smem = (size_t)NS * (8 + 2 * TNW) * 1024;
     const void* fn = a.epi == EPI_RESID ? (const void*)gemm_mid_kernel<TNW, NS, EPI_RESID> : (const void*)gemm_mid_kernel<TNW, NS, EPI_NONE>;
     if (smem > 65536) { hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); if (e != hipSuccess) return e; }
@@ -181,7 +180,20 @@ static hipError_t launch_mid_t(const GemmP& p, const GemmArgs& a, const MidPlan&
     else hipLaunchKernelGGL((gemm_mid_kernel<TNW, NS, EPI_NONE>), dim3(pl.blocks), dim3(256), smem, st, p, a.K >> 5, pl.nbm, pl.nbn);
     return hipGetLastError();
 }
-static hipError_t launch_mid(const GemmP& p, const GemmArgs& a, hipStream_t st, int force_tnw = 0) {
+static hipError_t launch_mid(const GemmP& p, const GemmArgs& a, hipStream_t st, int force = 0) {
+    if (force >= 20) {          // 20 + 10 * (NS - 3) + TNW : small tiles, several blocks per CU
+        const int ns = 3 + (force - 20) / 10, t = (force - 20) % 10;
+        MidPlan q{t, cdiv(a.M, 128), cdiv(a.N >> 4, 2 * t), 0, 0}; q.blocks = q.nbm * q.nbn;
+        if (a.plan_out) { a.plan_out[0] = GEMM_K_MID; a.plan_out[1] = q.blocks; a.plan_out[2] = 1; a.plan_out[3] = q.blocks; }
+        if (t == 2 && ns == 3) return launch_mid_t<2, 3>(p, a, q, st);
+        if (t == 2 && ns == 4) return launch_mid_t<2, 4>(p, a, q, st);
+        if (t == 2 && ns == 5) return launch_mid_t<2, 5>(p, a, q, st);
+        if (t == 3 && ns == 3) return launch_mid_t<3, 3>(p, a, q, st);
+        if (t == 3 && ns == 4) return launch_mid_t<3, 4>(p, a, q, st);
+        if (t == 4 && ns == 3) return launch_mid_t<4, 3>(p, a, q, st);
+        return hipErrorInvalidValue;
+    }
+    const int force_tnw = force;
     const MidPlan pl = mid_plan(a, force_tnw);
     if (a.plan_out) { a.plan_out[0] = GEMM_K_MID; a.plan_out[1] = pl.nbm * pl.nbn; a.plan_out[2] = 1; a.plan_out[3] = pl.blocks; }
     switch (pl.tnw) {
