@@ -250,6 +250,11 @@ int mmd_op_gemm_w8(mmd_ctx* ctx, const void* X, const void* Wq, const uint8_t* q
 int mmd_op_gemm_bench(mmd_ctx* ctx, int M, int N, int K, int epi, int variant, int iters, float* avg_ms_out, const void* X, const void* W);
 int mmd_op_rmsnorm(mmd_ctx* ctx, const void* x, const void* w, void* y, int M, int H, float eps);
 int mmd_op_layernorm(mmd_ctx* ctx, const void* x, const void* w, const void* b, void* y, int M, int H, float eps);
+/* the autocast tower's residual step (models/modeling_live.py:28: `hidden (fp32) + sublayer_out (fp16)` promotes, LayerNorm returns fp32, the next linear casts to
+ * fp16): h32[M,H] = (pos16 ? float(pos16[m % period]) : h32) + float(y16); out16 = fp16(LayerNorm(h32) * w16 + b16) when w16 is given; outbf = bf16(h32) when outbf
+ * is given (h32 itself is not rewritten then).  All 16-bit operands are IEEE half except outbf.  H % 8 == 0, H <= 2048. */
+int mmd_op_resid32_layernorm(mmd_ctx* ctx, const void* y16, float* h32, const void* pos16, int period, const void* w16, const void* b16, void* out16, void* outbf,
+                             int M, int H, float eps);
 /* q [S, nh*d] (rotated in place), k/v [S, nkv*d] appended rotated/unrotated at pos0.. into Kc/Vc [nkv, cap, d] */
 int mmd_op_rope_append(mmd_ctx* ctx, void* qkv, int S, int nh, int nkv, int d, float theta, int64_t pos0, void* q_out,
                        void* Kc, void* Vc, int64_t cap);

@@ -99,6 +99,7 @@ _SIGS = {
     'mmd_op_gemm_w8': (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _I]),
     'mmd_op_rmsnorm': (_I, [_VP, _VP, _VP, _VP, _I, _I, _F]),
     'mmd_op_layernorm': (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _F]),
+    'mmd_op_resid32_layernorm': (_I, [_VP, _VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _I, _I, _F]),
     'mmd_op_rope_append': (_I, [_VP, _VP, _I, _I, _I, _I, _F, _I64, _VP, _VP, _VP, _I64]),
     'mmd_op_attention': (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I64, _I64, _I, _I]),
     'mmd_op_attention_bench': (_I, [_VP, _I, _I, _I, _I, _I64, _I, _I, C.POINTER(_F)]),

@@ -1690,6 +1690,12 @@ extern "C" int mmd_op_layernorm(mmd_ctx* c, const void* x, const void* w, const 
     if (!c) return MMD_EINVAL; hipSetDevice(c->device);
     HIPCHK(c, launch_layernorm(c->cfg.dtype, x, w, b, y, M, H, eps, c->stream)); return MMD_OK;
 }
+extern "C" int mmd_op_resid32_layernorm(mmd_ctx* c, const void* y16, float* h32, const void* pos16, int period, const void* w16, const void* b16, void* out16, void* outbf,
+                                        int M, int H, float eps) {
+    if (!c) return MMD_EINVAL; hipSetDevice(c->device);
+    if (!y16 || !h32 || (w16 && (!b16 || !out16)) || (pos16 && period <= 0)) FAIL(c, MMD_EINVAL, "resid32_layernorm: missing operand");
+    HIPCHK(c, launch_resid32_layernorm(y16, h32, pos16, period, w16, b16, out16, outbf, M, H, eps, c->stream)); return MMD_OK;
+}
 extern "C" int mmd_op_rope_append(mmd_ctx* c, void* qkv, int S, int nh, int nkv, int d, float theta, int64_t pos0, void* q_out, void* Kc, void* Vc, int64_t cap) {
     if (!c) return MMD_EINVAL; hipSetDevice(c->device);
     std::vector<float> t(d / 2);

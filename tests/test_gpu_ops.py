@@ -124,6 +124,40 @@ def test_norms(ops):
         assert_close(ops.layernorm(x, w, b, 1e-6), O.layer_norm(xr, wr, br, 1e-6), ops.dtype, what='layernorm')
 
 
+@pytest.mark.parametrize('M,H,period', [(5, 1152, 0), (729 * 3, 1152, 729), (37, 64, 0), (130, 2048, 13), (1, 72, 0)])
+def test_resid32_layernorm_is_the_autocast_residual_step(M, H, period):
+    """resid32_layernorm_kernel (the fp16 tower's fp32 residual stream, models/modeling_live.py:28 under autocast): h32 += float(y16) (or = position row + y16 for the
+    embeddings), LayerNorm of the fp32 row -> fp16, and the bf16 image of the row for the tower's result -- against the same steps in torch: the fp32 stream and the bf16
+    image BIT-exact (one fp32 add per element, one rounding), the LayerNorm output to fp16 rounding of the fp32 result."""
+    import ctypes as C
+    from rawops import RawOps, _ptr
+    from mmduet_amd._lib import lib, check
+    ops = RawOps(torch.bfloat16)
+    dev = ops.dev
+    g = torch.Generator(device=dev).manual_seed(M + H)
+    y = (torch.randn(M, H, generator=g, device=dev) * 2).to(torch.float16)
+    h = torch.randn(M, H, generator=g, device=dev) * 5
+    w = (1 + 0.1 * torch.randn(H, generator=g, device=dev)).to(torch.float16); b = (0.1 * torch.randn(H, generator=g, device=dev)).to(torch.float16)
+    pos = (torch.randn(max(period, 1), H, generator=g, device=dev) * 0.5).to(torch.float16) if period else None
+    ops.m._bind_stream()
+    # (1) add + LayerNorm, output in place of y
+    h1, y1 = h.clone(), y.clone()
+    check(lib().mmd_op_resid32_layernorm(ops.ctx, _ptr(y1), _ptr(h1), _ptr(pos), period, _ptr(w), _ptr(b), _ptr(y1), None, M, H, 1e-6), ops.ctx)
+    torch.cuda.synchronize()
+    ref_h = (pos.float()[torch.arange(M, device=dev) % period] if period else h) + y.float()
+    assert torch.equal(h1, ref_h)
+    ref_ln = torch.nn.functional.layer_norm(ref_h.double(), (H,), w.double(), b.double(), 1e-6)
+    err = (y1.double() - ref_ln).abs().max().item()
+    assert err <= 2.0 ** -10 * max(1.0, ref_ln.abs().max().item()), (M, H, err)
+    # (2) add only, bf16 image out, the fp32 stream left alone
+    h2 = h.clone(); out = torch.empty(M, H, dtype=torch.bfloat16, device=dev)
+    check(lib().mmd_op_resid32_layernorm(ops.ctx, _ptr(y), _ptr(h2), _ptr(pos), period, None, None, None, _ptr(out), M, H, 1e-6), ops.ctx)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref_h.to(torch.bfloat16)) and torch.equal(h2, h)
+    # operand checks
+    assert lib().mmd_op_resid32_layernorm(ops.ctx, _ptr(y), _ptr(h2), None, 0, _ptr(w), None, None, None, M, H, 1e-6) != 0
+
+
 @pytest.mark.parametrize('pos0', [0, 1000, 30000])
 def test_rope_and_kv_append(ops, pos0):
     g = torch.Generator().manual_seed(pos0 + 1)
