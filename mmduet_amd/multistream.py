@@ -129,6 +129,11 @@ class _Slot(threading.Thread):
                                                  final_kv_len=len(d.past_key_values) if d.past_key_values else 0)
                     if self.sched.on_result is not None:
                         self.sched.on_result(n, video, self.sched.results[n])
+                    # give the stream's KV arena back to the model's pool NOW: the slot <-> driver <-> proxy cycle otherwise keeps it alive until the cyclic collector
+                    # runs, and the next video of this slot maps a fresh arena (mmd_stream_create: ~90 ms of address reservation + page mapping each)
+                    if not self.sched.keep_drivers:
+                        d.past_key_values = None
+                        self.driver = d = None
         except BaseException as e:          # surfaces in MultiStreamInfer.run()
             self.error = e
         finally:
@@ -154,6 +159,7 @@ class MultiStreamInfer:
         self.args, self.driver_cls = args, driver_cls
         self.vit_lookahead_batches = vit_lookahead_batches
         self.per_slot_rows = max(256, model.max_step_tokens // n_slots)
+        self.keep_drivers = False             # True: a finished video's driver (and its KV handle) stays reachable as slot.driver (tests that read the arena afterwards)
         self.rounds = self.merged_rows = 0
         self.round_log = None                 # set to a list to record (segments, rows, seconds) per merged forward
         self.exec_seconds = 0.0               # time inside the merged forwards (launch + the one sync), the rest is driver host work

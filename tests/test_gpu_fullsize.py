@@ -201,6 +201,7 @@ def _multi_case(key, cfgname, n_streams, k, model, tok, w32, w16, n_e2e):
         videos.append(dict(frames=fr, conversation=[{'role': 'user', 'content': QUERY, 'time': 0.0}],
                            driver_attrs=dict(forced_frames=frozenset(forced), eos_token_id=-1, record_head_logits=True, sink_key=s)))
     ms = MultiStreamInfer(B.driver_args(args, 1.0, k), model=model, tokenizer=tok, n_slots=n_streams, driver_cls=Rec)
+    ms.keep_drivers = True          # the KV arenas are compared with the oracle's below
     t0 = time.perf_counter()
     results = ms.run(videos)
     torch.cuda.synchronize()
