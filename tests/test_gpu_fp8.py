@@ -72,7 +72,7 @@ def test_quantiser_is_bit_exact_with_torch_e4m3fn(ops, N, K):
     assert torch.equal(Wq.cpu().float(), q_ref.float())                 # the bf16 copy holds exactly the fp8 values
 
 
-@pytest.mark.parametrize('M', [1, 7, 16, 33, 49, 64, 200, 1274])
+@pytest.mark.parametrize('M', [1, 7, 16, 33, 49, 64, 98, 147, 200, 256, 1274])
 @pytest.mark.parametrize('N,K,epi', [(4608, 3584, 'none'), (3584, 3584, 'resid'), (1024, 3584, 'swiglu'), (3584, 18944, 'resid')])
 def test_fp8_gemm_every_regime_matches_fp32_on_dequantised_weights(ops, M, N, K, epi):
     """tolerance: 1.2e-2 x max(1, |ref|max) -- the bf16 output bound; the quantised VALUES are exact in every kernel"""
@@ -245,6 +245,19 @@ def test_fp8_model_at_7b_width_chunk_and_decode_rows():
     ref = o32(inputs_embeds=torch.cat(frames)[None].float(), past_key_values=oc)
     want = torch.cat([ref.informative_logits[0, rows], ref.relevance_logits[0, rows]], -1).cpu()
     e_chunk, e_per, e_cp = (chunk - want).abs().max().item(), (per - want).abs().max().item(), (chunk - per).abs().max().item()
+    # short chunks (2 .. 5 frames = 98 .. 245 rows per forward: gemm_stream_kernel on the bf16(q) copy, the per-channel scale applied to its fp32 slabs / in its
+    # SwiGLU epilogue, fused slab consumers) -- round 4: the regime between the per-frame step and the tile GEMMs
+    e_short = 0.0
+    base2 = m(inputs_embeds=prompt).past_key_values          # (its own arena: the chunk's context above is continued by the decode rows below)
+    for kf in (2, 3, 4, 5):
+        cache_s, got = m.cache_prefix(base2, len(base2)), []
+        for j0 in range(0, 10, kf):
+            fr = frames[j0:j0 + kf]
+            sc, cache_s = m.frame_step(torch.cat(fr)[None], cache_s, [49 * (j + 1) - 1 for j in range(len(fr))])
+            got.append(sc)
+        got = torch.cat(got)[:10]
+        e_short = max(e_short, (got - want[:10]).abs().max().item())
+    assert e_short < 6e-2, e_short
     # decode rows: 6 single-token steps from the chunk's context, lm logits of each
     toks = [(torch.randn(1, 1, 3584, generator=g, device=dev) * 0.5).to(torch.bfloat16) for _ in range(6)]
     hc, ocache, e_dec, e_lm = c_chunk, ref.past_key_values, 0.0, 0.0
@@ -259,7 +272,7 @@ def test_fp8_model_at_7b_width_chunk_and_decode_rows():
         from conftest import ROOT
         path = os.path.join(ROOT, 'gpurun_out', 'parity_r04.json')
         cur = json.load(open(path)) if os.path.exists(path) else {}
-        cur['fp8_true_width_2_layers'] = dict(chunk_vs_fp32=e_chunk, per_frame_vs_fp32=e_per, chunk_vs_per_frame=e_cp, decode_rows_head_vs_fp32=e_dec, decode_rows_lm_vs_fp32=e_lm,
+        cur['fp8_true_width_2_layers'] = dict(chunk_vs_fp32=e_chunk, per_frame_vs_fp32=e_per, chunk_vs_per_frame=e_cp, short_chunks_vs_fp32=e_short, decode_rows_head_vs_fp32=e_dec, decode_rows_lm_vs_fp32=e_lm,
                                               lm_scale=r.logits.abs().max().item())
         json.dump(cur, open(path, 'w'), indent=1, sort_keys=True)
     except Exception:
