@@ -188,6 +188,7 @@ def parse(argv=None):
     p.add_argument('--multi-frames-per-forward', type=int, default=13)
     p.add_argument('--weights', choices=['bf16', 'fp8'], default=None, help='fp8 = e4m3 per-output-channel scaled LLM weights (BASELINE configs[4]); reported with dtype fp8, never the bf16 headline')
     p.add_argument('--phase', choices=['ab', 'b'], default='ab', help="'b': Phase B alone -- the frame embeddings come from a feature file written before the timed region (mmduet_amd/features.py); LLM-only frames/s, never the headline")
+    p.add_argument('--prof-steps', type=int, default=2, help='sample kernel durations (HIP events, --prof-stride) in the first N timed steps only (every step runs the same workload; the HIP runtime keeps an event thread busy for as long as events are being recorded: 0.6 CPU-s per step); 0 = all timed steps')
     p.add_argument('--tower-dtype', choices=['auto', 'bf16', 'fp16', 'fp16_resid16'], default='auto', help="vision tower arithmetic: fp16 = the reference's torch.cuda.amp.autocast() tower (models/modeling_live.py:28), bf16 = the model dtype; auto = the product default")
     p.add_argument('--host-sync', choices=['auto', 'spin', 'yield', 'blocking'], default='auto', help='how this rank waits for the GPU (hipSetDeviceFlags before the first HIP call): blocking frees the host core a spinning wait burns -- matters when 8 ranks share 16 cores')
     p.add_argument('--layers', type=int, default=None, help='debug: override LLM layer count (INVALID as a measurement)')
@@ -565,11 +566,13 @@ def main():
     cpu0 = time.process_time(); thr0 = thread_cpu_times()
     fwd = 0
     step_blocks = []
-    for _ in range(args.steps):
+    for si in range(args.steps):
         scs, n_resp = one_step()
         allsc, lens = gather(scs)                                          # ONE RCCL all-gather of the padded score block
         step_blocks.append(allsc)
         fwd += driver.forward_calls if multi_runner is None else multi_runner.ms.rounds
+        if prof_on and args.prof_steps > 0 and si + 1 == args.prof_steps:
+            model.prof_enable(False)                                       # the sampled launches of the first `prof_steps` timed steps are the sample: every step runs the same workload
     sync()
     dt = time.perf_counter() - t0
     thr1 = thread_cpu_times()
@@ -628,7 +631,7 @@ def main():
                 # capped grid beside a response's decoding (burst schedule) -- is kept next to it
                 r2 = roof_from(p2, dom)
                 overl = dict(achieved=roof['achieved'], frac=roof['frac'], avg_launch_us=roof['avg_launch_us'], launches_timed=roof['launches_timed'],
-                             sampling_stride=args.prof_stride, note='inside the timed region: the tower runs on a side HIP stream next to the LLM steps (and on half the CUs beside decode bursts), '
+                             sampling_stride=args.prof_stride, sampled_steps=(args.prof_steps if args.prof_steps > 0 else args.steps), note='inside the timed region: the tower runs on a side HIP stream next to the LLM steps (and on half the CUs beside decode bursts), '
                              'so launches of the class share the chip and read longer although the step is shorter')
                 roof.update(achieved=r2['achieved'], frac=r2['frac'], avg_launch_us=r2['avg_launch_us'], launches_timed=r2['launches_timed'], sampling_stride=1,
                             source='one more pass of the same workload in this run with tower and LLM on ONE HIP stream, every launch of the class bracketed with HIP events (untimed)')
