@@ -190,6 +190,12 @@ STREAM_CASES = [
      dict(stream_end_score_sum_threshold=2.0, score_heads='informative_score,relevance_score', remove_assistant_turns=True, repetition_penalty=1.15)),
     ('sum_remove', 56, 12, 1.0, [{'role': 'user', 'content': 'Narrate.', 'time': 0.0}],
      dict(stream_end_score_sum_threshold=1.6, score_heads='informative_score', remove_assistant_turns=True, running_list_length=3)),
+    # edge cases (round 4; appended so that the frames of the cases above keep their place in the generator's stream): a one-frame stream that responds on its only
+    # frame, a query whose time is never reached, a response on EVERY frame including the last (with the repetition penalty carried across responses)
+    ('one_frame_respond', 56, 1, 1.0, [{'role': 'user', 'content': 'Hi.', 'time': 0.0}], dict(stream_end_prob_threshold=0.0, score_heads='informative_score')),
+    ('query_after_end', 56, 5, 1.0, [{'role': 'user', 'content': 'Late.', 'time': 99.0}], dict(stream_end_prob_threshold=1.0)),
+    ('respond_every_frame', 56, 4, 2.0, [{'role': 'user', 'content': 'Go.', 'time': 0.0}],
+     dict(stream_end_prob_threshold=0.0, score_heads='informative_score', repetition_penalty=1.15)),
 ]
 
 
