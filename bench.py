@@ -191,6 +191,8 @@ def parse(argv=None):
     p.add_argument('--prof-steps', type=int, default=2, help='sample kernel durations (HIP events, --prof-stride) in the first N timed steps only (every step runs the same workload; the HIP runtime keeps an event thread busy for as long as events are being recorded: 0.6 CPU-s per step); 0 = all timed steps')
     p.add_argument('--tower-dtype', choices=['auto', 'bf16', 'fp16', 'fp16_resid16'], default='auto', help="vision tower arithmetic: fp16 = the reference's torch.cuda.amp.autocast() tower (models/modeling_live.py:28), bf16 = the model dtype; auto = the product default")
     p.add_argument('--host-sync', choices=['auto', 'spin', 'yield', 'blocking'], default='auto', help='how this rank waits for the GPU (hipSetDeviceFlags before the first HIP call): blocking frees the host core a spinning wait burns -- matters when 8 ranks share 16 cores')
+    p.add_argument('--frames-on-host', action='store_true', help='the uint8 frames start in PINNED HOST memory and cross to the GPU inside the timed region (per tower batch, on the tower stream) -- the end-to-end form of the path (the reference: pixel_values.to(cuda), test/inference.py:203); without the flag the frames are resident in HBM (the headline, per the bench contract) and the host-frames rate is reported next to it under "host_frames"')
+    p.add_argument('--host-frames-steps', type=int, default=3, help='steps of the secondary host-frames leg (0 = skip)')
     p.add_argument('--layers', type=int, default=None, help='debug: override LLM layer count (INVALID as a measurement)')
     a = p.parse_args(argv)
     c = CONFIGS[a.config]
@@ -485,7 +487,8 @@ def main():
     model, tok, cfg = build(args, device)
     R = args.resolution if not args.tiny else 48
     g = torch.Generator().manual_seed(1 + rank)
-    frames = torch.randint(0, 256, (args.frames, 3, R, R), dtype=torch.uint8, generator=g).to(device)     # resident in HBM
+    frames_host = torch.randint(0, 256, (args.frames, 3, R, R), dtype=torch.uint8, generator=g).pin_memory()
+    frames = frames_host if args.frames_on_host else frames_host.to(device)     # default: resident in HBM when the timed region starts
     query = 'Please narrate the video in real time.'[:24]
     T, S = args.frames, max(1, args.streams_per_gpu)
     forced = sorted(random.Random(0).sample(range(1, T + 1), args.responses)) if args.responses > 0 else []   # fixed pseudo-random frames
@@ -663,6 +666,23 @@ def main():
         multi = dict(streams_per_gpu=args.multi_stream, frames_per_forward=args.multi_frames_per_forward, value=round(fps, 2), unit='frames/s (this GPU)',
                      ms_per_step=round(ms_step, 1), forwards_per_step=rounds, replayed_frames=replay, time_in_forwards_frac=round(frac, 3),
                      note='mmduet_amd.multistream: one LLM forward carries frame chunks and decode rows of all streams; per-stream results as single-stream')
+    host_leg = None
+    if multi_runner is None and args.phase == 'ab' and args.host_frames_steps > 0 and not args.frames_on_host:
+        # secondary measurement, never the headline: the same workload with the frames starting in pinned host memory; every tower batch uploads its own frames
+        # on the tower's side stream inside the timed steps (mmduet_amd/inference.py input_video_stream / _issue_vit)
+        run_stream(driver, frames_host, query)
+        sync(); th = time.perf_counter()
+        for _ in range(args.host_frames_steps):
+            sc_h, _ = run_stream(driver, frames_host, query)
+        sync(); th = time.perf_counter() - th
+        tm = torch.tensor([th], dtype=torch.float64, device=device)
+        if world > 1:
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        th = float(tm.item())
+        host_leg = dict(value=round(world * args.host_frames_steps * args.frames / th, 2), unit='frames/s', steps=args.host_frames_steps, ms_per_step=round(th / args.host_frames_steps * 1e3, 2),
+                        rel_to_resident=round((world * args.host_frames_steps * args.frames / th) / (world * S * args.steps * args.frames / dt), 4),
+                        scores_equal_resident=bool(torch.equal(sc_h, scs[0])) if not args.frames_on_host else None,
+                        note='frames in pinned host memory, %.1f MB per stream uploaded per tower batch inside the timed steps; `value` of the line is the HBM-resident form' % (frames_host.numel() / 1e6))
     parity = recorded_parity(args)
     if rank == 0 and not (args.tiny or args.no_parity_check or args.phase == 'b' or args.layers):
         try:
@@ -687,8 +707,8 @@ def main():
                        'max_new_tokens': args.max_new_tokens, 'response_frames': forced, 'llm_forwards_per_step': fwd // max(1, args.steps),
                        'kv_tokens_end': kv_end, 'weights': ('random init N(0,0.02), true shapes' if not args.tiny else 'tiny') + ('' if args.weights == 'bf16' else ', LLM matrices quantised to fp8 e4m3 per output channel'),
                        'parallelism': f'dp{world} ({S} stream(s) per GPU, one RCCL all-gather of the [{world},{S},{T}+1,2] score block per step, issued by libmmduet_hip (mmd_gather_block))',
-                       'native_gather_check': native, 'tower_overlap': not args.no_overlap, 'tower_dtype': getattr(model, 'tower_dtype', None), 'phase': 'A+B' if args.phase == 'ab' else 'B only (frame embeddings pre-extracted to a feature file; LLM side alone)', 'layers_override': args.layers},
-            'verified': verified, 'resp_head_logit_delta': parity, 'roofline': roof, 'roofline_secondary': roof2, 'cpu_baseline': cpu, 'multi_stream': multi,
+                       'native_gather_check': native, 'frames_start_in': 'pinned host memory (uploaded inside the timed region)' if args.frames_on_host else 'HBM', 'tower_overlap': not args.no_overlap, 'tower_dtype': getattr(model, 'tower_dtype', None), 'phase': 'A+B' if args.phase == 'ab' else 'B only (frame embeddings pre-extracted to a feature file; LLM side alone)', 'layers_override': args.layers},
+            'verified': verified, 'resp_head_logit_delta': parity, 'roofline': roof, 'roofline_secondary': roof2, 'cpu_baseline': cpu, 'multi_stream': multi, 'host_frames': host_leg,
         }
         import ctypes
         ctypes.CDLL(None).fflush(None)          # RCCL's banner sits in C stdio's buffer when stdout is a pipe: push it out BEFORE the JSON line

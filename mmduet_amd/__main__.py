@@ -29,6 +29,7 @@ def main(argv=None):
     from .inference import LiveInferForBenchmark
     from .results import result_record
     from .distributed import init_distributed, shard_indices, shard_shape, gather_scores
+    from .prefetch import ClipPrefetcher, pin
     args = parse_args('test', argv)
     rank, world, local = init_distributed()
     if torch.cuda.is_available():
@@ -37,8 +38,11 @@ def main(argv=None):
     mine = shard_indices(len(data), rank, world)
     infer = LiveInferForBenchmark(args)
     out_name = args.output_fname if world == 1 else f'{args.output_fname}.rank{rank}'
-    def load(ex):
-        """One test entry -> (frames uint8 [T,3,R,R], fps, duration, conversation) or None when unreadable (test/datasets.py:102-104)."""
+    # ---- a clip's way to the driver, in two stages (mmduet_amd/prefetch.py; the reference: DataLoader(num_workers=4), test/inference.py:341) ----
+    def load_host(i):
+        """HOST stage (loader threads, no GPU call): test entry i -> dict(kind, tensors in pinned host memory, fps / duration / conversation), or None when
+        unreadable (test/datasets.py:102-104)."""
+        ex = data[i]
         conv = [dict(t) for t in ex['conversation']]
         try:
             if 'features' in ex and args.features_dir:
@@ -48,29 +52,67 @@ def main(argv=None):
                 fps = ex.get('fps', args.frame_fps)
                 if args.max_num_frames:
                     feats = feats[:args.max_num_frames]
-                return feats, fps, ex.get('video_duration', len(feats) / fps), [{'role': 'system', 'content': args.system_prompt}] + conv
+                return dict(kind='features', frames=pin(feats), fps=fps, duration=ex.get('video_duration', len(feats) / fps), conv=conv, index=i)
             if 'video' in ex or 'decoded' in ex:
-                from .video_input import load_video_frames
-                if 'video' in ex:            # a container this package can read without a codec library (Motion-JPEG / uncompressed AVI, video_decode.py)
-                    from .video_decode import read_avi
-                    raw, in_fps, count = read_avi(os.path.join(args.input_dir, ex['video']))
+                from .video_input import sampling_selector, frame_sampling_plan
+                if 'video' in ex:            # a container this package can read without a codec library (Motion-JPEG / uncompressed AVI, video_decode.py):
+                    from .video_decode import read_avi          # only the frames the sampling schedule keeps are decoded
+                    sel = sampling_selector(args.frame_fps, args.max_num_frames)
+                    raw, in_fps, count, kept = read_avi(os.path.join(args.input_dir, ex['video']), select=sel)
+                    n_dec = sel.n_decodable
                 else:
-                    raw, in_fps, count = torch.from_numpy(np.load(os.path.join(args.input_dir, ex['decoded']))), ex['input_fps'], ex.get('frame_count')
-                out = load_video_frames(infer.model, raw, in_fps, count, output_fps=args.frame_fps,
-                                        resolution=args.frame_resolution, max_num_frames=args.max_num_frames,
-                                        time_instruction_format=args.time_instruction_format)
-                frames, fps, duration = out[0], out[1], out[2]
-                if args.time_instruction_format is not None:      # test/datasets.py:97-98
-                    conv[0]['content'] = out[3] + '\n' + conv[0]['content']
-            else:
-                frames = torch.from_numpy(np.load(os.path.join(args.input_dir, ex['frames'])))
-                fps = ex.get('fps', args.frame_fps)
-                duration = ex.get('video_duration', len(frames) / fps)
+                    full = np.load(os.path.join(args.input_dir, ex['decoded']), mmap_mode='r')
+                    in_fps, count = ex['input_fps'], ex.get('frame_count')
+                    kept = frame_sampling_plan(in_fps, len(full) if count is None else count, args.frame_fps, args.max_num_frames, n_decodable=len(full))[0]
+                    raw = torch.from_numpy(np.ascontiguousarray(full[kept])) if kept else torch.empty((0,) + full.shape[1:], dtype=torch.uint8)
+                    n_dec = len(full)
+                return dict(kind='raw', raw=pin(raw), in_fps=in_fps, count=count, kept=kept, n_decodable=n_dec, conv=conv, index=i)
+            frames = torch.from_numpy(np.load(os.path.join(args.input_dir, ex['frames'])))
+            if args.max_num_frames:
+                frames = frames[:args.max_num_frames]
+            fps = ex.get('fps', args.frame_fps)
+            return dict(kind='frames', frames=pin(frames), fps=fps, duration=ex.get('video_duration', len(frames) / fps), conv=conv, index=i)
         except Exception as e:
             print(f"error loading {ex.get('question_id')} due to exception {e}, this example will be skipped", file=sys.stderr)
             return None
-        if args.max_num_frames:
-            frames = frames[:args.max_num_frames]
+
+    copy_stream = torch.cuda.Stream(device=infer.device) if infer.device.type == 'cuda' else None
+
+    def stage_device(h):
+        """DEVICE stage, early half: start the upload of a raw clip on the copy stream (asynchronous: the buffer is pinned), to be met by `finish`."""
+        if h is None or h['kind'] != 'raw' or copy_stream is None or 'dev' in h:
+            return h
+        with torch.cuda.stream(copy_stream):
+            h['dev'] = h['raw'].to(infer.device, non_blocking=True)
+            h['ready'] = torch.cuda.Event(); h['ready'].record(copy_stream)
+        return h
+
+    def finish(h):
+        """DEVICE stage, late half (main thread, the driver's stream) -> (frames uint8 [T,3,R,R] | features, fps, duration, conversation) or None."""
+        if h is None:
+            return None
+        ex, conv = data[h['index']], h['conv']
+        try:
+            if h['kind'] == 'raw':
+                from .video_input import load_video_frames
+                stage_device(h)
+                raw = h.get('dev', h['raw'])
+                if 'ready' in h:
+                    torch.cuda.current_stream(infer.device).wait_event(h['ready'])
+                    raw.record_stream(torch.cuda.current_stream(infer.device))
+                out = load_video_frames(infer.model, raw, h['in_fps'], h['count'], output_fps=args.frame_fps, resolution=args.frame_resolution,
+                                        max_num_frames=args.max_num_frames, time_instruction_format=args.time_instruction_format,
+                                        presampled=(h['kept'], h['n_decodable']))
+                frames, fps, duration = out[0], out[1], out[2]
+                if args.time_instruction_format is not None:      # test/datasets.py:97-98
+                    conv[0]['content'] = out[3] + '\n' + conv[0]['content']
+                if args.max_num_frames:
+                    frames = frames[:args.max_num_frames]
+            else:
+                frames, fps, duration = h['frames'], h['fps'], h['duration']
+        except Exception as e:
+            print(f"error loading {ex.get('question_id')} due to exception {e}, this example will be skipped", file=sys.stderr)
+            return None
         return frames, fps, duration, [{'role': 'system', 'content': args.system_prompt}] + conv
 
     local_scores = {}          # dataset index -> [[informative, relevance] per frame] of the videos this rank ran
@@ -78,46 +120,63 @@ def main(argv=None):
     def keep_scores(i, debug_data):
         local_scores[i] = [[d['informative_score'], d['relevance_score']] for d in debug_data]
 
-    with open(out_name, 'w') as f_out:
-        if args.streams_per_gpu > 1:
-            # several videos share every LLM forward.  Clips are loaded when a slot takes them and every record is written (and flushed)
-            # as its video completes, in completion order -- a crash loses nothing, a long test file is never resident at once
-            from .multistream import MultiStreamInfer
-            ms = MultiStreamInfer(args, model=infer.model, tokenizer=infer.tokenizer, n_slots=args.streams_per_gpu)
+    failure = None
+    pf = ClipPrefetcher(load_host, mine, workers=args.num_workers)
+    try:
+        with open(out_name, 'w') as f_out:
+            if args.streams_per_gpu > 1:
+                # several videos share every LLM forward.  A slot takes its next clip from the prefetcher (in dataset order) and every record is written (and
+                # flushed) as its video completes, in completion order -- a crash loses nothing, a long test file is never resident at once
+                from .multistream import MultiStreamInfer
+                ms = MultiStreamInfer(args, model=infer.model, tokenizer=infer.tokenizer, n_slots=args.streams_per_gpu)
 
-            def entry(i):
-                ex = data[i]
+                def entry(i):
+                    def make():
+                        got = pf.take()
+                        assert got is not None and got[0] == i, (got and got[0], i)
+                        v = finish(got[1])
+                        return None if v is None else dict(frames=v[0], fps=v[1], conversation=v[3], ex=data[i], duration=v[2], index=i)
+                    return make
 
-                def make():
-                    v = load(ex)
-                    return None if v is None else dict(frames=v[0], fps=v[1], conversation=v[3], ex=ex, duration=v[2], index=i)
-                return make
-
-            def on_result(n, video, res):
-                rec = result_record(video['ex']['question_id'], res['responses'], video['duration'], res['debug_data'], evaluator_format=args.evaluator_format)
-                f_out.write(json.dumps(rec) + '\n')
-                f_out.flush()
-                keep_scores(video['index'], res['debug_data'])
-            ms.run([entry(i) for i in mine], on_result=on_result)
-        for n, i in enumerate([] if args.streams_per_gpu > 1 else mine):
-            ex = data[i]
-            v = load(ex)
-            if v is None:
-                continue
-            frames, fps, duration, conversation = v
-            infer.reset()
-            infer.set_fps(fps=fps)
-            if frames.dtype == torch.uint8:
-                infer.input_video_stream(frames)
+                def on_result(n, video, res):
+                    rec = result_record(video['ex']['question_id'], res['responses'], video['duration'], res['debug_data'], evaluator_format=args.evaluator_format)
+                    f_out.write(json.dumps(rec) + '\n')
+                    f_out.flush()
+                    keep_scores(video['index'], res['debug_data'])
+                ms.run([entry(i) for i in mine], on_result=on_result)
             else:
-                infer.input_feature_stream(frames)
-            infer.input_query_stream(conversation)
-            responses = infer.inference()
-            rec = result_record(ex['question_id'], responses, duration, infer.debug_data_list, evaluator_format=args.evaluator_format)
-            f_out.write(json.dumps(rec) + '\n')
-            keep_scores(i, infer.debug_data_list)
-            if n % 5 == 0:
-                f_out.flush()
+                n = 0
+                cur = pf.take()
+                while cur is not None:
+                    i, h = cur
+                    nxt = None
+                    v = finish(h)
+                    if v is not None:
+                        frames, fps, duration, conversation = v
+                        infer.reset()
+                        infer.set_fps(fps=fps)
+                        if frames.dtype == torch.uint8:
+                            infer.input_video_stream(frames)
+                        else:
+                            infer.input_feature_stream(frames)
+                        infer.input_query_stream(conversation)
+                        if pf.next_ready():           # the next clip is decoded already: its upload runs under this clip's LLM steps
+                            nxt = pf.take()
+                            stage_device(nxt[1])
+                        responses = infer.inference()
+                        rec = result_record(data[i]['question_id'], responses, duration, infer.debug_data_list, evaluator_format=args.evaluator_format)
+                        f_out.write(json.dumps(rec) + '\n')
+                        keep_scores(i, infer.debug_data_list)
+                        if n % 5 == 0:
+                            f_out.flush()
+                        n += 1
+                    cur = nxt if nxt is not None else pf.take()
+    except BaseException as e:          # (world > 1: this rank still joins the collective below with the scores it has, then re-raises -- the other ranks must not hang on it)
+        failure = e
+        if world == 1:
+            raise
+    finally:
+        pf.close()
     if world > 1:
         # the ONE collective of the path.  n_max is known without communication (deterministic assignment); the longest stream is not (frame counts come from
         # the clips), so gather_scores precedes the block by its 16-byte shape exchange.  A skipped (unreadable) clip travels as a zero-length stream.
@@ -128,11 +187,16 @@ def main(argv=None):
             merged = {}
             for i, ex in enumerate(data):
                 r, slot = i % world, i // world
-                merged[str(ex['question_id'])] = allsc[r, slot, :int(lens[r, slot])].tolist()
+                key = str(ex['question_id'])
+                if key in merged:           # duplicate question ids must not collapse silently: later ones carry their dataset index
+                    key = f'{key}#{i}'
+                merged[key] = allsc[r, slot, :int(lens[r, slot])].tolist()
             with open(f'{args.output_fname}.scores.json', 'w') as f:
                 json.dump(merged, f)
         import torch.distributed as dist
         dist.barrier()
+        if failure is not None:
+            raise failure
 
 
 if __name__ == '__main__':

@@ -70,6 +70,7 @@ class LiveTestArguments(LiveTrainingArguments):
     kv_capacity_tokens: int = 0          # 0 = size the KV arena from max_num_frames
     max_new_tokens: int = 200            # test/inference.py:42 uses a 200-wide output buffer
     overlap_vision: bool = True          # encode frames on a side HIP stream, overlapping the LLM steps
+    num_workers: int = 4                 # clip loader threads of the CLI (the reference: DataLoader(num_workers=4), test/inference.py:341); 0 = load inline, no prefetch
     streams_per_gpu: int = 1             # > 1: that many videos share each LLM forward (mmduet_amd/multistream.py)
     evaluator_format: bool = False       # write debug_data in the shape test/evaluate.py reads (results.result_record)
     features_dir: Optional[str] = None   # entries of --test_fname that carry "features": "<file>" read a pre-extracted feature file from here (mmduet_amd/features.py)

@@ -910,7 +910,8 @@ static hipError_t launch_gqa128(AttnP& p, const AttnArgs& a, hipStream_t st) {
     const int G = a.nh / a.nkv, rows_total = a.S * G;
     // chunks (>= 1024 rows per kv head): 256-row blocks, one per CU, four-slot ring; MMDUET_ATTN_CHUNK8=0 keeps the 128-row form (A/B switch)
     static const bool chunk8_off = getenv("MMDUET_ATTN_CHUNK8") && atoi(getenv("MMDUET_ATTN_CHUNK8")) == 0;
-    const bool chunk8 = RT == 2 && rows_total >= 1024 && !chunk8_off;
+    static const int chunk8_min = getenv("MMDUET_ATTN_CHUNK8_MIN") ? atoi(getenv("MMDUET_ATTN_CHUNK8_MIN")) : 1024;          // (round-5 probe, to be removed)
+    const bool chunk8 = RT == 2 && rows_total >= chunk8_min && !chunk8_off;
     const int qblocks = cdiv(rows_total, chunk8 ? 256 : 64 * RT);
     const int resident = chunk8 ? 256 : 512;                       // blocks the chip holds at once
     static const double chunk8_unit = getenv("MMDUET_ATTN_CHUNK8_UNIT") ? atof(getenv("MMDUET_ATTN_CHUNK8_UNIT")) : 1.0;          // (swept 1.0 .. 2.6 at 0 / 3.8 k / 8.9 k / 14 k keys: flat up to 2.0, 1.0 best at 3.8 k)

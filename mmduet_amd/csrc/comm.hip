@@ -108,8 +108,19 @@ extern "C" int mmd_comm_set_stream(mmd_comm* c, void* hip_stream) {
     hipStream_t ns = (hipStream_t)hip_stream;
     if (ns != c->stream && c->issued) {
         hipSetDevice(c->device);
-        if (!c->order && hipEventCreateWithFlags(&c->order, hipEventDisableTiming) != hipSuccess) { c->err = "hipEventCreate failed"; return MMD_EHIP; }
-        if (hipEventRecord(c->order, c->stream) != hipSuccess || hipStreamWaitEvent(ns, c->order, 0) != hipSuccess) { c->err = "stream hand-over of the communicator failed"; return MMD_EHIP; }
+        // the new stream waits for an event recorded behind the last gather on the old one.  If the event cannot be made or recorded (the old handle may be a
+        // stream its owner has since destroyed) fall back to draining the old stream on the host; either way the NEW stream is adopted -- a failed hand-over must
+        // never leave later gathers on a stream that is unordered with the kernels producing their input.
+        bool ordered = (c->order || hipEventCreateWithFlags(&c->order, hipEventDisableTiming) == hipSuccess) &&
+                       hipEventRecord(c->order, c->stream) == hipSuccess && hipStreamWaitEvent(ns, c->order, 0) == hipSuccess;
+        if (!ordered) {
+            (void)hipGetLastError();
+            const bool drained = hipStreamSynchronize(c->stream) == hipSuccess;
+            (void)hipGetLastError();
+            c->stream = ns;
+            if (!drained) { c->err = "stream hand-over of the communicator failed (event and host drain both refused); the new stream was adopted"; return MMD_EHIP; }
+            return MMD_OK;
+        }
     }
     c->stream = ns;
     return MMD_OK;

@@ -148,7 +148,9 @@ class NativeScoreGather:
     def _on_current_stream(self):
         """Every gather is issued on torch's CURRENT stream: its input was produced there and its output is consumed there, so stream order is the only
         ordering needed (a communicator bound to the stream of its construction would race with work on any other stream)."""
-        self._lib.mmd_comm_set_stream(self._h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        rc = self._lib.mmd_comm_set_stream(self._h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        if rc:
+            raise self._err(f'mmd_comm_set_stream failed ({rc}): {self._lib.mmd_comm_last_error(self._h).decode()}')
 
     def gather(self, scores, t_max):
         """scores [T,2] fp32 on the device -> (all [world, t_max, 2] fp32 NaN-padded, lengths [world] int32), device tensors."""

@@ -143,7 +143,7 @@ class LiveInferForBenchmark:
         self.stream_end_score_sum = 0
         self.consecutive_n_frames = 0
         self._frame_batch = {}               # frame embedding (data_ptr) -> tower batch index, overlap mode
-        self._vit_out = self._vit_pixels = None
+        self._vit_out = self._vit_pixels = self._vit_host = None
         self._vit_fused = False
         self._vit_batches, self._vit_events, self._vit_waited = [], [], set()
         self.forward_calls = 0              # LLM forwards issued (diagnostics of the chunked schedule)
@@ -159,9 +159,8 @@ class LiveInferForBenchmark:
         if not overlap:
             vb = _tower_batch(self.model)
             if fused:
-                frames_dev = video_frames.to(self.device)
-                for b0 in range(0, len(frames_dev), vb):
-                    embeds = self.model.visual_embed_frames(frames_dev[b0:b0 + vb]).split(self.frame_num_tokens)
+                for b0 in range(0, len(video_frames), vb):          # (host frames cross per tower batch; asynchronously when the caller pinned them)
+                    embeds = self.model.visual_embed_frames(video_frames[b0:b0 + vb].to(self.device, non_blocking=True)).split(self.frame_num_tokens)
                     self.frame_embeds_queue.extend(((r + b0) / self.frame_fps, f) for r, f in enumerate(embeds))
                 return
             pixel_values = self.image_processor.preprocess(video_frames, return_tensors='pt')['pixel_values']
@@ -185,7 +184,13 @@ class LiveInferForBenchmark:
         self._vit_out = torch.empty(T * nt, self.hidden_size, dtype=self.torch_dtype, device=self.device)
         side.wait_stream(main)
         self._vit_fused = fused
-        if fused:
+        self._vit_host = None
+        if fused and video_frames.device.type == 'cpu' and self.device.type == 'cuda':
+            # host frames (the CLI's loader threads hand over pinned clips; the reference: pixel_values.to('cuda'), test/inference.py:203): every tower batch uploads
+            # its own frames on the tower's side stream right before it runs (_issue_vit) -- no synchronous whole-video copy in front of the first LLM step
+            self._vit_host = video_frames
+            self._vit_pixels = torch.empty(video_frames.shape, dtype=torch.uint8, device=self.device)
+        elif fused:
             self._vit_pixels = video_frames.to(self.device)             # the raw uint8 frames stay resident; each tower batch resamples its own
         else:
             with torch.cuda.stream(side):
@@ -228,6 +233,8 @@ class LiveInferForBenchmark:
             b0, b1 = self._vit_batches[len(self._vit_events)]
             with torch.cuda.stream(self._vit_stream):
                 if getattr(self, '_vit_fused', False):
+                    if getattr(self, '_vit_host', None) is not None:
+                        self._vit_pixels[b0:b1].copy_(self._vit_host[b0:b1], non_blocking=True)
                     self.model.visual_embed_frames(self._vit_pixels[b0:b1], out=self._vit_out[b0 * nt:b1 * nt])
                 else:
                     self.model.visual_embed(self._vit_pixels[b0:b1], out=self._vit_out[b0 * nt:b1 * nt])

@@ -32,8 +32,13 @@ def _chunks(buf, start, end):
         pos += 8 + size + (size & 1)
 
 
-def read_avi(path, max_frames=None):
-    """-> (frames uint8 [N,H,W,3] BGR host tensor, fps, header_frame_count).  Raises AviError on anything but MJPEG / uncompressed RGB24 video."""
+def read_avi(path, max_frames=None, select=None):
+    """-> (frames uint8 [N,H,W,3] BGR host tensor, fps, header_frame_count).  Raises AviError on anything but MJPEG / uncompressed RGB24 video.
+
+    `select(fps, header_frame_count, n_frames_in_file) -> iterable of frame indices`: decode ONLY those frames (in file order) and return
+    (frames [len(kept),H,W,3], fps, header_frame_count, kept).  Every frame of the two supported codecs is coded independently, so a frame the
+    sampling schedule drops need not be decoded at all -- cv2.VideoCapture.read() in the reference's loop (test/datasets.py:46-50) decodes every
+    frame and throws 29 of 30 away at 1 fps; the kept pixels are the same either way."""
     buf = memoryview(open(path, 'rb').read())
     if len(buf) < 12 or bytes(buf[:4]) != b'RIFF' or bytes(buf[8:12]) != b'AVI ':
         raise AviError(f'{path}: not a RIFF AVI file')
@@ -87,7 +92,16 @@ def read_avi(path, max_frames=None):
             elif cc[:2] == tag and cc[2:] in (b'dc', b'db') and size > 0:
                 yield at, size
 
-    for at, size in frames_in(*movi):
+    fps = info['rate'] / info['scale'] if info['rate'] and info['scale'] else (1e6 / info['us_per_frame'] if info['us_per_frame'] else 0.0)
+    located = list(frames_in(*movi))
+    if max_frames:
+        located = located[:max_frames]
+    count = info['length'] or info['total_frames'] or len(located)
+    kept = None
+    if select is not None:
+        kept = [int(i) for i in select(float(fps), int(count), len(located))]
+        located = [located[i] for i in kept]
+    for at, size in located:
         data = buf[at:at + size]
         if mjpeg:
             rgb = np.asarray(Image.open(io.BytesIO(data)).convert('RGB'))
@@ -96,13 +110,14 @@ def read_avi(path, max_frames=None):
             stride = (W * 3 + 3) & ~3
             a = np.frombuffer(data, dtype=np.uint8, count=stride * H).reshape(H, stride)[:, :W * 3].reshape(H, W, 3)
             frames.append(a[::-1] if info['height'] > 0 else a)              # positive biHeight = bottom-up rows; stored order is already BGR
-        if max_frames and len(frames) >= max_frames:
-            break
+    if not frames and select is not None and not kept:
+        return torch.empty((0, H, W, 3), dtype=torch.uint8), float(fps), int(count), kept          # (an empty schedule is the caller's error to raise, as np.stack([]) is the reference's)
     if not frames:
         raise AviError(f'{path}: no decodable frames')
-    fps = info['rate'] / info['scale'] if info['rate'] and info['scale'] else (1e6 / info['us_per_frame'] if info['us_per_frame'] else 0.0)
-    count = info['length'] or info['total_frames'] or len(frames)
-    return torch.from_numpy(np.ascontiguousarray(np.stack(frames))), float(fps), int(count)
+    out = torch.from_numpy(np.ascontiguousarray(np.stack(frames)))
+    if select is not None:
+        return out, float(fps), int(count), kept
+    return out, float(fps), int(count)
 
 
 def write_mjpeg_avi(path, frames_rgb, fps, quality=95, header_frame_count=None):

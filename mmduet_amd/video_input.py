@@ -54,7 +54,7 @@ def letterbox_frames(model, frames, resolution=384, pad_color=(0, 0, 0), bgr_inp
     """frames: uint8 [T,H,W,3] (decoder layout; moved to the model's device if needed) -> uint8 [T,3,R,R] on the device."""
     if frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[-1] != 3:
         raise ValueError(f'letterbox_frames expects uint8 [T,H,W,3], got {frames.dtype} {tuple(frames.shape)}')
-    frames = frames.to(model.device).contiguous()
+    frames = frames.to(model.device, non_blocking=True).contiguous()          # (a pinned host clip -- the CLI's loader threads pin theirs -- crosses asynchronously, in stream order)
     T, H, W, _ = frames.shape
     out = torch.empty((T, 3, resolution, resolution), dtype=torch.uint8, device=model.device)
     pad = (C.c_uint8 * 3)(*[int(p) for p in pad_color])
@@ -77,16 +77,35 @@ def time_instruction(fmt, video_duration, n_frames, frame_sec):
 
 
 def load_video_frames(model, decoded_frames, input_fps, frame_count=None, output_fps=2, resolution=384, max_num_frames=100,
-                      time_instruction_format=None, pad_color=(0, 0, 0), budget='ceil'):
+                      time_instruction_format=None, pad_color=(0, 0, 0), budget='ceil', presampled=None):
     """`load_video` given the decoder's output: decoded_frames uint8 [N,H,W,3] BGR (host or device), in decode order.
-    Returns (frames uint8 [T,3,R,R] on the device, output_fps, video_duration[, time_instruction])."""
-    n = int(decoded_frames.shape[0])
+    Returns (frames uint8 [T,3,R,R] on the device, output_fps, video_duration[, time_instruction]).
+    presampled = (kept, n_decodable): `decoded_frames` already holds ONLY the frames `kept` of a file with n_decodable frames (video_decode.read_avi(select=...),
+    the CLI's loader threads): the schedule is recomputed and must agree, the picking is skipped."""
+    n = int(decoded_frames.shape[0]) if presampled is None else int(presampled[1])
     kept, out_fps, duration, frame_sec = frame_sampling_plan(input_fps, n if frame_count is None else frame_count, output_fps,
                                                              max_num_frames, n_decodable=n, budget=budget)
     if not kept:
         raise ValueError('need at least one array to stack')          # np.stack([]) in the reference (test/datasets.py:85)
-    picked = decoded_frames[torch.as_tensor(kept, device=decoded_frames.device)]
+    if presampled is None:
+        picked = decoded_frames[torch.as_tensor(kept, device=decoded_frames.device)]
+    else:
+        if list(presampled[0]) != kept or int(decoded_frames.shape[0]) != len(kept):
+            raise ValueError('presampled frames do not follow the sampling schedule')
+        picked = decoded_frames
     frames = letterbox_frames(model, picked, resolution, pad_color)
     if time_instruction_format is None:
         return frames, out_fps, duration
     return frames, out_fps, duration, time_instruction(time_instruction_format, duration, len(kept), frame_sec)
+
+
+class sampling_selector:
+    """The `select` callback of video_decode.read_avi: the frames the reference's sampling loop keeps, so that only those are decoded.  Remembers the file's
+    frame count it was called with (`n_decodable`), which `load_video_frames(presampled=...)` needs to recompute the same schedule."""
+
+    def __init__(self, output_fps, max_num_frames, budget='ceil'):
+        self.output_fps, self.max_num_frames, self.budget, self.n_decodable = output_fps, max_num_frames, budget, None
+
+    def __call__(self, input_fps, frame_count, n_decodable):
+        self.n_decodable = int(n_decodable)
+        return frame_sampling_plan(input_fps, frame_count, self.output_fps, self.max_num_frames, n_decodable=n_decodable, budget=self.budget)[0]

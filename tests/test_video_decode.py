@@ -82,3 +82,42 @@ def test_cli_video_entry_equals_decoded_entry(tmp_path, monkeypatch):
                   '--stream_end_prob_threshold', '0.5', '--max_new_tokens', '4'])
         outs.append([json.loads(l) for l in open(tmp_path / f'{tag}.jsonl')])
     assert outs[0] == outs[1] and len(outs[0][0]['debug_data']) == 6 and outs[0][0]['video_duration'] == 4.0
+
+
+def test_sampled_decode_equals_decode_then_pick(tmp_path):
+    """read_avi(select=...) decodes only the frames the reference's sampling loop keeps (test/datasets.py:41-50); the kept frames equal read_avi + pick."""
+    from mmduet_amd.video_input import sampling_selector, frame_sampling_plan
+    rng = np.random.default_rng(5)
+    fr = rng.integers(0, 256, (40, 24, 32, 3)).astype(np.uint8)
+    write_mjpeg_avi(tmp_path / 'c.avi', fr, 10.0, quality=90, header_frame_count=43)
+    full, fps, count = read_avi(tmp_path / 'c.avi')
+    for out_fps, cap in ((2.0, 100), (1.0, 3), (0, 7)):
+        sel = sampling_selector(out_fps, cap)
+        got, fps2, count2, kept = read_avi(tmp_path / 'c.avi', select=sel)
+        ref_kept = frame_sampling_plan(fps, count, out_fps, cap, n_decodable=len(full))[0]
+        assert kept == ref_kept and sel.n_decodable == 40 and (fps2, count2) == (fps, count)
+        assert torch.equal(got, full[torch.as_tensor(kept)])
+
+
+def test_clip_prefetcher_order_and_inline_mode():
+    import threading, time
+    from mmduet_amd.prefetch import ClipPrefetcher
+    seen = []
+
+    def load(i):
+        time.sleep(0.01 * (5 - i % 5))           # later indices finish earlier: order must still hold
+        seen.append((i, threading.current_thread().name))
+        return None if i == 3 else {'index': i}
+    for workers in (0, 1, 4):
+        seen.clear()
+        with ClipPrefetcher(load, range(9), workers=workers) as pf:
+            first = pf.take()
+            assert first == (0, {'index': 0})
+            if workers:
+                time.sleep(0.2)
+                assert pf.next_ready()                       # the following clips were loaded while the consumer was busy
+            else:
+                assert not pf.next_ready() and len(seen) == 1   # inline: nothing is loaded before it is asked for
+            rest = list(pf)
+        assert [i for i, _ in rest] == list(range(1, 9)) and rest[2][1] is None and pf.take() is None
+        assert all(n.startswith('mmduet-clip') for _, n in seen) == (workers > 0)

@@ -6,9 +6,10 @@ import torch
 from mmduet_amd._lib import lib, check
 from rawops import RawOps
 ops = RawOps(torch.bfloat16)
-for S in (1, 49, 392, 1274):
+small = len(sys.argv) > 1 and sys.argv[1] == 'small'          # the split-KV forms only (S <= 64), shipped kernel only
+for S in ((1, 4, 24, 49, 64) if small else (1, 49, 392, 1274)):
     for n in (0, 1024, 4096, 15000, 30000):
-        for v in (2, 3):
+        for v in ((3,) if small else (2, 3)):
             ms = C.c_float()
             check(lib().mmd_op_attention_bench(ops.ctx, S, 28, 4, 128, n, v, 20, C.byref(ms)), ops.ctx)
             fl = 4.0 * S * (n + S) * 128 * 28
