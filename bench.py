@@ -28,7 +28,7 @@ import torch
 
 HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_BF16_PEAK_TF = 2500.0      # dense bf16 MFMA peak
-PMC_TRAFFIC = ('profiles/r04_pmc_traffic.json', 'profiles/r03_pmc_traffic.json', 'profiles/r02_pmc_traffic.json', 'profiles/r01_pmc_traffic.json')      # newest first
+PMC_TRAFFIC = ('profiles/r05_pmc_traffic.json', 'profiles/history/r04_pmc_traffic.json', 'profiles/history/r03_pmc_traffic.json')      # newest first
 
 CONFIGS = {
     # name: (frames, responses, frames_per_forward, streams_per_gpu, workload text)
@@ -99,7 +99,7 @@ def thread_cpu_times():
 def recorded_parity(args):
     """The second half of BASELINE.json's metric ("resp-head logit delta"): NOT measured by this run -- the recorded result of tests/test_gpu_fullsize.py
     (this workload through the product driver against the fp32 oracle on the GPU, same weights, same frames), copied to profiles/ when the test last ran on an MI355X."""
-    for path in ('profiles/r04_parity_full_size.json', 'profiles/r03_parity_full_size.json'):
+    for path in ('profiles/r05_parity_full_size.json', 'profiles/history/r04_parity_full_size.json'):
         try:
             rec = json.load(open(os.path.join(ROOT, path))).get(args.config)
             if not rec or rec.get('weights') != ('fp8' if args.weights == 'fp8' else 'bf16'):
@@ -182,7 +182,7 @@ def parse(argv=None):
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-parity-check', action='store_true', help='skip the post-timing oracle check of a stream prefix (resp_head_logit_delta.measured_in_run)')
     p.add_argument('--prof-stride', type=int, default=31, help='bracket every n-th launch of the dominant kernel class with HIP events inside the timed region (round 4: 7 -> 31 -- the event pairs, not the kernels, '
-                   'kept a runtime thread 75 %% busy: 0.65 CPU s per 0.85 s step and -2 %% frames/s, profiles/r04_host_thread_probe.txt)')
+                   'kept a runtime thread 75 %% busy: 0.65 CPU s per 0.85 s step and -2 %% frames/s, profiles/history/r04_host_thread_probe.txt)')
     p.add_argument('--no-prof', action='store_true', help='do not bracket the dominant kernel with HIP events in the timed region')
     p.add_argument('--multi-stream', type=int, default=4, help='also measure S streams per GPU in shared forwards (reported under "multi_stream"; never the headline value; 0 = skip)')
     p.add_argument('--multi-frames-per-forward', type=int, default=13)

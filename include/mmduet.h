@@ -236,6 +236,11 @@ int mmd_op_gemm(mmd_ctx* ctx, const void* X, const void* W, const void* bias, co
 /* what the dispatcher chose for the most recent GEMM of this context: out4 = {kernel (0 tile64, 1 tile128, 2 skinny, 3 gemv16, 4 big64,
  * 5 big128, 6 ring256), output tiles, K splits, blocks launched} */
 int mmd_op_gemm_last_plan(mmd_ctx* ctx, int* out4);
+/* a producer GEMM and its ONLY consumer: T = epi1(X[M,K1] . W1[N1,K1]^T + b1), Y[M,N2] = T . W2[N2,T]^T (+ R).  piece_major != 0 lets the intermediate live in the ring
+ * kernel's piece-major activation layout when both GEMMs take that kernel (what the tower's fc1 -> fc2 and a chunk's gate_up -> down do inside the model); *used_pm_out says
+ * whether it did.  Same bits either way. */
+int mmd_op_gemm_pair(mmd_ctx* ctx, const void* X, const void* W1, const void* b1, int epi1, const void* W2, const void* R, void* Y, int M, int N1, int K1, int N2,
+                     int piece_major, int* used_pm_out);
 /* the weight-streaming GEMMs in slab mode (what the fused LLM schedule launches for M <= 256): `*splits_out` fp32 partial slabs [splits][M][N] of X . W^T in slabs_out
  * (device, room for max_splits slabs); variant 2 = the dispatcher's choice by M (gemv16 / skinny / stream), 8 = gemm_stream_kernel */
 int mmd_op_gemm_slabs(mmd_ctx* ctx, const void* X, const void* W, int M, int N, int K, int variant, float* slabs_out, int max_splits, int* splits_out);
@@ -259,10 +264,15 @@ int mmd_op_resid32_layernorm(mmd_ctx* ctx, const void* y16, float* h32, const vo
 int mmd_op_rope_append(mmd_ctx* ctx, void* qkv, int S, int nh, int nkv, int d, float theta, int64_t pos0, void* q_out,
                        void* Kc, void* Vc, int64_t cap);
 /* causal GQA attention with query offset: q [S, nh*d], Kc/Vc [nkv, cap, d], n_ctx = tokens before this step;
- * out [S, nh*d].  causal = 0 -> full attention over n_ctx + S keys.  variant: 0 auto, 1 simple, 2 mfma. */
+ * out [S, nh*d].  causal = 0 -> full attention over n_ctx + S keys.  variant: 0 auto, 1 simple, 2 mfma, 3 the arena kernels (attn_gqa128_kernel), 4 row-major
+ * K / V (the tower's), 5 attn_gqa128_w1_kernel. */
 int mmd_op_attention(mmd_ctx* ctx, const void* q, const void* Kc, const void* Vc, void* out, int S, int nh, int nkv, int d,
                      int64_t n_ctx, int64_t cap, int causal, int variant);
 int mmd_op_attention_bench(mmd_ctx* ctx, int S, int nh, int nkv, int d, int64_t n_ctx, int variant, int iters, float* avg_ms_out);
+/* which attention form the most recent launch of this process took (what mmd_op_gemm_last_plan is for the GEMMs: parity tests assert that the production kernel really
+ * ran): 1 one wave per row, 2 16-row MFMA tiles, 3 / 4 attn_gqa128_kernel with 16- / 32-row waves (decode and two-slot forms / 256-row phase-split chunks), 5
+ * attn_gqa128_w1_kernel (per-frame steps, short chunks), 6 register-staged row-major (ViT), 7 attn_d72_ring_kernel (SigLIP-so400m); out2 = {form, key splits} */
+int mmd_op_attention_last_form(int* out2);
 int mmd_op_pool(mmd_ctx* ctx, const void* x, void* y, int B, int grid, int H, int mode, int stride);
 
 #ifdef __cplusplus

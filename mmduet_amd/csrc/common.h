@@ -9,6 +9,7 @@ typedef uint16_t bf16_t;   // raw bfloat16 storage
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
@@ -140,11 +141,13 @@ struct GemmArgs {
     int ring_max_blocks = 0;                    // > 0: cap on the persistent grid (co-residency experiments: leave CU resources to another stream)
     const GemvChain* chain = nullptr;           // gemv16 path only (M <= 16, packed bf16 / fp8 weights); see GemvChain
     int* plan_out = nullptr;                    // if set: int[4] = {kernel (GEMM_K_*), output tiles, K splits, blocks launched}
+    int x_pm = 0, y_pm = 0;                     // X is / Y becomes a PIECE-MAJOR activation ([M/16][K/32] pieces of 16 rows x 32 elements, gemm_ringx_kernel): ring GEMMs only -- ask gemm_ring_auto first
     int f16 = 0;                                // operands, bias, residual and output are IEEE half (launch_gemm(MMD_F16, ...): the fp16 vision tower; ring / big kernels only)
 };
 // which kernel the dispatcher chose (mmd_op_gemm_last_plan; parity tests assert the production kernel really ran)
 enum { GEMM_K_TILE64 = 0, GEMM_K_TILE128 = 1, GEMM_K_SKINNY = 2, GEMM_K_GEMV16 = 3, GEMM_K_BIG64 = 4, GEMM_K_BIG128 = 5, GEMM_K_RING256 = 6, GEMM_K_RING128X2 = 7, GEMM_K_STREAM = 8 };
 bool gemm_can_slab(int dtype, const GemmArgs& a);
+bool gemm_ring_auto(int dtype, const GemmArgs& a);          // would the automatic dispatch run this GEMM on gemm_ringx_kernel (plain or split-K)?  (what a piece-major operand needs)
 
 // launchers (dtype = mmd_dtype).  All return hipError_t of the launch.
 hipError_t launch_gemm(int dtype, const GemmArgs& a, hipStream_t st, int* kind_out);

@@ -14,7 +14,6 @@
 #include <type_traits>
 
 #include "gemm_ring.h"
-#include "gemm_ringw.h"
 
 template <typename T> struct Frag;
 template <> struct Frag<bf16_t> { using type = bf16x8_t; static constexpr int KSTEP = 32; };
@@ -900,14 +899,13 @@ static void launch_gemv16(const GemmP& p, const GemmArgs& a, hipStream_t st) {
 
 // gemm_stream_kernel: 32 < M <= 256, packed bf16 weights, slab output (fused consumers) or the SwiGLU epilogue.  K must be a whole number of steps.
 static bool stream_ok(int dtype, const GemmArgs& a) {
-    static const bool off = getenv("MMDUET_NO_STREAM") != nullptr;
-    if (off || dtype != MMD_BF16 || a.f16 || !a.Wp || a.M <= 32 || a.M > 256 || (a.N % 16) != 0 || (a.ldx % 8) != 0 || ((uintptr_t)a.X % 16) != 0 || a.out_f32) return false;
+    if (dtype != MMD_BF16 || a.f16 || !a.Wp || a.M <= 32 || a.M > 256 || (a.N % 16) != 0 || (a.ldx % 8) != 0 || ((uintptr_t)a.X % 16) != 0 || a.out_f32) return false;
     if (a.Wp8 && a.M <= 64) return false;                                  // fp8 builds keep the 1-byte skinny kernel where it exists
     if ((long long)a.M * a.ldx * 2 >= (1ll << 32)) return false;            // X addressed as base + 32-bit offset
     const int ksb = a.M <= 128 ? 4 : 2;          // k-tiles per step of the instantiation that serves this M
     if ((a.K % (ksb * 32)) != 0) return false;
     if (a.epi == EPI_SWIGLU) return (a.N % 32) == 0 && !a.slabs_out;
-    if (a.slabs_out) return a.splitk_ws != nullptr && a.epi == EPI_NONE;
+    if (a.slabs_out) return a.splitk_ws != nullptr && a.epi == EPI_NONE && (size_t)a.M * a.N * sizeof(float) <= a.splitk_ws_bytes;          // (even ONE slab must fit)
     // epilogue in place (unfused schedule, several streams per forward): the same K split into the workspace, then the serial slab reduce applies bias / residual / activation --
     // slab for slab what the fused consumers do, so both schedules produce the same bits
     return a.splitk_ws != nullptr && (a.N % 4) == 0 && (a.ldy % 4) == 0 && (a.epi != EPI_RESID || (a.ldr % 4) == 0);
@@ -1280,76 +1278,18 @@ static hipError_t launch_ringx_dbg(const GemmP& p, const GemmArgs& a, hipStream_
     return hipGetLastError();
 }
 #endif
-// flags: bit 0 = 4-wave 256x128 blocks (two per CU), bit 1 = 32x32x16 MFMA, bit 3 = 4-slot ring, bit 4 = refill DMAs in the first rows of a step
+// flags: 16 = 8 waves, 256 x 256 tiles, three-slot ring, refill DMAs in the first rows of a step (every tower / projector GEMM, gate_up and split-K down of a chunk);
+//        17 = 4 waves, 256 x 128 tiles, two blocks per CU (a chunk's qkv / o_proj where 256 x 256 tiles cannot fill the chip).  The other instantiations the template was
+//        built to test (late refill, 32x32x16 MFMA, four slots) lost their A/B (header of gemm_ringx_kernel) and are no longer compiled into the library.
 static hipError_t launch_ringx(int flags, const GemmP& p, const GemmArgs& a, hipStream_t st, int splits = 1) {
-    const int f = flags & 27;
     if (a.f16) return launch_ringx_t<4, false, 3, true, true>(p, a, st, 1);          // the fp16 tower runs the shipped instantiation
-    if ((flags & 32) && f == 1) return launch_ringx_t<2, false, 3, false>(p, a, st, splits, false);
-    if ((flags & 32) && f == 17) return launch_ringx_t<2, false, 3, true>(p, a, st, splits, false);
-    switch (f) {
-        case 0: return launch_ringx_t<4, false, 3, false>(p, a, st, splits);
-        case 1: return launch_ringx_t<2, false, 3, false>(p, a, st, splits);
-        case 2: return launch_ringx_t<4, true, 3, false>(p, a, st, splits);
-        case 3: return launch_ringx_t<2, true, 3, false>(p, a, st, splits);
-        case 8: return launch_ringx_t<4, false, 4, false>(p, a, st, splits);
+    switch (flags & 27) {
         case 16: return launch_ringx_t<4, false, 3, true>(p, a, st, splits);
         case 17: return launch_ringx_t<2, false, 3, true>(p, a, st, splits);
-        case 24: return launch_ringx_t<4, false, 4, true>(p, a, st, splits);
-        case 26: return launch_ringx_t<4, true, 4, true>(p, a, st, splits);
         default: return hipErrorInvalidValue;
     }
 }
 
-// gemm_ringw_kernel (W fragments straight from L2 into registers, X-only LDS ring): which = 0 (3 slots, 3 W buffers), 1 (4 slots, 2 buffers)
-template <int NS, int NB, bool F16>
-static hipError_t launch_ringw_t(const GemmP& p, const GemmArgs& a, hipStream_t st, int splits) {
-    if (F16) splits = 1;
-    while (splits > 1 && (a.epi == EPI_SWIGLU || !a.splitk_ws || (size_t)splits * a.M * a.N * sizeof(float) > a.splitk_ws_bytes)) --splits;
-    const int tiles = cdiv(a.N, 256) * cdiv(a.M, 256);
-    const int cap = a.ring_max_blocks > 0 && a.ring_max_blocks < 256 ? a.ring_max_blocks : 256;
-    dim3 grid(splits > 1 || tiles <= cap ? tiles : cap, 1, splits);
-    set_plan(a, GEMM_K_RING256, tiles, splits, (int)grid.x * splits);
-    const size_t smem = (size_t)NS * 256 * 32 * sizeof(bf16_t) + 16 * 1024;         // X ring + two 1 KB transposition slots per wave
-    const int KT = a.K >> 5;
-    const dim3 block(512);
-    GemmP q = p;
-    q.dump = ring_dump_slot();
-    if (!q.dump) return hipErrorOutOfMemory;
-    static const int direct_stores = getenv("MMDUET_RINGW_DIRECT_STORES") ? atoi(getenv("MMDUET_RINGW_DIRECT_STORES")) : 0;          // A/B switches
-    static const int dephase = getenv("MMDUET_RINGW_DEPHASE") ? atoi(getenv("MMDUET_RINGW_DEPHASE")) : 0;          // (measured: no difference once the stores are lane-adjacent)
-    q.flags = direct_stores ? 1 : 0;
-    // blocks that own one tile fewer start ~half a tile late (a K step ~ 0.8 us, a sleep unit ~ 4 us)
-    q.kper = (dephase && splits == 1 && tiles > (int)grid.x) ? (int)((a.K / 32) * 0.8 * 0.5 / 4.0 * dephase + 0.5) : 0;
-    if (smem > 65536) {
-        static bool attr_set[64] = {};
-        int adev = 0; hipGetDevice(&adev);
-        if (adev >= 0 && adev < 64 && !attr_set[adev]) {
-#define RW_ATTR(E) hipFuncSetAttribute((const void*)gemm_ringw_kernel<E, NS, NB, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            RW_ATTR(EPI_NONE) RW_ATTR(EPI_GELU_TANH) RW_ATTR(EPI_RESID)
-            if constexpr (!F16) { RW_ATTR(EPI_GELU_ERF) RW_ATTR(EPI_SWIGLU) }
-#undef RW_ATTR
-            attr_set[adev] = true;
-        }
-    }
-    switch (a.epi) {
-        case EPI_GELU_TANH: hipLaunchKernelGGL((gemm_ringw_kernel<EPI_GELU_TANH, NS, NB, F16>), grid, block, smem, st, q, KT); break;
-        case EPI_RESID: hipLaunchKernelGGL((gemm_ringw_kernel<EPI_RESID, NS, NB, F16>), grid, block, smem, st, q, KT); break;
-        case EPI_NONE: hipLaunchKernelGGL((gemm_ringw_kernel<EPI_NONE, NS, NB, F16>), grid, block, smem, st, q, KT); break;
-        case EPI_GELU_ERF: if constexpr (!F16) { hipLaunchKernelGGL((gemm_ringw_kernel<EPI_GELU_ERF, NS, NB, false>), grid, block, smem, st, q, KT); break; } else return hipErrorInvalidValue;
-        case EPI_SWIGLU: if constexpr (!F16) { hipLaunchKernelGGL((gemm_ringw_kernel<EPI_SWIGLU, NS, NB, false>), grid, block, smem, st, q, KT); break; } else return hipErrorInvalidValue;
-        default: return hipErrorInvalidValue;
-    }
-    if (splits > 1) {
-        if (a.ring_slabs_out) { *a.ring_slabs_out = splits; return hipGetLastError(); }
-        long long work = (long long)a.M * ((a.N + 3) / 4);
-        hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), dim3(cdiv(work, 256)), dim3(256), 0, st, p, splits);
-    }
-    return hipGetLastError();
-}
-static hipError_t launch_ringw(int which, const GemmP& p, const GemmArgs& a, hipStream_t st, int splits = 1) {
-    if (a.f16) return which == 1 ? launch_ringw_t<4, 2, true>(p, a, st, 1) : launch_ringw_t<3, 3, true>(p, a, st, 1);
-    return which == 1 ? launch_ringw_t<4, 2, false>(p, a, st, splits) : launch_ringw_t<3, 3, false>(p, a, st, splits);
-}
 
 // the ring GEMM addresses its operands as uniform base + 32-bit byte offset
 static bool ring_size_ok(const GemmArgs& a) { return (long long)a.M * a.ldx * 2 < (1ll << 32) && (long long)a.N * a.K * 2 < (1ll << 32); }
@@ -1368,12 +1308,30 @@ static bool skinny_packed_ok(int dtype, const GemmArgs& a) {
            ((uintptr_t)a.X % 16) == 0 && (a.epi != EPI_SWIGLU || (a.N % 32) == 0);
 }
 
+// the two automatic ring conditions of launch_t (kept in one place: the model asks before it lays an activation out piece-major)
+static bool ring256_auto(const GemmArgs& a) {
+    return a.M >= 512 && (a.N % 32) == 0 && big_packed_ok(MMD_BF16, a, 16) && ring_size_ok(a) && ring_tiles_ok((long long)cdiv(a.M, 256) * cdiv(a.N, 256));
+}
+static bool ring256_split_auto(const GemmArgs& a) {
+    if (a.f16 || !(a.M >= 512 && a.K >= 8192 && big_packed_ok(MMD_BF16, a, 16) && (a.N % 32) == 0 && a.epi != EPI_SWIGLU && a.splitk_ws != nullptr && ring_size_ok(a))) return false;
+    const int t256 = cdiv(a.M, 256) * cdiv(a.N, 256);
+    int sp = 256 / t256; if (sp < 1) sp = 1;
+    while (sp > 1 && a.K / sp < 1024) --sp;
+    while (sp > 1 && (size_t)sp * a.M * a.N * sizeof(float) > a.splitk_ws_bytes) --sp;
+    return sp >= 2;
+}
+bool gemm_ring_auto(int dtype, const GemmArgs& a) {
+    if (dtype != MMD_BF16 && dtype != MMD_F16) return false;
+    GemmArgs b = a; b.f16 = dtype == MMD_F16;
+    if (b.variant != GEMM_AUTO || b.wscale) return false;
+    return ring256_auto(b) || ring256_split_auto(b);
+}
 template <typename T>
 static hipError_t launch_t(const GemmArgs& a, hipStream_t st, int* kind_out) {
     GemmP p;
     p.X = a.X; p.W = a.W; p.bias = a.bias; p.R = a.R; p.Y = a.Y; p.ws = a.splitk_ws; p.wscale = a.wscale;
     p.ldx = a.ldx; p.ldw = a.ldw; p.ldr = a.ldr; p.ldy = a.ldy;
-    p.M = a.M; p.N = a.N; p.K = a.K; p.epi = a.epi; p.out_f32 = a.out_f32; p.slabs = a.slabs_out ? 1 : 0; p.dump = nullptr; p.flags = 0; p.kper = 0;
+    p.M = a.M; p.N = a.N; p.K = a.K; p.epi = a.epi; p.out_f32 = a.out_f32; p.slabs = a.slabs_out ? 1 : 0; p.dump = nullptr; p.flags = 0; p.kper = 0; p.x_pm = a.x_pm; p.y_pm = a.y_pm;
     p.vec = (sizeof(T) == 2 && (a.ldx % 8) == 0 && (a.ldw % 8) == 0 && ((uintptr_t)a.X % 16) == 0 && ((uintptr_t)a.W % 16) == 0) ? 1 : 0;
     if (a.ring_slabs_out) *a.ring_slabs_out = 0;
     if (a.M <= 0 || a.N <= 0) return hipSuccess;
@@ -1381,6 +1339,9 @@ static hipError_t launch_t(const GemmArgs& a, hipStream_t st, int* kind_out) {
     bool skinny = (variant == GEMM_SKINNY) || (variant == GEMM_AUTO && a.M <= 64);
     bool large = (variant == GEMM_LARGE) || (variant == GEMM_AUTO && a.M >= 256 && a.N >= 128);
     if (kind_out) *kind_out = skinny ? MMD_K_GEMM_SKINNY : MMD_K_GEMM_TILE;
+    if ((a.x_pm || a.y_pm) && (sizeof(T) != 2 || variant != GEMM_AUTO || !(ring256_auto(a) || ring256_split_auto(a)) || a.wscale ||
+                               (a.x_pm && (a.K % 32)) || (a.y_pm && ((a.epi == EPI_SWIGLU ? a.N / 2 : a.N) % 32))))
+        return hipErrorInvalidValue;          // a piece-major operand exists for the ring kernel only (the caller asks gemm_ring_auto first)
     if constexpr (sizeof(T) == 2) {
         // the weight-streaming regime above the GEMV's 16 rows: per-frame steps, short chunks (gemm_stream_kernel); slab consumers or the SwiGLU epilogue
         if ((variant == GEMM_AUTO || variant == GEMM_SKINNY || variant == GEMM_STREAM) && stream_ok(MMD_BF16, a)) {
@@ -1410,22 +1371,16 @@ static hipError_t launch_t(const GemmArgs& a, hipStream_t st, int* kind_out) {
         }
 #endif
         // 256^2 tiles pay once there are ~1.5 block waves of them (every ViT / projector GEMM, gate_up of a >= 600-row chunk)
-        if (variant == GEMM_RING256 || (variant == GEMM_AUTO && a.M >= 512 && (a.N % 32) == 0 && big_packed_ok(MMD_BF16, a, 16) && ring_size_ok(a) &&
-                                        ring_tiles_ok((long long)cdiv(a.M, 256) * cdiv(a.N, 256)) && !getenv("MMDUET_NO_RING256"))) {
+        if (variant == GEMM_RING256 || (variant == GEMM_AUTO && ring256_auto(a))) {
             if (!big_packed_ok(MMD_BF16, a, 16) || (a.N % 32) != 0 || !ring_size_ok(a)) return hipErrorInvalidValue;
             p.W = a.Wp;
             if (kind_out) *kind_out = MMD_K_GEMM_TILE;
-            // gemm_ringw_kernel (W operand straight to registers, lane-adjacent output stores) is 5-7 % faster than the ring on the tower's short-K shapes in isolation
-            // (qkv 188 -> 175 us, o 67 -> 63, fc1 265 -> 252: profiles/r04_ringw_ab.json) and loses 5-9 % where W is streamed from HBM or K is long (fc2, gate_up, 8192^3).
-            // Inside the model the stream is +-0.5 % either way (profiles/r04_gemm_experiments.md): it stays OPT-IN (MMDUET_RINGW=1), the shipped tower runs the ring.
-            static const bool use_ringw = getenv("MMDUET_RINGW") != nullptr && atoi(getenv("MMDUET_RINGW")) != 0;
-            if (variant == GEMM_AUTO && use_ringw && a.ring_flags == 16 && !a.wscale && a.K <= 2048 && (long long)a.N * a.K * 2 <= (48ll << 20)) return launch_ringw(0, p, a, st);
             return launch_ringx(a.ring_flags, p, a, st);
         }
         // long K with under one block wave of 256^2 tiles (down_proj of a chunk): split K across grid.z so ~one block per CU runs a
         // long steady state (1.05 PF at M = 1274 against 0.84 PF for the 128-row kernel's 3-way split); K = 3584 shapes lose to it
         const bool ring_split_ok = big_packed_ok(MMD_BF16, a, 16) && (a.N % 32) == 0 && a.epi != EPI_SWIGLU && a.splitk_ws != nullptr && ring_size_ok(a);
-        if (!a.f16 && (variant == GEMM_RING256_SPLIT || (variant == GEMM_AUTO && a.M >= 512 && a.K >= 8192 && ring_split_ok && !getenv("MMDUET_NO_RING256")))) {
+        if (!a.f16 && (variant == GEMM_RING256_SPLIT || (variant == GEMM_AUTO && a.M >= 512 && a.K >= 8192 && ring_split_ok))) {
             if (variant == GEMM_RING256_SPLIT && (!big_packed_ok(MMD_BF16, a, 16) || (a.N % 32) != 0 || !ring_size_ok(a))) return hipErrorInvalidValue;
             const int t256 = cdiv(a.M, 256) * cdiv(a.N, 256);
             int sp = 256 / t256; if (sp < 1) sp = 1;
@@ -1457,15 +1412,6 @@ static hipError_t launch_t(const GemmArgs& a, hipStream_t st, int* kind_out) {
             return variant == 96 ? launch_ringx_dbg<1>(p, a, st) : (variant == 97 ? launch_ringx_dbg<2>(p, a, st) : launch_ringx_dbg<3>(p, a, st));
         }
 #endif
-        if (variant >= GEMM_RINGW && variant < GEMM_RINGW + 8) {          // forced gemm_ringw instantiations: + 0 / 1 = (3,3) / (4,2) slots, W buffers; + 4: split K
-            if (!big_packed_ok(MMD_BF16, a, 16) || (a.N % 32) != 0 || !ring_size_ok(a) || a.wscale) return hipErrorInvalidValue;          // (no per-channel weight scale in this kernel: its shapes are the tower's)
-            const int w = (variant - GEMM_RINGW) & 3;
-            int sp = 1;
-            if ((variant - GEMM_RINGW) & 4) { sp = 256 / (cdiv(a.M, 256) * cdiv(a.N, 256)); if (sp < 2) sp = 2; while (sp > 2 && a.K / sp < 1024) --sp; }
-            p.W = a.Wp;
-            if (kind_out) *kind_out = MMD_K_GEMM_TILE;
-            return launch_ringw(w == 1 ? 1 : 0, p, a, st, sp);
-        }
         if (variant >= GEMM_RINGX && variant < GEMM_RINGX + 128) {          // forced ring variants (A/B and parity of every instantiation)
             if (!big_packed_ok(MMD_BF16, a, 16) || (a.N % 32) != 0 || !ring_size_ok(a)) return hipErrorInvalidValue;
             const int flags = variant - GEMM_RINGX;
@@ -1491,8 +1437,7 @@ static hipError_t launch_t(const GemmArgs& a, hipStream_t st, int* kind_out) {
             // mid-M (a chunk's qkv / o_proj): once some CU would carry three or more 128-row blocks, one 256x128 ring tile per CU (4-wave ring, flags 17) is the
             // shorter schedule.  Per-CU cost in units of one 128x64 block at two per CU (17.5 us at K = 3584), fitted to tools/probes/midm_ring4w_sweep.py:
             // n blocks of 128x64 cost max(1.83, n), of 128x128 max(2.29, 1.77 n), a 256x128 ring tile 2.95 (M = 1323 qkv 75 -> 51 us, M = 1911 o 63 -> 58 us)
-            static const bool no_r4 = getenv("MMDUET_NO_RING4W") != nullptr;
-            if (bn && variant == GEMM_AUTO && !a.f16 && !no_r4 && a.M >= 512 && a.K >= 1024 && (a.N % 128) == 0 && big_packed_ok(MMD_BF16, a, 16) && ring_size_ok(a)) {
+            if (bn && variant == GEMM_AUTO && !a.f16 && a.M >= 512 && a.K >= 1024 && (a.N % 128) == 0 && big_packed_ok(MMD_BF16, a, 16) && ring_size_ok(a)) {
                 const long long mt128 = cdiv(a.M, 128);
                 const double nb = bn == 64 ? (double)cdiv(mt128 * (a.N / 64), 256) : (double)cdiv(t128, 256);
                 const double cbig = bn == 64 ? (nb > 1.83 ? nb : 1.83) : (1.77 * nb > 2.29 ? 1.77 * nb : 2.29);

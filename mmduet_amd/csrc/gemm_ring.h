@@ -13,7 +13,8 @@ struct GemmP {
     int M, N, K, epi, out_f32, kper, vec;
     int slabs;         // skinny kernel: always leave fp32 slabs in ws (the consumer kernel reduces them)
     void* dump;        // ring kernel: 8 KB nobody reads -- masked output lanes store here (a per-device buffer of the launcher, never the split-K workspace)
-    int flags;         // gemm_ringw_kernel: bit 0 = output stores straight from the accumulator layout (A/B switch of the lane-adjacent epilogue)
+    int flags;         // (unused)
+    int x_pm, y_pm;    // ring kernel: X / Y in the PIECE-MAJOR activation layout (see gemm_ringx_kernel): piece (m >> 4, k >> 5) = 16 rows x 32 elements = 1 KB contiguous
 };
 
 // guard-free epilogue of the big-tile kernel: N % BN == 0, ldy/ldr % 4 == 0 (dispatch conditions), one 8-byte access
@@ -120,6 +121,11 @@ __device__ __forceinline__ void big_store_swiglu(const GemmP& p, int m, int n_ga
 // the epilogue exchanges neighbouring column groups across lanes (v_permlane16/32_swap) so every lane stores 16 contiguous bytes.
 // Tile order: bijective XCD remap, then bands of up to 8 m-tiles swept m-fastest (for N > M this is the W-panel-stationary order).
 //
+// Piece-major activations (round 5; GemmP::x_pm / y_pm): an intermediate with ONE producer and ONE consumer that are both this kernel (the tower's fc1 + GELU -> fc2,
+// gate_up + SwiGLU -> down of a chunk) is stored as [M / 16][N / 32] pieces of 16 rows x 32 elements, 1 KB contiguous each, rows of 64 B inside.  The epilogue's wave
+// instruction already writes exactly one such piece (16 rows x 64 B: 16 scattered row segments in the row-major form, one contiguous 1 KB burst here: the store probe of round 4
+// measured 3.40 against 5.71 us per 33.5 MB), and the consumer's X piece is the same 1 KB run (16 row segments of 64 B in the row-major form).  Same values in other places.
+//
 // Shipped instantiation: WN = 4 (8 waves, 256 x 256), 16x16x32 MFMA, NS = 3, EARLY (the refill DMAs in the FIRST rows of a step).
 // What the template parameters were built to test, on random operands, within one process (profiles/r02_gemm_shapes.json):
 //   EARLY  refill DMAs issued right after the barrier instead of in the last rows: +3-5 % (1.20 -> 1.25 PF on gate_up at M = 1274).
@@ -184,10 +190,16 @@ __global__ __launch_bounds__(WN * 128, 2) void gemm_ringx_kernel(GemmP p, int KT
     // DMA, one VGPR per X piece and none per W piece -- a W piece is 1 KB contiguous, lane l reads bytes 16 l..).  Operand sizes under 4 GB are a dispatch condition.
     unsigned xo[XP]; long long wo[WP];
     const unsigned wlane = lane * 16;
+    const int xstep = p.x_pm ? 1024 : BK * 2;          // bytes from one K slice of an X piece to the next
     auto tile_sources = [&]() {
 #pragma unroll
         for (int j = 0; j < XP; ++j) {
             const int pi = wave + NW * j;
+            if (p.x_pm) {          // piece-major X: the whole piece is ONE contiguous 1 KB run (row group clamped to the last one; its rows past M are never-written memory that only feeds masked output rows)
+                int grp = (m0 >> 4) + pi; const int gmax = (p.M - 1) >> 4; grp = grp < gmax ? grp : gmax;
+                xo[j] = (unsigned)(grp * (p.K >> 5)) * 1024u + (unsigned)(srow * 64 + ((spos ^ sswz) * 16));
+                continue;
+            }
             int row = m0 + pi * 16 + srow; row = row < p.M ? row : p.M - 1;
             xo[j] = (unsigned)(row * (int)p.ldx + ((spos ^ sswz) * 8)) * 2u;
         }
@@ -205,7 +217,7 @@ __global__ __launch_bounds__(WN * 128, 2) void gemm_ringx_kernel(GemmP p, int KT
                                              (__attribute__((address_space(3))) void*)(lds + slot * SE + (wave + NW * j) * 512), 16, 0, 0);
             return;
         }
-        const char* ub = (const char*)X + (long long)(t0 + step) * (BK * 2);
+        const char* ub = (const char*)X + (long long)(t0 + step) * xstep;
         asm volatile("" : "+s"(ub));          // keep base + zext(offset) as written (hipcc would hoist X + offset into a 64-bit VGPR pair per piece and add the K step there)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ub + xo[j]),
                                          (__attribute__((address_space(3))) void*)(lds + slot * SE + (wave + NW * j) * 512), 16, 0, 0);
@@ -414,8 +426,10 @@ __global__ __launch_bounds__(WN * 128, 2) void gemm_ringx_kernel(GemmP p, int KT
                     const int ns0 = min(nb, p.N - 32) + lq * 4, ns1 = min(nb + 32, p.N - 32) + lq * 4;      // N tail: clamp the scale reads
                     const s16x8_t v = pair_to_row8(big_value_swiglu(acc[i][0], acc[i][1], p.wscale, ns0), big_value_swiglu(acc[i][2], acc[i][3], p.wscale, ns1));
                     const bool ok = m < p.M && nb + 32 * (lq & 1) + 32 <= p.N;
-                    if constexpr (PST) *reinterpret_cast<s16x8_t*>(ok ? (bf16_t*)p.Y + (long long)m * p.ldy + ob + (lq & 1) * 16 + (lq >> 1) * 8 : dump) = v;
-                    else if (ok) *reinterpret_cast<s16x8_t*>((bf16_t*)p.Y + (long long)m * p.ldy + ob + (lq & 1) * 16 + (lq >> 1) * 8) = v;
+                    bf16_t* const yd = p.y_pm ? (bf16_t*)p.Y + ((long long)(m >> 4) * (p.N >> 6) + (ob >> 5)) * 512 + lr * 32 + (lq & 1) * 16 + (lq >> 1) * 8
+                                              : (bf16_t*)p.Y + (long long)m * p.ldy + ob + (lq & 1) * 16 + (lq >> 1) * 8;          // piece-major: this wave instruction writes ONE contiguous 1 KB piece
+                    if constexpr (PST) *reinterpret_cast<s16x8_t*>(ok ? yd : dump) = v;
+                    else if (ok) *reinterpret_cast<s16x8_t*>(yd) = v;
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; j += 2) {
@@ -424,8 +438,10 @@ __global__ __launch_bounds__(WN * 128, 2) void gemm_ringx_kernel(GemmP p, int KT
                         if constexpr (DBG == 6) { const u32x4_t w = __builtin_bit_cast(u32x4_t, v); asm volatile("" :: "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3])); }      // timing only: converted, not stored
                         else {
                             const bool ok = m < p.M && nb + 16 * (lq & 1) + 16 <= p.N;
-                            if constexpr (PST) *reinterpret_cast<s16x8_t*>(ok ? (bf16_t*)p.Y + (long long)m * p.ldy + nb + (lq & 1) * 16 + (lq >> 1) * 8 : dump) = v;
-                            else if (ok) *reinterpret_cast<s16x8_t*>((bf16_t*)p.Y + (long long)m * p.ldy + nb + (lq & 1) * 16 + (lq >> 1) * 8) = v;
+                            bf16_t* const yd = p.y_pm ? (bf16_t*)p.Y + ((long long)(m >> 4) * (p.N >> 5) + (nb >> 5)) * 512 + lr * 32 + (lq & 1) * 16 + (lq >> 1) * 8
+                                                      : (bf16_t*)p.Y + (long long)m * p.ldy + nb + (lq & 1) * 16 + (lq >> 1) * 8;
+                            if constexpr (PST) *reinterpret_cast<s16x8_t*>(ok ? yd : dump) = v;
+                            else if (ok) *reinterpret_cast<s16x8_t*>(yd) = v;
                         }
                     }
                 }

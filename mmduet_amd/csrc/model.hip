@@ -88,8 +88,9 @@ struct mmd_ctx {
     float dec_pen = 0.f; int64_t dec_eos = 0; bool no_graph = false;
     int last_plan[4] = {-1, 0, 0, 0};   // kernel / tiles / splits / blocks of the most recent gemm() (mmd_op_gemm_last_plan)
     bool no_fuse = false;              // MMDUET_NO_FUSE=1: keep the unfused launch schedule (A/B and parity cross-check)
+    bool no_pm = false;                // MMDUET_NO_FUSE=1 | 2: MLP intermediates stay row-major (gemm_pair_pm)
     bool gemm_half = false;            // the GEMMs issued right now belong to the fp16 vision tower (cfg.tower_f16): IEEE-half operands
-    int tower_ring_flags = -1, tower_ring_blocks = 0;   // MMDUET_TOWER_RING / MMDUET_TOWER_RING_BLOCKS: ring GEMM form of the tower (co-residency experiments)
+    int tower_ring_flags = -1, tower_ring_blocks = 0;   // mmd_set_tower_share: persistent-grid cap of the tower's ring GEMMs beside a response's decoding
     int hid_compact = 0;               // > 0: l_hid holds that many compact rows (in the order of the `need` list) instead of all S rows of the step
     bool full_tower = false;           // mmd_vit_set_full_tower(1): the last encoder layer runs on ALL tokens (feature extraction, debug taps); default: on the tokens the bilinear pool reads
     bool last_sparse = false;          // the most recent vit_tower ran its last layer on the pooled rows only (v_h then holds no full output: the debug taps refuse)
@@ -185,8 +186,8 @@ static void prof_drain(mmd_ctx* c) {
 // ---- GEMM wrapper --------------------------------------------------------------------------------------------------
 static int gemm(mmd_ctx* c, const void* X, int64_t ldx, const void* W, int64_t ldw, const void* bias, const void* R, int64_t ldr, void* Y,
                 int64_t ldy, int M, int N, int K, int epi, int out_f32 = 0, int variant = GEMM_AUTO, const void* Wp = nullptr, bool tower = false,
-                const void* Wp8 = nullptr, const float* wscale = nullptr, const GemvChain* chain = nullptr, int* ring_slabs_out = nullptr) {
-    GemmArgs a; a.chain = chain; a.ring_slabs_out = ring_slabs_out;
+                const void* Wp8 = nullptr, const float* wscale = nullptr, const GemvChain* chain = nullptr, int* ring_slabs_out = nullptr, int pm = 0) {
+    GemmArgs a; a.chain = chain; a.ring_slabs_out = ring_slabs_out; a.x_pm = pm & 1; a.y_pm = (pm >> 1) & 1;          // pm: 1 = X is piece-major, 2 = Y becomes piece-major (gemm_pair_pm)
     a.X = X; a.ldx = ldx; a.W = W; a.ldw = ldw; a.Wp = Wp; a.bias = bias; a.R = R; a.ldr = ldr; a.Y = Y; a.ldy = ldy;
     a.M = M; a.N = N; a.K = K; a.epi = epi; a.out_f32 = out_f32; a.variant = variant; a.Wp8 = Wp8; a.wscale = wscale;
     a.splitk_ws = tower ? c->v_splitk_ws : c->splitk_ws; a.splitk_ws_bytes = tower ? c->v_splitk_bytes : c->splitk_bytes;
@@ -198,6 +199,20 @@ static int gemm(mmd_ctx* c, const void* X, int64_t ldx, const void* W, int64_t l
     ProfScope ps(c, kind, bytes, 2.0 * M * N * K);
     HIPCHK(c, launch_gemm(c->gemm_half ? MMD_F16 : c->cfg.dtype, a, c->stream, nullptr));          // gemm_half: inside the fp16 vision tower (vit_tower sets it)
     return MMD_OK;
+}
+
+// May the intermediate between a producer GEMM (X1 [M,K1] -> T [M,N1], epilogue epi1) and its ONLY consumer (T -> [M,N2]) live in the ring kernel's piece-major layout?
+// Yes when the automatic dispatch runs BOTH on gemm_ringx_kernel (same conditions the launcher itself evaluates: gemm_ring_auto).
+static bool gemm_pair_pm(mmd_ctx* c, bool tower, const void* X1, int64_t ldx1, const void* W1p, const void* b1, int N1w, int K1, int epi1, void* T, int64_t ldt,
+                         const void* W2p, int N2, const void* R2, int64_t ldr2, void* Y2, int64_t ldy2, int epi2, int M) {
+    if (c->no_pm) return false;
+    const int dt = c->gemm_half ? MMD_F16 : c->cfg.dtype;
+    GemmArgs a; memset(&a, 0, sizeof(a)); a.ring_flags = 16;
+    a.X = X1; a.ldx = ldx1; a.Wp = W1p; a.bias = b1; a.Y = T; a.ldy = ldt; a.M = M; a.N = N1w; a.K = K1; a.epi = epi1; a.variant = GEMM_AUTO;
+    a.splitk_ws = tower ? c->v_splitk_ws : c->splitk_ws; a.splitk_ws_bytes = tower ? c->v_splitk_bytes : c->splitk_bytes;
+    GemmArgs b = a;
+    b.X = T; b.ldx = ldt; b.Wp = W2p; b.bias = nullptr; b.R = R2; b.ldr = ldr2; b.Y = Y2; b.ldy = ldy2; b.N = N2; b.K = (int)ldt; b.epi = epi2;
+    return gemm_ring_auto(dt, a) && gemm_ring_auto(dt, b);
 }
 
 // ---- create / destroy ------------------------------------------------------------------------------------------------
@@ -226,12 +241,11 @@ extern "C" int mmd_create(const mmd_config* cfg, int device, mmd_ctx** out) {
     c->vit_kpad = (int)round_up(3 * cfg->vit_patch * cfg->vit_patch, 64);
     c->vit_ipad = (int)round_up(cfg->vit_intermediate, 64);
     c->qkv_w = cfg->vision_only ? 0 : (cfg->num_heads + 2 * cfg->num_kv_heads) * cfg->head_dim;
-    { const char* nf = getenv("MMDUET_NO_FUSE"); c->no_fuse = nf && nf[0] == '1'; }
+    { const char* nf = getenv("MMDUET_NO_FUSE"); c->no_fuse = nf && nf[0] == '1'; c->no_pm = nf && (nf[0] == '1' || nf[0] == '2'); }          // (2: only the piece-major MLP intermediates off -- their A/B)
     { const char* nf = getenv("MMDUET_NO_CHAIN"); c->no_chain = nf && nf[0] == '1'; }
     { const char* nf = getenv("MMDUET_NO_SLAB_NORM"); c->no_slab_norm = nf && nf[0] == '1'; }
     { const char* nf = getenv("MMDUET_FULL_LAST_LAYER"); c->full_last_layer = nf && nf[0] == '1'; }
     { const char* nf = getenv("MMDUET_NO_ROPE_FUSE"); c->no_rope_fuse = nf && nf[0] == '1'; }
-    { const char* e = getenv("MMDUET_TOWER_RING"); if (e) c->tower_ring_flags = atoi(e); e = getenv("MMDUET_TOWER_RING_BLOCKS"); if (e) c->tower_ring_blocks = atoi(e); }
     // graph replay of the decode step is opt-in (MMDUET_GRAPH=1): measured on MI355X it is not faster than eager launches
     // from this C++ loop (458 vs 480-500 ms for 128 tokens) -- the step is bound by the ~1.5 us GPU-side kernel boundaries,
     // which a graph does not remove, not by host launch latency.
@@ -553,7 +567,7 @@ static int alloc_workspaces(mmd_ctx* c) {
         const int pout_ = (c->vit_grid + g.pool_stride - 1) / g.pool_stride;
         c->v_h32_rows = Mv; WS(c->v_h32, (size_t)(Mv + (int64_t)g.max_vit_batch * 4 * pout_ * pout_) * C * sizeof(float));
     }
-    WS(c->v_qkv, (size_t)Mv * 3 * C * e); WS(c->v_attn, (size_t)Mv * C * e); WS(c->v_mlp, (size_t)Mv * c->vit_ipad * e);
+    WS(c->v_qkv, (size_t)Mv * 3 * C * e); WS(c->v_attn, (size_t)Mv * C * e); WS(c->v_mlp, (size_t)round_up(Mv, 16) * c->vit_ipad * e);          // (rows padded to 16: the piece-major form of fc1's output holds whole 16-row pieces)
     if (g.vit_class_token) { WS(c->v_patch, (size_t)Mv * C * e); }
     c->v_splitk_bytes = (size_t)32 << 20; WS(c->v_splitk_ws, c->v_splitk_bytes);
     c->v_attn_bytes = (size_t)32 << 20; WS(c->v_attn_ws, c->v_attn_bytes);
@@ -567,7 +581,7 @@ static int alloc_workspaces(mmd_ctx* c) {
     int64_t S = round_up(g.max_step_tokens, 128);
     WS(c->l_h, (size_t)S * H * e); WS(c->l_xn, (size_t)S * H * e); WS(c->l_qkv, (size_t)S * c->qkv_w * e);
     WS(c->l_q, (size_t)S * g.num_heads * g.head_dim * e); WS(c->l_attn, (size_t)S * g.num_heads * g.head_dim * e);
-    WS(c->l_act, (size_t)S * g.intermediate_size * e); WS(c->l_hid, (size_t)S * H * e);
+    WS(c->l_act, (size_t)round_up(S, 16) * g.intermediate_size * e); WS(c->l_hid, (size_t)S * H * e);          // (l_act rows padded to 16: whole pieces in its piece-major form)
     c->splitk_bytes = (size_t)64 << 20; WS(c->splitk_ws, c->splitk_bytes);
     WS(c->chain_ssq, (size_t)GEMV_CHAIN_ROWS * GEMV_SSQ_STRIDE * sizeof(float)); WS(c->rope_tab, (size_t)S * 64 * 2 * sizeof(float));          // (cos, sin) of a step's positions: decode steps and, since round 3, chunks
     c->attn_bytes = (size_t)128 << 20; WS(c->attn_ws, c->attn_bytes);
@@ -618,10 +632,9 @@ static int vit_tower(mmd_ctx* c, const void* px, int B, bool col_ready = false, 
     // The bilinear pool behind the projector reads (2 out)^2 = 196 of a frame's 729 tokens, and everything after the LAST layer's K / V is row-wise: that layer's
     // queries, o_proj, LayerNorm, MLP (and the projector) run on those rows alone.  K and V still come from all tokens.  Same values into the same arithmetic;
     // callers that want the tower's full output (feature extraction, debug taps) switch it off with mmd_vit_set_full_tower.
-    static const bool no_sparse = getenv("MMDUET_FULL_PROJECTOR") != nullptr;
     const int pout = (c->vit_grid + g.pool_stride - 1) / g.pool_stride, U = 4 * pout * pout;
     // (the half forms of the kernels exist for M > 64 GEMMs and S >= 64 attention only: a compact block below that keeps the full last layer -- ADVICE r03)
-    const bool sparse_last = for_pool && !no_sparse && !c->full_tower && !c->full_projector && g.pool_mode == MMD_POOL_BILINEAR && U < T && TS == T && !g.vit_post_layernorm &&
+    const bool sparse_last = for_pool && !c->full_tower && !c->full_projector && g.pool_mode == MMD_POOL_BILINEAR && U < T && TS == T && !g.vit_post_layernorm &&
                              g.vit_act != 1 && g.vit_layers > 0 && !g.vision_only && (!g.tower_f16 || (U >= 64 && B * U > 64));
     c->last_sparse = sparse_last;
     c->tower_compact = false;
@@ -650,8 +663,9 @@ static int vit_tower(mmd_ctx* c, const void* px, int B, bool col_ready = false, 
                 float* hc32 = c->v_h32 + c->v_h32_rows * C;
                 rc = gemm(c, c->v_attn, C, L.wo, C, L.bo, nullptr, 0, c->v_xn, C, Mc, C, C, EPI_NONE, 0, GEMM_AUTO, L.wo_p, true); if (rc) return rc;
                 { ProfScope ps(c, MMD_K_NORM_ROPE, 12.0 * Mc * C, 0); HIPCHK(c, launch_resid32_layernorm(c->v_xn, hc32, nullptr, 1, L.ln2w, L.ln2b, c->v_xn, nullptr, Mc, C, g.vit_ln_eps, st)); }
-                rc = gemm(c, c->v_xn, C, L.w1, C, L.b1, nullptr, 0, c->v_mlp, c->vit_ipad, Mc, c->vit_ipad, C, EPI_GELU_TANH, 0, GEMM_AUTO, L.w1_p, true); if (rc) return rc;
-                rc = gemm(c, c->v_mlp, c->vit_ipad, L.w2, c->vit_ipad, L.b2, nullptr, 0, c->v_xn, C, Mc, C, c->vit_ipad, EPI_NONE, 0, GEMM_AUTO, L.w2_p, true); if (rc) return rc;
+                const bool pm = gemm_pair_pm(c, true, c->v_xn, C, L.w1_p, L.b1, c->vit_ipad, C, EPI_GELU_TANH, c->v_mlp, c->vit_ipad, L.w2_p, C, nullptr, 0, c->v_xn, C, EPI_NONE, Mc);
+                rc = gemm(c, c->v_xn, C, L.w1, C, L.b1, nullptr, 0, c->v_mlp, c->vit_ipad, Mc, c->vit_ipad, C, EPI_GELU_TANH, 0, GEMM_AUTO, L.w1_p, true, nullptr, nullptr, nullptr, nullptr, pm ? 2 : 0); if (rc) return rc;
+                rc = gemm(c, c->v_mlp, c->vit_ipad, L.w2, c->vit_ipad, L.b2, nullptr, 0, c->v_xn, C, Mc, C, c->vit_ipad, EPI_NONE, 0, GEMM_AUTO, L.w2_p, true, nullptr, nullptr, nullptr, nullptr, pm ? 1 : 0); if (rc) return rc;
                 { ProfScope ps(c, MMD_K_NORM_ROPE, 8.0 * Mc * C, 0); HIPCHK(c, launch_resid32_layernorm(c->v_xn, hc32, nullptr, 1, nullptr, nullptr, nullptr, hc, Mc, C, g.vit_ln_eps, st)); }          // -> bf16 features
                 c->tower_compact = true;
                 c->last_vit_B = B;
@@ -659,8 +673,9 @@ static int vit_tower(mmd_ctx* c, const void* px, int B, bool col_ready = false, 
             }
             rc = gemm(c, c->v_attn, C, L.wo, C, L.bo, hc, C, hc, C, Mc, C, C, EPI_RESID, 0, GEMM_AUTO, L.wo_p, true); if (rc) return rc;
             { ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * Mc * C * es(c), 0); HIPCHK(c, launch_layernorm(dt, hc, L.ln2w, L.ln2b, c->v_xn, Mc, C, g.vit_ln_eps, st)); }
-            rc = gemm(c, c->v_xn, C, L.w1, C, L.b1, nullptr, 0, c->v_mlp, c->vit_ipad, Mc, c->vit_ipad, C, EPI_GELU_TANH, 0, GEMM_AUTO, L.w1_p, true); if (rc) return rc;
-            rc = gemm(c, c->v_mlp, c->vit_ipad, L.w2, c->vit_ipad, L.b2, hc, C, hc, C, Mc, C, c->vit_ipad, EPI_RESID, 0, GEMM_AUTO, L.w2_p, true); if (rc) return rc;
+            const bool pm = gemm_pair_pm(c, true, c->v_xn, C, L.w1_p, L.b1, c->vit_ipad, C, EPI_GELU_TANH, c->v_mlp, c->vit_ipad, L.w2_p, C, hc, C, hc, C, EPI_RESID, Mc);
+            rc = gemm(c, c->v_xn, C, L.w1, C, L.b1, nullptr, 0, c->v_mlp, c->vit_ipad, Mc, c->vit_ipad, C, EPI_GELU_TANH, 0, GEMM_AUTO, L.w1_p, true, nullptr, nullptr, nullptr, nullptr, pm ? 2 : 0); if (rc) return rc;
+            rc = gemm(c, c->v_mlp, c->vit_ipad, L.w2, c->vit_ipad, L.b2, hc, C, hc, C, Mc, C, c->vit_ipad, EPI_RESID, 0, GEMM_AUTO, L.w2_p, true, nullptr, nullptr, nullptr, nullptr, pm ? 1 : 0); if (rc) return rc;
             if (g.tower_f16) { ProfScope ps(c, MMD_K_OTHER, 0, 0); HIPCHK(c, launch_convert(hc, MMD_F16, hc, MMD_BF16, (int64_t)Mc * C, st)); }
             c->tower_compact = true;
             c->last_vit_B = B;
@@ -679,8 +694,9 @@ static int vit_tower(mmd_ctx* c, const void* px, int B, bool col_ready = false, 
         if (r32) {
             rc = gemm(c, c->v_attn, C, L.wo, C, L.bo, nullptr, 0, c->v_xn, C, M, C, C, EPI_NONE, 0, GEMM_AUTO, L.wo_p, true); if (rc) return rc;
             { ProfScope ps(c, MMD_K_NORM_ROPE, 12.0 * M * C, 0); HIPCHK(c, launch_resid32_layernorm(c->v_xn, c->v_h32, nullptr, 1, L.ln2w, L.ln2b, c->v_xn, nullptr, M, C, g.vit_ln_eps, st)); }
-            rc = gemm(c, c->v_xn, C, L.w1, C, L.b1, nullptr, 0, c->v_mlp, c->vit_ipad, M, c->vit_ipad, C, EPI_GELU_TANH, 0, GEMM_AUTO, L.w1_p, true); if (rc) return rc;
-            rc = gemm(c, c->v_mlp, c->vit_ipad, L.w2, c->vit_ipad, L.b2, nullptr, 0, c->v_xn, C, M, C, c->vit_ipad, EPI_NONE, 0, GEMM_AUTO, L.w2_p, true); if (rc) return rc;
+            const bool pm = gemm_pair_pm(c, true, c->v_xn, C, L.w1_p, L.b1, c->vit_ipad, C, EPI_GELU_TANH, c->v_mlp, c->vit_ipad, L.w2_p, C, nullptr, 0, c->v_xn, C, EPI_NONE, M);
+            rc = gemm(c, c->v_xn, C, L.w1, C, L.b1, nullptr, 0, c->v_mlp, c->vit_ipad, M, c->vit_ipad, C, EPI_GELU_TANH, 0, GEMM_AUTO, L.w1_p, true, nullptr, nullptr, nullptr, nullptr, pm ? 2 : 0); if (rc) return rc;
+            rc = gemm(c, c->v_mlp, c->vit_ipad, L.w2, c->vit_ipad, L.b2, nullptr, 0, c->v_xn, C, M, C, c->vit_ipad, EPI_NONE, 0, GEMM_AUTO, L.w2_p, true, nullptr, nullptr, nullptr, nullptr, pm ? 1 : 0); if (rc) return rc;
             ProfScope ps(c, MMD_K_NORM_ROPE, 12.0 * M * C, 0);
             if (i + 1 < g.vit_layers) { HIPCHK(c, launch_resid32_layernorm(c->v_xn, c->v_h32, nullptr, 1, c->VL[i + 1].ln1w, c->VL[i + 1].ln1b, c->v_xn, nullptr, M, C, g.vit_ln_eps, st)); }
             else { HIPCHK(c, launch_resid32_layernorm(c->v_xn, c->v_h32, nullptr, 1, nullptr, nullptr, nullptr, c->v_h, M, C, g.vit_ln_eps, st)); }          // hidden_states[-1].to(bf16)
@@ -688,13 +704,15 @@ static int vit_tower(mmd_ctx* c, const void* px, int B, bool col_ready = false, 
         }
         rc = gemm(c, c->v_attn, C, L.wo, C, L.bo, c->v_h, C, c->v_h, C, M, C, C, EPI_RESID, 0, GEMM_AUTO, L.wo_p, true); if (rc) return rc;
         { ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * M * C * es(c), 0); HIPCHK(c, launch_layernorm(dt, c->v_h, L.ln2w, L.ln2b, c->v_xn, M, C, g.vit_ln_eps, st)); }
+        bool pm = false;          // fc1's output in the ring kernel's piece-major layout (its only reader is fc2)
         if (g.vit_act == 1) {      // CLIP quick_gelu: plain fc1, then x * sigmoid(1.702 x) on the storage-rounded output (secondary path: not fused)
             rc = gemm(c, c->v_xn, C, L.w1, C, L.b1, nullptr, 0, c->v_mlp, c->vit_ipad, M, c->vit_ipad, C, EPI_NONE, 0, GEMM_AUTO, L.w1_p, true); if (rc) return rc;
             HIPCHK(c, launch_quick_gelu(dt, c->v_mlp, (int64_t)M * c->vit_ipad, st));
         } else {
-            rc = gemm(c, c->v_xn, C, L.w1, C, L.b1, nullptr, 0, c->v_mlp, c->vit_ipad, M, c->vit_ipad, C, EPI_GELU_TANH, 0, GEMM_AUTO, L.w1_p, true); if (rc) return rc;
+            pm = gemm_pair_pm(c, true, c->v_xn, C, L.w1_p, L.b1, c->vit_ipad, C, EPI_GELU_TANH, c->v_mlp, c->vit_ipad, L.w2_p, C, c->v_h, C, c->v_h, C, EPI_RESID, M);
+            rc = gemm(c, c->v_xn, C, L.w1, C, L.b1, nullptr, 0, c->v_mlp, c->vit_ipad, M, c->vit_ipad, C, EPI_GELU_TANH, 0, GEMM_AUTO, L.w1_p, true, nullptr, nullptr, nullptr, nullptr, pm ? 2 : 0); if (rc) return rc;
         }
-        rc = gemm(c, c->v_mlp, c->vit_ipad, L.w2, c->vit_ipad, L.b2, c->v_h, C, c->v_h, C, M, C, c->vit_ipad, EPI_RESID, 0, GEMM_AUTO, L.w2_p, true); if (rc) return rc;
+        rc = gemm(c, c->v_mlp, c->vit_ipad, L.w2, c->vit_ipad, L.b2, c->v_h, C, c->v_h, C, M, C, c->vit_ipad, EPI_RESID, 0, GEMM_AUTO, L.w2_p, true, nullptr, nullptr, nullptr, nullptr, pm ? 1 : 0); if (rc) return rc;
     }
     if (g.vit_post_layernorm) { HIPCHK(c, launch_layernorm(dt, c->v_h, c->post_w, c->post_b, c->v_h, M, C, g.vit_ln_eps, st)); }
     if (g.tower_f16 && !r32) { ProfScope ps(c, MMD_K_OTHER, 0, 0); HIPCHK(c, launch_convert(c->v_h, MMD_F16, c->v_h, MMD_BF16, (int64_t)M * C, st)); }          // in place, elementwise
@@ -787,9 +805,8 @@ static int connector_pool(mmd_ctx* c, const void* feats, int B, void* out) {
     const int C = g.vit_hidden, H = g.hidden_size, M = B * c->vit_tokens;
     // bilinear pooling reads (2 out)^2 tokens of each frame: run the (row-wise) projector on those alone -- 196 of 729 rows at the shipped sizes.  The class token, if
     // any, is not among the grid tokens the pool reads (vit_seq > vit_tokens): `feats` rows are then indexed per frame by vit_tokens as before.
-    static const bool full_proj = getenv("MMDUET_FULL_PROJECTOR") != nullptr;
     const int pout = (c->vit_grid + g.pool_stride - 1) / g.pool_stride;
-    if (g.pool_mode == MMD_POOL_BILINEAR && !full_proj && !c->full_projector && 4 * pout * pout < c->vit_tokens && c->vit_seq == c->vit_tokens) {
+    if (g.pool_mode == MMD_POOL_BILINEAR && !c->full_projector && 4 * pout * pout < c->vit_tokens && c->vit_seq == c->vit_tokens) {
         const int Mc = B * 4 * pout * pout;
         const void* fc = feats;
         if (c->tower_compact && feats == c->v_col) c->tower_compact = false;          // the tower already left exactly these rows (consumed once)
@@ -1259,6 +1276,8 @@ static int llm_step_segs(mmd_ctx* c, const StepSeg* segs, int nseg, const void* 
     // The hidden states of a chunk's LAST layer are read at a few rows only (the frame-end rows of the two heads, the row whose logits are wanted); its K / V must exist
     // for every token, but its o_proj and MLP are row-wise: they run on the rows somebody reads, through the weight-streaming kernels (M <= 64).  The reference computes all
     // rows and drops them (the lm_head over all positions is "pure waste the build skips" -- the same holds one layer down).
+    // (Not for the fused schedule, S <= 256 -- ADVICE r04: there every GEMM of the layer is bound by the 466 MB of weights it streams, not by its rows; the row-gathered
+    //  last layer would stream the same weights for fewer rows and add the gather launches: nothing to win, so the gate is `!fused`, not a row count.)
     bool sparse_last = false;
     if (need_rows && n_need > 0 && n_need <= 64 && !fused && S > 64 && dt == MMD_BF16 && H <= 4096 && (H & 3) == 0 && !c->no_fuse && !c->full_last_layer && !hidden_out && !dyn) {
         GemmArgs probe; memset(&probe, 0, sizeof(probe));
@@ -1357,12 +1376,14 @@ static int llm_step_segs(mmd_ctx* c, const StepSeg* segs, int nseg, const void* 
         } else {
             rc = gemm(c, c->l_attn, (int64_t)nh * d, L.wo, (int64_t)nh * d, nullptr, c->l_h, H, c->l_h, H, S, H, nh * d, EPI_RESID, 0, GEMM_AUTO, L.wo_p, false, L.wo_8, L.so); if (rc) return rc;
             { ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * S * H * e, 0); HIPCHK(c, launch_rmsnorm(dt, c->l_h, L.ln2, c->l_xn, S, H, g.rms_norm_eps, st)); }
-            rc = gemm(c, c->l_xn, H, L.wgu, H, nullptr, nullptr, 0, c->l_act, I, S, 2 * I, H, EPI_SWIGLU, 0, GEMM_AUTO, L.wgu_p, false, L.wgu_8, L.sgu); if (rc) return rc;
+            // (the SwiGLU product has ONE reader, down_proj: piece-major when both run on the ring kernel -- every bf16 chunk of >= 512 rows)
+            const bool pm = !L.sgu && !L.sdown && gemm_pair_pm(c, false, c->l_xn, H, L.wgu_p, nullptr, 2 * I, H, EPI_SWIGLU, c->l_act, I, L.wdown_p, H, c->l_h, H, c->l_h, H, EPI_RESID, S);
+            rc = gemm(c, c->l_xn, H, L.wgu, H, nullptr, nullptr, 0, c->l_act, I, S, 2 * I, H, EPI_SWIGLU, 0, GEMM_AUTO, L.wgu_p, false, L.wgu_8, L.sgu, nullptr, nullptr, pm ? 2 : 0); if (rc) return rc;
             // a split-K down_proj (long K, under one block wave of tiles: every chunk) leaves its fp32 slabs; ONE pass then sums them, adds the residual stream, and
             // normalises for the next layer (or the final norm) -- instead of splitk_reduce (+ residual) followed by a separate RMSNorm launch re-reading the row
             int rs = 0;
             rc = gemm(c, c->l_act, I, L.wdown, I, nullptr, c->l_h, H, c->l_h, H, S, H, I, EPI_RESID, 0, GEMM_AUTO, L.wdown_p, false, L.wdown_8, L.sdown, nullptr,
-                      (dt == MMD_BF16 && H <= 4096 && (H & 3) == 0 && !c->no_fuse && !c->no_slab_norm) ? &rs : nullptr); if (rc) return rc;
+                      (dt == MMD_BF16 && H <= 4096 && (H & 3) == 0 && !c->no_fuse && !c->no_slab_norm) ? &rs : nullptr, pm ? 1 : 0); if (rc) return rc;
             if (rs > 1) {
                 ProfScope ps(c, MMD_K_NORM_ROPE, 4.0 * S * H * e + 4.0 * rs * S * H, 0);
                 HIPCHK(c, launch_slab_resid_rmsnorm(c->splitk_ws, rs, S, H, c->l_h, c->l_h, next_norm, g.rms_norm_eps, next_xn, st, L.sdown));          // (fp8 matrices: the tile GEMM's slabs are unscaled)
@@ -1609,6 +1630,7 @@ extern "C" int mmd_op_gemm(mmd_ctx* c, const void* X, const void* W, const void*
 // slabs_out (device, room for max_splits); variant GEMM_SKINNY (auto by M: gemv16 / skinny / stream) or GEMM_STREAM
 extern "C" int mmd_op_gemm_slabs(mmd_ctx* c, const void* X, const void* W, int M, int N, int K, int variant, float* slabs_out, int max_splits, int* splits_out) {
     if (!c || !X || !W || !slabs_out || !splits_out || max_splits < 1) return MMD_EINVAL;
+    if (M <= 0 || N <= 0 || K <= 0 || M > 256 || (N % 16) != 0 || (K % 32) != 0 || (variant != GEMM_SKINNY && variant != GEMM_STREAM)) FAIL(c, MMD_EINVAL, "gemm_slabs: 1 <= M <= 256, N %% 16 == 0, K %% 32 == 0, variant 2 or 8");
     hipSetDevice(c->device);
     void* Wp = nullptr;
     int rc = make_packed(c, W, N, K, &Wp); if (rc) return rc;
@@ -1616,6 +1638,7 @@ extern "C" int mmd_op_gemm_slabs(mmd_ctx* c, const void* X, const void* W, int M
     int splits = 0;
     g.X = X; g.ldx = K; g.Wp = Wp; g.M = M; g.N = N; g.K = K; g.epi = EPI_NONE; g.variant = variant;
     g.splitk_ws = slabs_out; g.splitk_ws_bytes = (size_t)max_splits * M * N * sizeof(float); g.slabs_out = &splits; g.plan_out = c->last_plan;
+    if (!Wp || !gemm_can_slab(c->cfg.dtype, g)) { if (Wp) dev_free(c, Wp); FAIL(c, MMD_EINVAL, "gemm_slabs: no slab kernel takes M = %d, N = %d, K = %d in this context's dtype", M, N, K); }          // (a shape no slab kernel accepts would fall through to a tile kernel with Y == nullptr)
     hipError_t e = launch_gemm(c->cfg.dtype, g, c->stream, nullptr);
     hipStreamSynchronize(c->stream);
     dev_free(c, Wp);
@@ -1644,6 +1667,25 @@ extern "C" int mmd_op_gemm_w8(mmd_ctx* c, const void* X, const void* Wq, const u
     rc = gemm(c, X, K, Wq, K, bias, R, NO, Y, NO, M, N, K, epi, out_f32, variant, Wp, false, Wp8, scale);
     hipStreamSynchronize(c->stream);
     dev_free(c, Wp); dev_free(c, Wp8);
+    return rc;
+}
+// producer GEMM (epilogue epi1) -> its only consumer (residual R or none), the intermediate piece-major when `piece_major` and both take the ring kernel (parity tests:
+// the same pair with piece_major = 0 must give the same bits).  *used_pm_out reports whether the piece-major layout really was used.
+extern "C" int mmd_op_gemm_pair(mmd_ctx* c, const void* X, const void* W1, const void* b1, int epi1, const void* W2, const void* R, void* Y, int M, int N1, int K1, int N2,
+                                int piece_major, int* used_pm_out) {
+    if (!c || !X || !W1 || !W2 || !Y) return MMD_EINVAL;
+    hipSetDevice(c->device);
+    if (!c->splitk_ws) { c->splitk_bytes = (size_t)64 << 20; int rc = dev_alloc(c, (void**)&c->splitk_ws, c->splitk_bytes); if (rc) return rc; }
+    const int T = epi1 == EPI_SWIGLU ? N1 / 2 : N1;
+    void *W1p = nullptr, *W2p = nullptr, *mid = nullptr; int rc;
+    if ((rc = make_packed(c, W1, N1, K1, &W1p)) || (rc = make_packed(c, W2, N2, T, &W2p)) || (rc = dev_alloc(c, &mid, (size_t)round_up(M, 16) * T * es(c)))) return rc;
+    const int epi2 = R ? EPI_RESID : EPI_NONE;
+    const bool pm = piece_major && gemm_pair_pm(c, false, X, K1, W1p, b1, N1, K1, epi1, mid, T, W2p, N2, R, N2, Y, N2, epi2, M);
+    if (used_pm_out) *used_pm_out = pm ? 1 : 0;
+    rc = gemm(c, X, K1, W1, K1, b1, nullptr, 0, mid, T, M, N1, K1, epi1, 0, GEMM_AUTO, W1p, false, nullptr, nullptr, nullptr, nullptr, pm ? 2 : 0);
+    if (!rc) rc = gemm(c, mid, T, W2, T, nullptr, R, N2, Y, N2, M, N2, T, epi2, 0, GEMM_AUTO, W2p, false, nullptr, nullptr, nullptr, nullptr, pm ? 1 : 0);
+    hipStreamSynchronize(c->stream);
+    dev_free(c, W1p); dev_free(c, W2p); dev_free(c, mid);
     return rc;
 }
 extern "C" int mmd_op_gemm_last_plan(mmd_ctx* c, int* out4) {
@@ -1708,6 +1750,7 @@ extern "C" int mmd_op_resid32_layernorm(mmd_ctx* c, const void* y16, float* h32,
                                         int M, int H, float eps) {
     if (!c) return MMD_EINVAL; hipSetDevice(c->device);
     if (!y16 || !h32 || (w16 && (!b16 || !out16)) || (pos16 && period <= 0)) FAIL(c, MMD_EINVAL, "resid32_layernorm: missing operand");
+    if (outbf && w16) FAIL(c, MMD_EINVAL, "resid32_layernorm: outbf (the tower's final bf16 result: h32 is not rewritten) and a LayerNorm output are exclusive");
     HIPCHK(c, launch_resid32_layernorm(y16, h32, pos16, period, w16, b16, out16, outbf, M, H, eps, c->stream)); return MMD_OK;
 }
 extern "C" int mmd_op_rope_append(mmd_ctx* c, void* qkv, int S, int nh, int nkv, int d, float theta, int64_t pos0, void* q_out, void* Kc, void* Vc, int64_t cap) {
@@ -1730,7 +1773,7 @@ extern "C" int mmd_op_attention(mmd_ctx* c, const void* q, const void* Kc, const
     a.q = q; a.ldq = (int64_t)nh * d; a.K = Kc; a.V = Vc; a.k_hs = cap * d; a.k_ts = d; a.v_hs = cap * d; a.v_ts = d; a.out = out; a.ldo = (int64_t)nh * d;
     a.S = S; a.nh = nh; a.nkv = nkv; a.d = d; a.n_ctx = n_ctx; a.causal = causal; a.batch = 1; a.ws = c->attn_ws; a.ws_bytes = c->attn_bytes; a.variant = variant;
     void* vt = nullptr;
-    if (variant == 3) {        // the GQA-128 kernel reads the transposed V arena layout: convert the row-major test input
+    if (variant == 3 || variant == 5) {        // the GQA-128 kernels read the transposed V arena layout: convert the row-major test input
         if (cap % 64 != 0) FAIL(c, MMD_EINVAL, "variant 3 needs cap %% 64 == 0");
         int rc = dev_alloc(c, &vt, (size_t)nkv * cap * d * es(c)); if (rc) return rc;
         HIPCHK(c, launch_transpose_v(c->cfg.dtype, Vc, vt, nkv, cap, d, c->stream));

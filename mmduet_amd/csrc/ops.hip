@@ -160,7 +160,7 @@ hipError_t launch_layernorm(int dtype, const void* x, const void* w, const void*
 //     out16[row] = fp16(LayerNorm(h32[row]) * w + b)        when ln_w is given            (the next linear's input)
 //     outbf[row] = bf16(h32[row])                           when outbf is given           (the tower's result: hidden_states[-1].to(images.dtype))
 // y16 and out16 may be the same buffer (a row is read whole before it is written).
-__global__ __launch_bounds__(256) void resid32_layernorm_kernel(const f16_t* __restrict__ y, float* __restrict__ h, const f16_t* __restrict__ pos, int period,
+__global__ __launch_bounds__(256) void resid32_layernorm_kernel(const f16_t* y /* may alias out16: no __restrict__ on either */, float* __restrict__ h, const f16_t* __restrict__ pos, int period,
                                                                 const f16_t* __restrict__ w, const f16_t* __restrict__ b, f16_t* out16, bf16_t* __restrict__ outbf,
                                                                 int M, int H, float eps) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;

@@ -93,3 +93,33 @@ def test_vit_ring_kernel_fits_four_blocks_and_keeps_its_dma_in_flight(attn_isa, 
     first_tr = min(i for i, l in enumerate(loop) if 'ds_read_b64_tr_b16' in l)
     assert waits[0][0] < first_tr and waits[1][0] < first_tr                 # both in front of the tile's first V read: nothing waits on the NEXT tile's DMA behind it
     assert not any(re.match(r'\s*global_load_dword', l) for l in loop), 'an ordinary global load inside the ring loop'
+
+
+def test_w1_kernel_has_no_spills_vgpr_form_mfmas_and_only_counted_waits(attn_isa):
+    """attn_gqa128_w1_kernel (attn_w1.h): <= 256 registers and NO AGPRs -- beyond 256 hipcc switches every MFMA to the AGPR form and pays an accvgpr move per score;
+    no scratch (a reload is VMEM: hipcc waits vmcnt(0) behind it and drains the K / V ring); every vmcnt wait of the kernel is one of the hand-written counted ones."""
+    name = '_Z21attn_gqa128_w1_kernelILi2ELi8EEv5AttnP'          # (several s_endpgm: the 2 / 1 / 0 row-tile programs end separately -- cut at the function's end label)
+    body = attn_isa[re.search(r'^' + name + r':', attn_isa, re.M).start():]
+    end = body.index('.Lfunc_end')
+    lines, meta = body[:end].split('\n'), body[end:end + 8000]
+    assert not any('scratch_' in l for l in lines), 'the w1 attention spills'
+    assert re.search(r'; ScratchSize: 0\b', meta)
+    assert int(re.search(r'; NumVgprs: (\d+)', meta).group(1)) <= 256 and int(re.search(r'; NumAgprs: (\d+)', meta).group(1)) == 0
+    assert not any('v_accvgpr' in l for l in lines)
+    text = [l.strip() for l in lines]
+    first_dma = min(i for i, l in enumerate(text) if l.startswith('global_load_lds_dwordx4'))
+    own = []
+    for i, l in enumerate(text):
+        if i > first_dma and 'vmcnt' in l and not l.startswith(';'):
+            # behind the first DMA: only the hand-written counted waits (inside ASMSTART / ASMEND) -- and the compiler's own wait for the q fragments' ordinary loads, which are
+            # OLDER than the first three tiles' DMAs (vmcnt(N >= 12): the DMAs stay in flight) -- and the epilogue's
+            w = re.fullmatch(r's_waitcnt vmcnt\((\d+)\)', l)
+            if w and 'ASMSTART' in text[i - 1]:
+                assert int(w.group(1)) in (0, 4, 8), l
+            elif not any(x.startswith('global_store') or x.startswith('buffer_store') for x in text[first_dma:i]):
+                own.append(i)
+                assert any(x.startswith('global_load_lds_dwordx4') for x in text[i:i + 40]), 'a compiler-inserted vmcnt wait that is not the q fragments\' (tiles 1, 2 are staged right behind that one)'
+    assert len(own) <= 2                                        # the 2- and 1-row-tile programs' q loads
+    loops = [i for i, l in enumerate(lines) if 'This Inner Loop Header: Depth=1' in l]
+    assert len(loops) >= 3                                      # the 2 / 1 / 0 row-tile programs
+    assert sum('s_barrier' in l for l in lines) >= 6            # ... each with its prologue barrier and one per tile

@@ -42,7 +42,7 @@ def ops_bf16():
 
 
 GENERIC_VARIANTS = [1, 2, 3]                                              # both dtypes, any shape
-TILE_VARIANTS = [4, 6, 7, 16, 17, 18, 19, 21, 23, 24, 32, 33, 40, 42, 44]     # bf16 MFMA tile kernels with shape conditions
+TILE_VARIANTS = [4, 6, 7, 32, 33, 36, 37]     # bf16 MFMA tile kernels with shape conditions (16 + ring flags: 16 / 17 = the shipped 8- / 4-wave instantiations, + 4 = split K)
 
 
 def _applies(variant, M, N, K):

@@ -109,12 +109,13 @@ def test_production_gemm_shapes_take_the_production_kernel_and_match_fp32(ops, n
         assert plan['kernel'] in RING and plan['splits'] >= expect['min_splits'], plan                                        # automatic split-K over grid.z
 
 
-@pytest.mark.parametrize('variant', [16, 17, 18, 19, 24, 32, 33, 40, 42])
+@pytest.mark.parametrize('variant', [32, 33])
 @pytest.mark.parametrize('name,M,N,K,epi', [('vit_fc1', 25515, 4352, 1152, 'gelu_tanh'), ('vit_o', 25515, 1152, 1152, 'resid'), ('gate_up_tail', 1303, 37888, 3584, 'swiglu'),
                                             ('ragged', 3000, 1184, 704, 'none')])
 def test_every_ring_instantiation_at_production_shapes(ops, variant, name, M, N, K, epi):
-    """gemm_ringx_kernel<EPI, WN, M32>: 8-wave 256x256 / 4-wave 256x128 blocks x 16x16x32 / 32x32x16 MFMA, persistent multi-tile loops, M and N tails.
-    All four must agree with fp32 math to the bf16 bound AND with each other to accumulation-order noise."""
+    """The two shipped gemm_ringx_kernel instantiations, forced (variant = GEMM_RINGX + flags: 16 = 8-wave 256x256, 17 = 4-wave 256x128), at production shapes:
+    persistent multi-tile loops, M and N tails; both agree with fp32 math to the bf16 bound.  (The instantiations that lost their A/B -- late refill, 32x32x16 MFMA,
+    four slots -- are no longer in the library: tools/probes/dropped/.)"""
     dev = ops.dev
     g = torch.Generator(device=dev).manual_seed(N + K)
     X = (torch.randn(M, K, generator=g, device=dev) * 0.7).to(torch.bfloat16)
@@ -190,6 +191,160 @@ def test_chunk_attention_at_production_sizes(ops, S, n_ctx):
     err = _rel_err(o, ref)
     _record(f'attn_S{S}_n{n_ctx}', rel_err=err)
     assert torch.isfinite(o.float()).all() and err <= 1.8e-2, err
+
+
+@pytest.mark.parametrize('M', [49, 98, 196])
+def test_stream_gemm_repeats_bit_identical_beside_a_copy_stream(ops, M):
+    """Race screen of gemm_stream_kernel: the default for every 32 < M <= 256 GEMM relies on a hand-counted `s_waitcnt vmcnt` over inline-asm weight loads hipcc
+    cannot see; a mis-count would show as a rare wrong tile, not as a parity failure.  Every shipped instantiation (M = 49 / 98 / 196 pick the 4- / 8- / 16-row-tile forms) in
+    slab mode with a K split (qkv, o, down), with the SwiGLU epilogue (gate_up) and with the in-place epilogue (residual), 40 times beside a copy stream: the same bits."""
+    dev = ops.dev
+    g = torch.Generator(device=dev).manual_seed(M)
+    noise = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
+    side = torch.cuda.Stream()
+    cases = [('slabs', 4608, 3584), ('slabs', 3584, 3584), ('slabs', 3584, 18944), ('swiglu', 37888, 3584), ('resid', 3584, 18944)]
+    for kind, N, K in cases:
+        X = (torch.randn(M, K, generator=g, device=dev) * 0.7).to(torch.bfloat16)
+        W = (torch.randn(N, K, generator=g, device=dev) / math.sqrt(K)).to(torch.bfloat16)
+        R = torch.randn(M, N, generator=g, device=dev).to(torch.bfloat16) if kind == 'resid' else None
+
+        def once():
+            if kind == 'slabs':
+                y, n = ops.gemm_slabs(X, W, variant=8)
+                assert n >= 2                                   # a real K split
+                return y
+            if kind == 'swiglu':
+                return ops.gemm(X, W, None, epi='swiglu', variant=8)
+            return ops.gemm(X, W, None, R=R, epi='resid', variant=8)
+        first = once().clone()
+        assert _plan(ops)['kernel'] == 8                        # GEMM_K_STREAM
+        for r in range(40):
+            if r % 3 == 0:
+                with torch.cuda.stream(side):
+                    noise[:128 << 20].copy_(noise[128 << 20:], non_blocking=True)
+            assert torch.equal(once(), first), (kind, N, K, r)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize('name,M,N1,K1,epi1,N2,resid', [('vit_mlp', 25515, 4352, 1152, 'gelu_tanh', 1152, True), ('vit_mlp_last_layer_rows_NOT_on_the_ring', 6860, 4352, 1152, 'gelu_tanh', 1152, False),
+                                                       ('llm_mlp', 1274, 37888, 3584, 'swiglu', 3584, True), ('llm_mlp_tail', 1303, 37888, 3584, 'swiglu', 3584, True),
+                                                       ('llm_mlp_short_chunk', 700, 37888, 3584, 'swiglu', 3584, True)])
+def test_piece_major_intermediate_gives_the_same_bits(ops, name, M, N1, K1, epi1, N2, resid):
+    """The MLP pairs of the path (SigLIP fc1 + GELU -> fc2: models/live_llava/video_head_live_llava_qwen.py:96-98; Qwen2MLP gate_up + SwiGLU -> down) with the intermediate in the
+    ring kernel's piece-major layout (1 KB pieces of 16 rows x 32 columns: the producer's wave instruction writes ONE contiguous piece, the consumer's X-DMA reads it back as one)
+    against the row-major intermediate: the same values travel through other addresses -> the same bits; M tails (row groups past M are never written), both epilogues, the
+    split-K consumer.  And against fp32 math."""
+    import ctypes as C
+    from mmduet_amd._lib import lib, check, EPI
+    from mmduet_amd.modeling_live import _ptr
+    dev = ops.dev
+    g = torch.Generator(device=dev).manual_seed(N1 + M)
+    X = (torch.randn(M, K1, generator=g, device=dev) * 0.7).to(torch.bfloat16)
+    W1 = (torch.randn(N1, K1, generator=g, device=dev) / math.sqrt(K1)).to(torch.bfloat16)
+    T = N1 // 2 if epi1 == 'swiglu' else N1
+    W2 = (torch.randn(N2, T, generator=g, device=dev) / math.sqrt(T)).to(torch.bfloat16)
+    b1 = (0.1 * torch.randn(N1, generator=g, device=dev)).to(torch.bfloat16) if epi1 != 'swiglu' else None
+    R = torch.randn(M, N2, generator=g, device=dev).to(torch.bfloat16) if resid else None
+    W1k = W1
+    if epi1 == 'swiglu':
+        gate, up = W1[:T], W1[T:]
+        W1k = torch.stack([gate.view(-1, 16, K1), up.view(-1, 16, K1)], 1).reshape(N1, K1).contiguous()
+    outs = []
+    for pm in (1, 0):
+        Y = torch.empty(M, N2, device=dev, dtype=torch.bfloat16)
+        used = C.c_int(-1)
+        ops.m._bind_stream()
+        check(lib().mmd_op_gemm_pair(ops.ctx, _ptr(X), _ptr(W1k), _ptr(b1), EPI[epi1], _ptr(W2), _ptr(R), _ptr(Y), M, N1, K1, N2, pm, C.byref(used)), ops.ctx, 'gemm_pair')
+        torch.cuda.synchronize()
+        # both GEMMs of the production pairs take the ring kernel; the 196-row last tower layer's fc2 (135 tiles: under one block wave) does not -- its intermediate stays row-major
+        assert used.value == (pm if 'NOT_on_the_ring' not in name else 0), (name, pm, used.value)
+        outs.append(Y)
+    assert torch.equal(outs[0], outs[1])
+    Xf = X.float()
+    if epi1 == 'swiglu':
+        mid = F.silu((Xf @ W1[:T].float().T).to(torch.bfloat16).float()).to(torch.bfloat16).float() * (Xf @ W1[T:].float().T).to(torch.bfloat16).float()
+    else:
+        mid = O.gelu_tanh(F.linear(Xf, W1.float(), b1.float()).to(torch.bfloat16).float())
+    ref = mid.to(torch.bfloat16).float() @ W2.float().T
+    if resid:
+        ref = ref.to(torch.bfloat16).float() + R.float()
+    err = _rel_err(outs[0], ref)
+    assert torch.isfinite(outs[0].float()).all() and err <= 2.4e-2, (name, err)
+
+
+# (per-frame steps and short chunks: attn_gqa128_w1_kernel, variant 5 = forced.  1 / 2 / 3 row blocks, blocks whose waves hold 2 / 1 / 0 row tiles, 1 .. 8 key tiles per split,
+#  new positions on tile boundaries, the masked diagonal inside the first / second half tile, a context too short for any split)
+W1_SHAPES = [(49, 15000), (49, 0), (49, 1), (49, 63), (49, 64), (49, 4047), (49, 30000), (24, 15000), (64, 4096), (98, 15000), (109, 8000), (131, 15000), (17, 300), (3, 70001),
+             (37, 129), (256, 5000), (300, 70000), (1274, 0)]
+
+
+@pytest.mark.parametrize('S,n_ctx', W1_SHAPES)
+def test_w1_attention_at_production_sizes(ops, S, n_ctx):
+    """attn_gqa128_w1_kernel (attn_w1.h: software-pipelined waves, balanced row blocks; Qwen2Attention.forward, transformers qwen2/modeling_qwen2.py:200-240) against fp32
+    math, same bound as the other forms.  (Inside the model the dispatch takes it for 17 .. 768 stacked rows over >= 4096 keys: tests/test_gpu_fullsize.py runs those steps.)"""
+    nh, nkv, d = 28, 4, 128
+    dev = ops.dev
+    g = torch.Generator(device=dev).manual_seed(S + n_ctx)
+    cap = (n_ctx + S + 100 + 63) // 64 * 64
+    q = torch.randn(S, nh * d, generator=g, device=dev).to(torch.bfloat16)
+    K = torch.randn(nkv, cap, d, generator=g, device=dev).to(torch.bfloat16)
+    V = torch.randn(nkv, cap, d, generator=g, device=dev).to(torch.bfloat16)
+    K[:, n_ctx + S:] = 1e4; V[:, n_ctx + S:] = 1e4            # beyond the valid range: must never reach the result
+    o = ops.attention(q, K, V, nh, nkv, d, n_ctx, True, 5)
+    ref = _ref_attention_gpu(q, K, V, nh, nkv, d, n_ctx)
+    err = _rel_err(o, ref)
+    _record(f'attn_w1_S{S}_n{n_ctx}', rel_err=err)
+    assert torch.isfinite(o.float()).all() and err <= 1.8e-2, err
+    # ... and it agrees with the phase-split / two-slot forms (variant 3) to accumulation-order noise: same fragments, same rounding points, other unit order
+    old = ops.attention(q, K, V, nh, nkv, d, n_ctx, True, 3)
+    assert _rel_err(o, old.float()) <= 8e-3
+
+
+def test_model_steps_take_the_attention_form_meant_for_them(width2):
+    """Inside the model (true widths, arena layout, the dispatcher's own choice): a per-frame step over a long context runs attn_gqa128_w1_kernel with two balanced row
+    blocks (343 stacked rows per kv head), a 26-frame chunk the 256-row phase-split form, a decode row the loader / compute ring, a step over a short context the two-slot
+    form -- mmd_op_attention_last_form is to the attention what mmd_op_gemm_last_plan is to the GEMMs."""
+    import ctypes as C
+    from mmduet_amd._lib import lib, check
+    m = width2[0]
+    A = m.new_cache(initial_tokens=15000 + 4096)
+    check(lib().mmd_kv_debug_set_len(A.arena.h, 15000), m._ctx, 'set_len')          # (the slots hold zeros: same traffic, same kernels)
+    form = (C.c_int * 2)()
+    for S, want in ((49, 5), (98, 5), (109, 5), (110, 4), (1274, 4), (1, 3), (2, 3)):
+        x = (torch.randn(1, S, m.config.hidden_size, device=m.device) * 0.5).to(torch.bfloat16)
+        out = m(inputs_embeds=x, past_key_values=type(A)(A.arena, 15000))
+        torch.cuda.synchronize()
+        assert torch.isfinite(out.informative_logits).all()
+        lib().mmd_op_attention_last_form(form)
+        assert form[0] == want, (S, list(form))
+        if want == 5:
+            assert form[1] >= 8                      # key splits: two row blocks x 4 kv heads fill the chip
+    B = m.new_cache(initial_tokens=8192)
+    check(lib().mmd_kv_debug_set_len(B.arena.h, 1000), m._ctx, 'set_len')
+    m(inputs_embeds=(torch.randn(1, 49, m.config.hidden_size, device=m.device) * 0.5).to(torch.bfloat16), past_key_values=type(B)(B.arena, 1000))
+    torch.cuda.synchronize(); lib().mmd_op_attention_last_form(form)
+    assert form[0] == 4                              # under 4096 keys the two-slot form stays (shorter pipeline fill)
+
+
+@pytest.mark.parametrize('S,n_ctx', [(49, 15000), (98, 30000), (24, 4100)])
+def test_w1_attention_repeats_bit_identical_beside_a_copy_stream(ops, S, n_ctx):
+    """Race screen of attn_gqa128_w1_kernel's LDS-DMA ring (hand-counted vmcnt, one barrier per tile, fragments read across phase boundaries): see the ring forms' screen below."""
+    nh, nkv, d = 28, 4, 128
+    dev = ops.dev
+    g = torch.Generator(device=dev).manual_seed(S + n_ctx)
+    cap = (n_ctx + S + 100 + 63) // 64 * 64
+    q = torch.randn(S, nh * d, generator=g, device=dev).to(torch.bfloat16)
+    K = torch.randn(nkv, cap, d, generator=g, device=dev).to(torch.bfloat16)
+    V = torch.randn(nkv, cap, d, generator=g, device=dev).to(torch.bfloat16)
+    noise = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
+    side = torch.cuda.Stream()
+    first = ops.attention(q, K, V, nh, nkv, d, n_ctx, True, 5).clone()
+    for r in range(60):
+        if r % 3 == 0:
+            with torch.cuda.stream(side):
+                noise[:128 << 20].copy_(noise[128 << 20:], non_blocking=True)
+        assert torch.equal(ops.attention(q, K, V, nh, nkv, d, n_ctx, True, 5), first), r
+    torch.cuda.synchronize()
 
 
 @pytest.mark.parametrize('S,n_ctx', [(1274, 15000), (637, 3000), (1, 15000), (2, 70001)])
@@ -553,62 +708,3 @@ def test_bench_launches_its_own_ranks_nccl():
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
     assert line['n_gpus'] == 2 and line['rccl_ranks'] == 2 and line['config']['native_gather_check'] == 'ok'
-
-
-# ---- gemm_ringw_kernel: W fragments straight from L2 into registers, X-only LDS ring (round 4) ------------------------------------------------------
-RINGW = {200: '3 slots / 3 W buffers', 201: '4 slots / 2 W buffers'}
-
-
-@pytest.mark.parametrize('variant', sorted(RINGW))
-@pytest.mark.parametrize('name,M,N,K,epi', [('vit_fc1', 25515, 4352, 1152, 'gelu_tanh'), ('vit_o', 25515, 1152, 1152, 'resid'), ('gate_up_tail', 1303, 37888, 3584, 'swiglu'),
-                                            ('ragged', 3000, 1184, 704, 'none'), ('k64', 700, 512, 64, 'none'), ('k128', 513, 256, 128, 'resid'), ('k192', 300, 288, 192, 'none'), ('k256', 300, 288, 256, 'none'), ('k320', 257, 64, 320, 'none')])
-def test_ringw_instantiations_match_fp32_and_the_shipped_ring(ops, variant, name, M, N, K, epi):
-    """gemm_ringw_kernel<EPI, NS, NB> (hand-counted vmcnt over inline-asm W loads + LDS-DMA X pieces) at production shapes, M / N tails and tiles of 2 .. 10 K slices
-    (prologue / tail paths): fp32 math to the bf16 bound, and the SAME BITS as the shipped ring (same products, same accumulation order per output element)."""
-    dev = ops.dev
-    g = torch.Generator(device=dev).manual_seed(N + K)
-    X = (torch.randn(M, K, generator=g, device=dev) * 0.7).to(torch.bfloat16)
-    W = (torch.randn(N, K, generator=g, device=dev) / math.sqrt(K)).to(torch.bfloat16)
-    b = (0.1 * torch.randn(N, generator=g, device=dev)).to(torch.bfloat16)
-    Xf = X.float()
-    if epi == 'swiglu':
-        gate, up = W[:N // 2], W[N // 2:]
-        Wi = torch.stack([gate.view(-1, 16, K), up.view(-1, 16, K)], 1).reshape(N, K).contiguous()
-        Y = ops.gemm(X, Wi, None, epi=epi, variant=variant); plan = _plan(ops)
-        Y0 = ops.gemm(X, Wi, None, epi=epi, variant=32)
-        ref = F.silu((Xf @ gate.float().T).to(torch.bfloat16).float()).to(torch.bfloat16).float() * (Xf @ up.float().T).to(torch.bfloat16).float()
-    elif epi == 'resid':
-        R = torch.randn(M, N, generator=g, device=dev).to(torch.bfloat16)
-        Y = ops.gemm(X, W, b, R=R, epi=epi, variant=variant); plan = _plan(ops)
-        Y0 = ops.gemm(X, W, b, R=R, epi=epi, variant=32)
-        ref = F.linear(Xf, W.float(), b.float()).to(torch.bfloat16).float() + R.float()
-    else:
-        Y = ops.gemm(X, W, b, epi=epi, variant=variant); plan = _plan(ops)
-        Y0 = ops.gemm(X, W, b, epi=epi, variant=32)
-        lin = F.linear(Xf, W.float(), b.float())
-        ref = O.gelu_tanh(lin.to(torch.bfloat16).float()) if epi == 'gelu_tanh' else lin
-    err = _rel_err(Y, ref)
-    assert torch.isfinite(Y.float()).all() and err <= 2.4e-2, (variant, name, err, plan)
-    assert plan['kernel'] == 6, plan
-    assert torch.equal(Y, Y0), (variant, name, (Y.float() - Y0.float()).abs().max().item())
-
-
-@pytest.mark.parametrize('variant', sorted(RINGW))
-def test_ringw_repeats_bit_identical_beside_a_copy_stream(ops, variant):
-    """Race screen of the hand-counted waits: a W fragment consumed before its load landed, or an X slot refilled early, shows as a rare differing tile -- repeat the
-    launch beside a copy stream that perturbs the memory system; every repeat must give the same bits (persistent multi-tile shape and a split-K launch)."""
-    dev = ops.dev
-    g = torch.Generator(device=dev).manual_seed(variant)
-    noise = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
-    side = torch.cuda.Stream()
-    for (M, N, K, v) in ((25515, 1152, 1152, variant), (1274, 3584, 18944, variant + 4)):
-        X = (torch.randn(M, K, generator=g, device=dev) * 0.7).to(torch.bfloat16)
-        W = (torch.randn(N, K, generator=g, device=dev) / math.sqrt(K)).to(torch.bfloat16)
-        first = ops.gemm(X, W, variant=v).clone()
-        assert _rel_err(first, Xf := X.float() @ W.float().T) <= 1.2e-2
-        for r in range(40):
-            if r % 3 == 0:
-                with torch.cuda.stream(side):
-                    noise[:128 << 20].copy_(noise[128 << 20:], non_blocking=True)
-            assert torch.equal(ops.gemm(X, W, variant=v), first), (v, r)
-    torch.cuda.synchronize()

@@ -88,6 +88,45 @@ def test_cli_over_predecoded_and_raw_decoded_entries(tmp_path, monkeypatch):
             assert x['video_time'] == y['video_time'] and abs(x['relevance_score'][1] - y['relevance_score'][1]) <= 1.5e-3
 
 
+def test_cli_prefetch_gives_identical_records(tmp_path, monkeypatch):
+    """`python -m mmduet_amd --num_workers N` (mmduet_amd/prefetch.py; the reference: DataLoader(num_workers=4), test/inference.py:341): clips decoded by loader threads into pinned
+    buffers while the GPU runs the current one, raw decoder output uploaded on a copy stream, letter-boxed frames per tower batch on the tower stream -- against the inline loader
+    (--num_workers 0): the same records, byte for byte, for every entry kind (frames / raw decoder output / Motion-JPEG container / unreadable), one and two streams per GPU."""
+    import mmduet_amd.inference as inf
+    import mmduet_amd.__main__ as cli
+    from mmduet_amd.video_decode import write_mjpeg_avi
+    model, cfgd, _ = hip_model('A')
+    tok = tokenizer_for(model.config)
+    monkeypatch.setattr(inf, 'build_model_and_tokenizer', lambda **kw: (model, tok))
+    R = model.config.frame_resolution
+    rng = np.random.default_rng(7)
+    entries = []
+    for i in range(3):
+        np.save(tmp_path / f'clip{i}.npy', rng.integers(0, 256, (4 + i, 3, R, R), dtype=np.uint8))
+        entries.append({'question_id': f'f{i}', 'frames': f'clip{i}.npy', 'fps': 1.0, 'video_duration': 4.0 + i, 'conversation': [{'role': 'user', 'content': 'what happens?', 'time': 0.0}]})
+    for i in range(2):
+        np.save(tmp_path / f'raw{i}.npy', rng.integers(0, 256, (30 + 10 * i, 30, 50, 3), dtype=np.uint8))
+        entries.append({'question_id': f'd{i}', 'decoded': f'raw{i}.npy', 'input_fps': 10.0, 'conversation': [{'role': 'user', 'content': 'describe', 'time': 0.0}]})
+    for i in range(3):
+        write_mjpeg_avi(tmp_path / f'v{i}.avi', rng.integers(0, 256, (24 + 6 * i, 36, 48, 3)).astype(np.uint8), 8.0)
+        entries.append({'question_id': f'v{i}', 'video': f'v{i}.avi', 'conversation': [{'role': 'user', 'content': 'describe', 'time': 0.0}]})
+    entries.insert(4, {'question_id': 'broken', 'frames': 'missing.npy', 'conversation': [{'role': 'user', 'content': 'x', 'time': 0.0}]})
+    json.dump(entries, open(tmp_path / 'test.json', 'w'))
+
+    def run(tag, *extra):
+        out = tmp_path / f'{tag}.jsonl'
+        cli.main(['--live_version', 'test', '--llm_pretrained', 'synthetic:0', '--input_dir', str(tmp_path), '--test_fname', str(tmp_path / 'test.json'), '--output_fname', str(out),
+                  '--frame_fps', '2', '--frame_resolution', str(R), '--max_num_frames', '6', '--time_instruction_format', 'vtimellm', '--stream_end_prob_threshold', '0.5',
+                  '--max_new_tokens', '4', *extra])
+        return [json.loads(l) for l in open(out)]
+    inline, pre = run('inline', '--num_workers', '0'), run('pre', '--num_workers', '4')
+    assert [r['question_id'] for r in inline] == [e['question_id'] for e in entries if e['question_id'] != 'broken']
+    assert inline == pre
+    two_inline, two_pre = run('two_inline', '--num_workers', '0', '--streams_per_gpu', '2'), run('two_pre', '--num_workers', '3', '--streams_per_gpu', '2')
+    key = lambda r: r['question_id']
+    assert sorted(two_inline, key=key) == sorted(two_pre, key=key) and len(two_pre) == len(inline)
+
+
 def test_demo_driver_on_gpu_with_concurrent_query_thread(model_f32):
     """LiveInferForDemo on the HIP model: `input_one_frame` from the generator thread while `encode_given_query` arrives from a second
     thread (the Gradio handler, demo/app.py:84-85).  The reference shares past_key_values unlocked; here both go through one lock, so
