@@ -504,6 +504,37 @@ def test_chunk_of_26_frames_equals_26_frame_steps_true_width(width2):
     assert maxerr(chunk, want) < 6e-2 and maxerr(per, want) < 6e-2 and maxerr(chunk, per) < 6e-2
 
 
+def test_per_frame_steps_over_a_long_context_true_width(width2):
+    """The reference's own schedule -- ONE frame per forward (test/inference.py:221-246) -- deep into a stream: three 1372-row chunks build a 4.1 k-token context, then eight
+    49-row frame steps and a 98-row step run on attn_gqa128_w1_kernel (asserted), against the fp32 oracle fed the same inputs; the bf16 oracle (the reference's eager rounding
+    points) is the yardstick.  Same bound as the chunk test above: 6e-2 on head logits (bf16, 2 layers)."""
+    import ctypes as C
+    from mmduet_amd._lib import lib
+    m, o32, o16 = width2
+    g = torch.Generator(device=m.device).manual_seed(9)
+    rnd = lambda S: (torch.randn(1, S, 3584, generator=g, device=m.device) * 0.5).to(torch.bfloat16)
+    cache = oc = oc16 = None
+    for _ in range(3):
+        x = rnd(1372)
+        cache = m(inputs_embeds=x, past_key_values=cache).past_key_values
+        oc = o32(inputs_embeds=x.float(), past_key_values=oc).past_key_values
+        oc16 = o16(inputs_embeds=x, past_key_values=oc16).past_key_values
+    form = (C.c_int * 2)()
+    worst = worst16 = 0.0
+    for S in [49] * 8 + [98]:
+        x = rnd(S)
+        out = m(inputs_embeds=x, past_key_values=cache); cache = out.past_key_values
+        torch.cuda.synchronize(); lib().mmd_op_attention_last_form(form)
+        assert form[0] == 5, (S, list(form))
+        ref = o32(inputs_embeds=x.float(), past_key_values=oc); oc = ref.past_key_values
+        r16 = o16(inputs_embeds=x, past_key_values=oc16); oc16 = r16.past_key_values
+        for a, b, c16 in ((out.informative_logits, ref.informative_logits, r16.informative_logits), (out.relevance_logits, ref.relevance_logits, r16.relevance_logits)):
+            worst = max(worst, maxerr(a[0, -1], b[0, -1])); worst16 = max(worst16, maxerr(c16[0, -1].float(), b[0, -1]))
+    assert len(cache) == 3 * 1372 + 8 * 49 + 98
+    _record('per_frame_long_context_2_layers', ours_vs_fp32=worst, bf16_oracle_vs_fp32=worst16)
+    assert worst < 6e-2, (worst, worst16)
+
+
 def test_fp32_mode_true_width_meets_1e3():
     """(f) fp32 build at the true widths (2 + 2 layers): head logits within 1e-3 of the fp32 oracle (the north-star tolerance), frame chunk and decode rows."""
     m, w, ocfg = _build(2, 2, torch.float32, max_vit_batch=2, max_step_tokens=512)

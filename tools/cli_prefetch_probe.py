@@ -32,11 +32,26 @@ json.dump(entries, open(os.path.join(d, 'test.json'), 'w'))
 t_make = time.perf_counter() - t0
 flags = ['--live_version', 'test', '--llm_pretrained', 'synthetic:0', '--input_dir', d, '--test_fname', os.path.join(d, 'test.json'), '--frame_fps', '1', '--frame_resolution', '336',
          '--max_num_frames', str(frames), '--stream_end_prob_threshold', '1.0', '--frames_per_forward', '26', '--bf16', 'true']
+# host-side phase times of the CLI's main loop (diagnostic: wrappers around the product's functions, product code unchanged)
+phase = {}
+def timed(name, fn):
+    def w(*a, **k):
+        t = time.perf_counter(); r = fn(*a, **k); phase.setdefault(name, []).append((time.perf_counter() - t) * 1e3); return r
+    return w
+import mmduet_amd.prefetch as pfm, mmduet_amd.results as resm, mmduet_amd.video_input as vim
+D = inf.LiveInferForBenchmark
+for nm in ('reset', 'input_video_stream', 'input_query_stream', 'inference'):
+    setattr(D, nm, timed(nm, getattr(D, nm)))
+pfm.ClipPrefetcher.take = timed('prefetcher.take', pfm.ClipPrefetcher.take)
+vim.load_video_frames = timed('load_video_frames (upload wait + letterbox)', vim.load_video_frames)
+resm.result_record = timed('result_record', resm.result_record)
 out = {}
 for w in ([0, workers] if os.environ.get('CLI_PROBE_AB', '1') == '1' else [workers]):
     torch.cuda.synchronize(); t = time.perf_counter()
     cli.main(flags + ['--output_fname', os.path.join(d, f'out_w{w}.jsonl'), '--num_workers', str(w)])
     torch.cuda.synchronize(); out[w] = time.perf_counter() - t
+    print(f'num_workers={w} host phases (ms per video, in call order): ' + '; '.join(f'{k}: ' + ' '.join(f'{x:.1f}' for x in v) for k, v in phase.items()), flush=True)
+    phase.clear()
 recs = {w: [json.loads(l) for l in open(os.path.join(d, f'out_w{w}.jsonl'))] for w in out}
 same = all(recs[w] == recs[list(out)[0]] for w in out)
 print(json.dumps(dict(clips=n_clips, frames_per_clip=frames, jpeg_frames_in_each_file=2 * frames, clip_bytes=os.path.getsize(os.path.join(d, 'clip0.avi')), make_clips_s=round(t_make, 1),

@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 export CLI_PROBE_DIR=/tmp/mmduet_cli_probe
 {
 echo "# python tools/cli_prefetch_probe.py 4 8 120: the CLI over 8 Motion-JPEG clips (240 JPEG frames each, 120 kept at 1 fps), 7B + so400m, k = 26, no responses; num_workers 0 = inline loader (round 4)"
-python3 $R/tools/cli_prefetch_probe.py 4 8 120 2>/dev/null | tail -1
+python3 $R/tools/cli_prefetch_probe.py 4 8 120 2>/dev/null | tail -3
 rm -rf $O/prof_cli
 CLI_PROBE_AB=0 rocprofv3 --kernel-trace -d $O/prof_cli -o trace -- python3 $R/tools/cli_prefetch_probe.py 4 8 120 > $O/${tag}_cli_prof.log 2>&1
 db=$(ls $O/prof_cli/*.db 2>/dev/null | head -1)
