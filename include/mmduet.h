@@ -265,13 +265,14 @@ int mmd_op_rope_append(mmd_ctx* ctx, void* qkv, int S, int nh, int nkv, int d, f
                        void* Kc, void* Vc, int64_t cap);
 /* causal GQA attention with query offset: q [S, nh*d], Kc/Vc [nkv, cap, d], n_ctx = tokens before this step;
  * out [S, nh*d].  causal = 0 -> full attention over n_ctx + S keys.  variant: 0 auto, 1 simple, 2 mfma, 3 the arena kernels (attn_gqa128_kernel), 4 row-major
- * K / V (the tower's), 5 attn_gqa128_w1_kernel. */
+ * K / V (the tower's), 5 attn_gqa128_w1_kernel, 6 attn_gqa128_chunk_kernel. */
 int mmd_op_attention(mmd_ctx* ctx, const void* q, const void* Kc, const void* Vc, void* out, int S, int nh, int nkv, int d,
                      int64_t n_ctx, int64_t cap, int causal, int variant);
 int mmd_op_attention_bench(mmd_ctx* ctx, int S, int nh, int nkv, int d, int64_t n_ctx, int variant, int iters, float* avg_ms_out);
 /* which attention form the most recent launch of this process took (what mmd_op_gemm_last_plan is for the GEMMs: parity tests assert that the production kernel really
  * ran): 1 one wave per row, 2 16-row MFMA tiles, 3 / 4 attn_gqa128_kernel with 16- / 32-row waves (decode and two-slot forms / 256-row phase-split chunks), 5
- * attn_gqa128_w1_kernel (per-frame steps, short chunks), 6 register-staged row-major (ViT), 7 attn_d72_ring_kernel (SigLIP-so400m); out2 = {form, key splits} */
+ * attn_gqa128_w1_kernel (per-frame steps, short chunks), 6 register-staged row-major (ViT), 7 attn_d72_ring_kernel (SigLIP-so400m), 8 attn_gqa128_chunk_kernel (multi-frame
+ * chunks, contiguous decomposition); out2 = {form, key splits or the most blocks sharing a unit} */
 int mmd_op_attention_last_form(int* out2);
 int mmd_op_pool(mmd_ctx* ctx, const void* x, void* y, int B, int grid, int H, int mode, int stride);
 

@@ -33,6 +33,8 @@ struct AttnP {
     int block_rows;     // attn_gqa128_w1_kernel: query rows per block (multiple of 16)
 };
 
+static int g_last_form[2] = {0, 0};          // (diagnostic only: which form the most recent launch took, mmd_op_attention_last_form)
+
 __device__ __forceinline__ long long v_off(const AttnP& p, long long tok, int e) {
     return p.v_tr ? (((tok >> 6) * p.d + e) << 6) + (tok & 63) : tok * p.v_ts + e;
 }
@@ -908,6 +910,7 @@ __global__ __launch_bounds__(256) void attn_combine128_rows_kernel(AttnP p, int 
 }
 
 #include "attn_w1.h"
+#include "attn_chunk.h"
 
 // attn_gqa128_w1_kernel (attn_w1.h): `qblocks` row blocks of block_rows (multiple of 16, <= 256) per kv head, `splits` key splits (the caller's choice)
 static hipError_t launch_gqa128_w1(AttnP& p, const AttnArgs& a, hipStream_t st, int qblocks, int block_rows, int splits_hint) {
@@ -987,6 +990,19 @@ static hipError_t launch_gqa128(AttnP& p, const AttnArgs& a, hipStream_t st) {
             const double rounds = (double)cdiv((long long)blocks * sp, resident);          // (a 256-row block's tile costs about what two resident 128-row blocks' tiles do: swept 1.0 .. 2.6, flat)
             const double cost = rounds * ((double)cdiv(tiles, sp) + 2.0) + (sp > 1 ? sp * rows_all * 6.7e-5 + 1.5 : 0.0);
             if (cost < best - 1e-9) { best = cost; splits = sp; }
+        }
+    }
+    if constexpr (RT == 2) {
+        // chunks: the contiguous (stream-K) decomposition of attn_chunk.h where the (unit, key split) grid is a bad fit -- it needs splits to fill the chip (each split is one more
+        // fp32 partial per row) or leaves a fifth of it idle -- and a block's range is long enough to carry its per-segment costs (>= 14 tiles; 40+ units).  Measured against
+        // the grid form over S = 147 .. 1911, 0 .. 30 k keys (profiles/r05_attention_chunk.md): 1.04 - 1.39 x where this rule takes it, the grid form elsewhere.
+        if (chunk8 && a.variant == 0 && !a.dyn && a.ws && blocks >= 40) {
+            const double eff = (double)blocks * splits / ((double)cdiv((long long)blocks * splits, resident) * resident);
+            if (chunk_tiles_total(a) / 256 >= 14 && !(splits == 1 && eff >= 0.8)) {
+                const hipError_t e = launch_gqa128_chunk(p, a, st);
+                if (e == hipSuccess) { g_last_form[0] = 8; return e; }
+                (void)hipGetLastError();
+            }
         }
     }
     int per = cdiv(tiles, splits) * 64;
@@ -1477,7 +1493,6 @@ static hipError_t launch_mfma(AttnP& p, const AttnArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
-static int g_last_form[2] = {0, 0};          // (diagnostic only: which form the most recent launch took, mmd_op_attention_last_form)
 extern "C" int mmd_op_attention_last_form(int* out2) { if (!out2) return MMD_EINVAL; out2[0] = g_last_form[0]; out2[1] = g_last_form[1]; return MMD_OK; }
 static hipError_t launch_attention_(int dtype, const AttnArgs& a, hipStream_t st, AttnP& p);
 hipError_t launch_attention(int dtype, const AttnArgs& a, hipStream_t st) {
@@ -1531,6 +1546,11 @@ static hipError_t launch_attention_(int dtype, const AttnArgs& a, hipStream_t st
         return launch_rowmajor<4, 8>(p, a, st, f16);
     }
     if (variant == 2 && !can_mfma) return hipErrorInvalidValue;
+    if (variant == 6) {          // the chunk kernel's contiguous decomposition, forced (attn_chunk.h)
+        if (!can_gqa128 || a.qkv_slabs || a.dyn || a.S * (a.nh / a.nkv) < 256) return hipErrorInvalidValue;
+        g_last_form[0] = 8;
+        return launch_gqa128_chunk(p, a, st);
+    }
     if (variant == 5) {          // software-pipelined waves, balanced row blocks (attn_w1.h)
         if (!can_gqa128 || a.qkv_slabs || a.dyn) return hipErrorInvalidValue;
         g_last_form[0] = 5;

@@ -1773,7 +1773,7 @@ extern "C" int mmd_op_attention(mmd_ctx* c, const void* q, const void* Kc, const
     a.q = q; a.ldq = (int64_t)nh * d; a.K = Kc; a.V = Vc; a.k_hs = cap * d; a.k_ts = d; a.v_hs = cap * d; a.v_ts = d; a.out = out; a.ldo = (int64_t)nh * d;
     a.S = S; a.nh = nh; a.nkv = nkv; a.d = d; a.n_ctx = n_ctx; a.causal = causal; a.batch = 1; a.ws = c->attn_ws; a.ws_bytes = c->attn_bytes; a.variant = variant;
     void* vt = nullptr;
-    if (variant == 3 || variant == 5) {        // the GQA-128 kernels read the transposed V arena layout: convert the row-major test input
+    if (variant == 3 || variant == 5 || variant == 6) {        // the GQA-128 kernels read the transposed V arena layout: convert the row-major test input
         if (cap % 64 != 0) FAIL(c, MMD_EINVAL, "variant 3 needs cap %% 64 == 0");
         int rc = dev_alloc(c, &vt, (size_t)nkv * cap * d * es(c)); if (rc) return rc;
         HIPCHK(c, launch_transpose_v(c->cfg.dtype, Vc, vt, nkv, cap, d, c->stream));

@@ -123,3 +123,22 @@ def test_w1_kernel_has_no_spills_vgpr_form_mfmas_and_only_counted_waits(attn_isa
     loops = [i for i, l in enumerate(lines) if 'This Inner Loop Header: Depth=1' in l]
     assert len(loops) >= 3                                      # the 2 / 1 / 0 row-tile programs
     assert sum('s_barrier' in l for l in lines) >= 6            # ... each with its prologue barrier and one per tile
+
+
+def test_chunk_kernel_contiguous_form_has_no_spills_and_only_counted_waits(attn_isa):
+    """attn_gqa128_chunk_kernel (attn_chunk.h): the wave program of the <2, 4, 8> form inside a segment loop -- same audit: no scratch, <= 256 registers, one barrier per tile in the
+    tile loop plus the one between segments, every vmcnt wait of the tile loop hand-written."""
+    name = '_Z24attn_gqa128_chunk_kernel5AttnP8ChunkTab'
+    body = attn_isa[re.search(r'^' + name + r':', attn_isa, re.M).start():]
+    end = body.index('.Lfunc_end')
+    lines, meta = body[:end].split('\n'), body[end:end + 8000]
+    assert not any('scratch_' in l for l in lines), 'the chunk attention spills'
+    assert re.search(r'; ScratchSize: 0\b', meta) and int(re.search(r'; NumVgprs: (\d+)', meta).group(1)) <= 256
+    inner = [i for i, l in enumerate(lines) if re.search(r'in Loop: Header=BB\d+_\d+ Depth=2', l)]
+    assert inner, 'tile loop (depth 2: inside the segment loop) not found'
+    loop = lines[min(inner) - 1:max(inner) + 2]
+    assert sum('v_mfma_f32_16x16x32_bf16' in l for l in loop) == 64
+    for i, l in enumerate(loop):
+        if 'vmcnt' in l and not l.strip().startswith(';'):
+            assert l.strip() in ('s_waitcnt vmcnt(0)', 's_waitcnt vmcnt(4)') and 'ASMSTART' in loop[i - 1], l
+    assert not any(re.match(r'\s*global_load_dword', l) for l in loop), 'an ordinary global load inside the ring loop'

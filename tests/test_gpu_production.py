@@ -302,7 +302,7 @@ def test_w1_attention_at_production_sizes(ops, S, n_ctx):
 
 def test_model_steps_take_the_attention_form_meant_for_them(width2):
     """Inside the model (true widths, arena layout, the dispatcher's own choice): a per-frame step over a long context runs attn_gqa128_w1_kernel with two balanced row
-    blocks (343 stacked rows per kv head), a 26-frame chunk the 256-row phase-split form, a decode row the loader / compute ring, a step over a short context the two-slot
+    blocks (343 stacked rows per kv head), a 26-frame chunk the 256-row phase-split form in its contiguous decomposition (attn_gqa128_chunk_kernel), a decode row the loader / compute ring, a step over a short context the two-slot
     form -- mmd_op_attention_last_form is to the attention what mmd_op_gemm_last_plan is to the GEMMs."""
     import ctypes as C
     from mmduet_amd._lib import lib, check
@@ -310,7 +310,7 @@ def test_model_steps_take_the_attention_form_meant_for_them(width2):
     A = m.new_cache(initial_tokens=15000 + 4096)
     check(lib().mmd_kv_debug_set_len(A.arena.h, 15000), m._ctx, 'set_len')          # (the slots hold zeros: same traffic, same kernels)
     form = (C.c_int * 2)()
-    for S, want in ((49, 5), (98, 5), (109, 5), (110, 4), (1274, 4), (1, 3), (2, 3)):
+    for S, want in ((49, 5), (98, 5), (109, 5), (110, 4), (1274, 8), (147, 4), (1, 3), (2, 3)):
         x = (torch.randn(1, S, m.config.hidden_size, device=m.device) * 0.5).to(torch.bfloat16)
         out = m(inputs_embeds=x, past_key_values=type(A)(A.arena, 15000))
         torch.cuda.synchronize()
@@ -324,6 +324,52 @@ def test_model_steps_take_the_attention_form_meant_for_them(width2):
     m(inputs_embeds=(torch.randn(1, 49, m.config.hidden_size, device=m.device) * 0.5).to(torch.bfloat16), past_key_values=type(B)(B.arena, 1000))
     torch.cuda.synchronize(); lib().mmd_op_attention_last_form(form)
     assert form[0] == 4                              # under 4096 keys the two-slot form stays (shorter pipeline fill)
+
+
+# (multi-frame chunks in the contiguous decomposition of attn_chunk.h, variant 6 = forced: units cut in 2 - 3 parts, units that one block covers alone (written straight to the
+#  output), many short units per block (first chunk of a stream), a single kv-head row block, ragged last row block, contexts on / off tile boundaries)
+CHUNK_SHAPES = [(1274, 0), (1274, 15000), (1274, 30000), (1323, 8000), (147, 0), (147, 1), (150, 63), (183, 64), (200, 100), (300, 70000), (637, 3), (1911, 27000), (2058, 127),
+                (512, 4097), (37, 129), (392, 15000), (40, 5000)]
+
+
+@pytest.mark.parametrize('S,n_ctx', CHUNK_SHAPES)
+def test_chunk_kernel_contiguous_decomposition(ops, S, n_ctx):
+    """attn_gqa128_chunk_kernel + attn_combine128_chunk_kernel against fp32 math (same bound as the grid form) and against the grid form itself (accumulation-order noise)."""
+    nh, nkv, d = 28, 4, 128
+    dev = ops.dev
+    g = torch.Generator(device=dev).manual_seed(S + n_ctx)
+    cap = (n_ctx + S + 100 + 63) // 64 * 64
+    q = torch.randn(S, nh * d, generator=g, device=dev).to(torch.bfloat16)
+    K = torch.randn(nkv, cap, d, generator=g, device=dev).to(torch.bfloat16)
+    V = torch.randn(nkv, cap, d, generator=g, device=dev).to(torch.bfloat16)
+    K[:, n_ctx + S:] = 1e4; V[:, n_ctx + S:] = 1e4            # beyond the valid range: must never reach the result
+    o = ops.attention(q, K, V, nh, nkv, d, n_ctx, True, 6)
+    ref = _ref_attention_gpu(q, K, V, nh, nkv, d, n_ctx)
+    err = _rel_err(o, ref)
+    _record(f'attn_chunk_S{S}_n{n_ctx}', rel_err=err)
+    assert torch.isfinite(o.float()).all() and err <= 1.8e-2, err
+    assert _rel_err(o, ops.attention(q, K, V, nh, nkv, d, n_ctx, True, 3).float()) <= 8e-3
+
+
+@pytest.mark.parametrize('S,n_ctx', [(1274, 15000), (1274, 1100), (637, 9000)])
+def test_chunk_kernel_repeats_bit_identical_beside_a_copy_stream(ops, S, n_ctx):
+    """Race screen of attn_gqa128_chunk_kernel: the ring restarts at every segment of a block's range (a barrier between the last P.V reads and the next stages)."""
+    nh, nkv, d = 28, 4, 128
+    dev = ops.dev
+    g = torch.Generator(device=dev).manual_seed(S + n_ctx)
+    cap = (n_ctx + S + 100 + 63) // 64 * 64
+    q = torch.randn(S, nh * d, generator=g, device=dev).to(torch.bfloat16)
+    K = torch.randn(nkv, cap, d, generator=g, device=dev).to(torch.bfloat16)
+    V = torch.randn(nkv, cap, d, generator=g, device=dev).to(torch.bfloat16)
+    noise = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
+    side = torch.cuda.Stream()
+    first = ops.attention(q, K, V, nh, nkv, d, n_ctx, True, 6).clone()
+    for r in range(60):
+        if r % 3 == 0:
+            with torch.cuda.stream(side):
+                noise[:128 << 20].copy_(noise[128 << 20:], non_blocking=True)
+        assert torch.equal(ops.attention(q, K, V, nh, nkv, d, n_ctx, True, 6), first), r
+    torch.cuda.synchronize()
 
 
 @pytest.mark.parametrize('S,n_ctx', [(49, 15000), (98, 30000), (24, 4100)])
