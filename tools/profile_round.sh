@@ -40,6 +40,6 @@ for pass in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY 
   rm -rf $O/pmc_$tag
 done
 python3 $R/tools/pmc_traffic.py $O/${tag}_pmc_FETCH_SIZE.txt $O/${tag}_pmc_WRITE_SIZE.txt > $O/${tag}_pmc_traffic.json 2>> $O/${tag}_bench.err
-python3 $R/tools/bench_gemm.py prod $O/${tag}_gemm_shapes.json auto,big,rx-8w-early,rx-4w-early,rx-8w-m32-ns4-early,ring256-splitK,DBG-no-dma > $O/${tag}_gemm.log 2>&1
+python3 $R/tools/bench_gemm.py prod $O/${tag}_gemm_shapes.json auto,big,rx-8w-early,rx-4w-early,ring256-splitK > $O/${tag}_gemm.log 2>&1
 ATTN_LIBRARY=0 python3 $R/tools/vit_attn_bench.py 5 2>&1 | grep -E "ViT attention|chunk attention" > $O/${tag}_attention_shapes.txt
 tail -c 1500 $O/${tag}_bench.json
