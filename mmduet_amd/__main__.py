@@ -16,7 +16,7 @@ Everything else (flags, JSONL output format, `--start_idx/--end_idx` sharding, s
 `--streams_per_gpu S` runs S videos at a time through shared LLM forwards (mmduet_amd/multistream.py), same records.
 With torchrun, entries are sharded over the ranks (`i % world == rank`) and every rank writes `<output_fname>.rank<r>`; the per-frame head
 scores of all ranks are then met by ONE all-gather (mmduet_amd.distributed.gather_scores: RCCL over xGMI on the GPUs) and rank 0 writes them, keyed by
-question_id in dataset order, to `<output_fname>.scores.json` -- the reference's seam for this is N hand-launched `--start_idx/--end_idx` processes
+question_id in dataset order, to `<output_fname>.scores.json` (and, in response mode, the generated token ids to `<output_fname>.responses.json`) -- the reference's seam for this is N hand-launched `--start_idx/--end_idx` processes
 (test/inference.py:335-338) whose files the user concatenates.
 """
 import json, os, sys
@@ -28,7 +28,7 @@ def main(argv=None):
     from .arguments_live import parse_args
     from .inference import LiveInferForBenchmark
     from .results import result_record
-    from .distributed import init_distributed, shard_indices, shard_shape, gather_scores
+    from .distributed import init_distributed, shard_indices, shard_shape, gather_scores, gather_responses
     from .prefetch import ClipPrefetcher, pin
     args = parse_args('test', argv)
     rank, world, local = init_distributed()
@@ -117,8 +117,11 @@ def main(argv=None):
 
     local_scores = {}          # dataset index -> [[informative, relevance] per frame] of the videos this rank ran
 
-    def keep_scores(i, debug_data):
+    local_ids = {}             # dataset index -> generated token ids of every response of that video
+
+    def keep_scores(i, debug_data, token_ids=()):
         local_scores[i] = [[d['informative_score'], d['relevance_score']] for d in debug_data]
+        local_ids[i] = [[int(t) for t in r] for r in token_ids]
 
     failure = None
     pf = ClipPrefetcher(load_host, mine, workers=args.num_workers)
@@ -142,7 +145,7 @@ def main(argv=None):
                     rec = result_record(video['ex']['question_id'], res['responses'], video['duration'], res['debug_data'], evaluator_format=args.evaluator_format)
                     f_out.write(json.dumps(rec) + '\n')
                     f_out.flush()
-                    keep_scores(video['index'], res['debug_data'])
+                    keep_scores(video['index'], res['debug_data'], res.get('response_token_ids', ()))
                 ms.run([entry(i) for i in mine], on_result=on_result)
             else:
                 n = 0
@@ -166,7 +169,7 @@ def main(argv=None):
                         responses = infer.inference()
                         rec = result_record(data[i]['question_id'], responses, duration, infer.debug_data_list, evaluator_format=args.evaluator_format)
                         f_out.write(json.dumps(rec) + '\n')
-                        keep_scores(i, infer.debug_data_list)
+                        keep_scores(i, infer.debug_data_list, getattr(infer, 'response_token_ids', ()))
                         if n % 5 == 0:
                             f_out.flush()
                         n += 1
@@ -193,6 +196,15 @@ def main(argv=None):
                 merged[key] = allsc[r, slot, :int(lens[r, slot])].tolist()
             with open(f'{args.output_fname}.scores.json', 'w') as f:
                 json.dump(merged, f)
+        # response mode: the generated token ids travel too (their own padded block; skipped on every rank alike when nothing was generated)
+        allids = gather_responses([local_ids.get(i, []) for i in mine], n_max=n_max)
+        if rank == 0 and any(t for w in allids for t in w):
+            ids = {}
+            for i, ex in enumerate(data):
+                key = str(ex['question_id'])
+                ids[key if key not in ids else f'{key}#{i}'] = allids[i % world][i // world]
+            with open(f'{args.output_fname}.responses.json', 'w') as f:
+                json.dump(ids, f)
         import torch.distributed as dist
         dist.barrier()
         if failure is not None:

@@ -97,6 +97,41 @@ def gather_scores(local_scores, t_max=None, n_max=None):
     return out[:, :, 1:], out[:, :, 0, 0].to(torch.int32)
 
 
+def gather_responses(local_ids, n_max):
+    """Response mode: the generated token ids of every stream travel with the scores ("for response mode also [n_resp, 1 + L] int64 token ids").
+    local_ids: per stream of this rank a list of responses, each a list of token ids.  Returns a list [world][n_max] of lists of id lists (empty beyond a rank's streams).
+    One 16-byte shape exchange (responses per stream and their length are not known in advance), then ONE all-gather of the padded block [n_max, r_max, 1 + l_max] int64
+    (column 0 = the response's length, -1 = no response) -- skipped on every rank alike when no rank generated anything."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    dev = torch.device('cuda', torch.cuda.current_device()) if (dist.is_initialized() and dist.get_backend() == 'nccl') else torch.device('cpu')
+    r_loc = max([len(r) for r in local_ids], default=0)
+    l_loc = max([len(t) for r in local_ids for t in r], default=0)
+    if len(local_ids) > n_max:
+        raise ValueError('more local streams than the agreed n_max')
+    r_max, l_max = r_loc, l_loc
+    if world > 1:
+        meta = torch.tensor([r_loc, l_loc], dtype=torch.int64, device=dev)
+        metas = torch.empty(world * 2, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(metas, meta)
+        metas = metas.view(world, 2).cpu()
+        r_max, l_max = int(metas[:, 0].max()), int(metas[:, 1].max())
+    if r_max == 0:
+        return [[[] for _ in range(n_max)] for _ in range(world)]
+    buf = torch.full((n_max, r_max, 1 + l_max), -1, dtype=torch.int64)
+    for i, resp in enumerate(local_ids):
+        for j, t in enumerate(resp):
+            buf[i, j, 0] = len(t)
+            buf[i, j, 1:1 + len(t)] = torch.as_tensor(t, dtype=torch.int64)
+    buf = buf.to(dev)
+    if world == 1:
+        out = buf[None]
+    else:
+        out = torch.empty((world, n_max, r_max, 1 + l_max), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(out.view(world * n_max, r_max, 1 + l_max), buf)
+    out = out.cpu()
+    return [[[out[w, i, j, 1:1 + int(out[w, i, j, 0])].tolist() for j in range(r_max) if int(out[w, i, j, 0]) >= 0] for i in range(n_max)] for w in range(world)]
+
+
 class NativeScoreGather:
     """`mmd_gather_scores` (include/mmduet.h): the all-gather issued by libmmduet_hip itself (RCCL bound at run time) on the
     model's stream.  The 128-byte communicator id is drawn on rank 0 and handed to the other ranks through a torch.distributed

@@ -87,6 +87,13 @@ def test_cli_two_ranks_equal_one_rank(dataset, streams_per_gpu):
         want = [[x['informative_score'], x['relevance_score']] for x in rec['debug_data']]
         got = scores[q]
         assert len(got) == len(want) and all(abs(a - b) <= 5.1e-4 for g, w in zip(got, want) for a, b in zip(g, w)), q      # the record is rounded to 3 decimals
+    # response mode: the generated token ids were gathered too, keyed like the scores; the texts of the records are their decoding
+    resp = json.load(open(two + '.responses.json'))
+    assert list(resp) == qids and resp['broken'] == []
+    for q, rec in ref.items():
+        n_assistant = sum(t['role'] == 'assistant' for t in rec['model_response_list'])
+        assert len(resp[q]) == n_assistant and all(len(t) > 0 for t in resp[q]), q
+    assert not os.path.exists(one + '.responses.json')
     # the product layer really ran on both ranks, through the driver's native entry points
     for log in logs:
         calls = dict(kv.split('=') for kv in [l for l in log.splitlines() if l.startswith('CLI_CALLS ')][-1].split()[1:])
