@@ -1024,15 +1024,16 @@ static void launch_skinny_mt(const GemmP& p, const GemmArgs& a, hipStream_t st) 
 //     which makes the row-strided fragment reads bank-conflict-free.
 //   * rows beyond M are clamped on load and masked at the store; N % BN == 0 and K % 64 == 0 are dispatch conditions.
 // ------------------------------------------------------------------------------------------------------------------
-template <int BN, int EPI, bool F16 = false>
+template <int BN, int EPI, bool F16 = false, int BM = 128>          // BM = 160 (round 5): 1274 rows x 56 column tiles = 448 blocks, two per CU in ONE round, instead of 560 (three rounds on 48 CUs)
 __global__ __launch_bounds__(256) void gemm_big_kernel(GemmP p, int KT) {
-    constexpr int BM = 128, BK = 64;
-    constexpr int TM = 4, TN = BN / 32;                      // 16x16 tiles per wave (wave tile 64 x BN/2)
+    constexpr int BK = 64;
+    static_assert(BM % 32 == 0, "two wave rows of whole 16-row tiles");
+    constexpr int TM = BM / 32, TN = BN / 32;                // 16x16 tiles per wave (wave tile BM/2 x BN/2)
     constexpr int XE = BM * BK, WE = BN * BK;                // elements per buffer image
     __shared__ __attribute__((aligned(16))) bf16_t lds[2 * (XE + WE)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * (BN / 2);
+    const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
     // XCD-aware tile order: consecutive block ids round-robin over the 8 XCDs; give each XCD a contiguous run of
     // n-tiles of one m-panel so the X panel stays in that XCD's L2
     const int nbx = gridDim.x, nby = gridDim.y;
@@ -1166,8 +1167,26 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(GemmP p, int KT) {
     }
 }
 
+// 160-row tiles of the 64-column form (plain / residual epilogue, bf16: a chunk's qkv / o_proj): when they take fewer block rounds per CU.  A CU holds three 128 x 64 blocks
+// (48 KB of LDS each) or two 160 x 64 ones (56 KB); a CU's time ~ blocks it runs x rows per block.
+static bool big_bm160(const GemmArgs& a, int BN) {
+    if (BN != 64 || a.f16 || (a.epi != EPI_NONE && a.epi != EPI_RESID) || a.M < 512) return false;
+    const long long t128 = (long long)(a.N / 64) * cdiv(a.M, 128), t160 = (long long)(a.N / 64) * cdiv(a.M, 160);
+    if (t160 > 512) return false;                                          // (a third block per CU would have to wait for a slot)
+    return (double)cdiv(t160, 256) * 160.0 < (double)cdiv(t128, 256) * 128.0 * 0.97;
+}
 template <int BN>
 static void launch_big(const GemmP& p, const GemmArgs& a, hipStream_t st) {
+    if (big_bm160(a, BN)) {
+        if constexpr (BN == 64) {
+            const int tiles = (a.N / 64) * cdiv(a.M, 160);
+            set_plan(a, GEMM_K_BIG64, tiles, 1, tiles);
+            const dim3 grid(a.N / 64, cdiv(a.M, 160), 1);
+            if (a.epi == EPI_RESID) hipLaunchKernelGGL((gemm_big_kernel<64, EPI_RESID, false, 160>), grid, dim3(256), 0, st, p, a.K >> 5);
+            else hipLaunchKernelGGL((gemm_big_kernel<64, EPI_NONE, false, 160>), grid, dim3(256), 0, st, p, a.K >> 5);
+            return;
+        }
+    }
     const int tiles = (a.N / BN) * cdiv(a.M, 128);
     int splits = 1;
     if (tiles < 320 && a.K >= 8192 && a.epi != EPI_SWIGLU && a.splitk_ws && !a.f16) {      // long K, under one block per CU (down_proj): split K

@@ -65,7 +65,9 @@ PROD_GEMMS = [  # name, M, N, K, epilogue, bias, expects
     ('llm_gate_up', 1274, 37888, 3584, 'swiglu', False, dict(min_tiles=257)),
     ('llm_down', 1274, 3584, 18944, 'resid', False, dict(min_splits=2)),
     ('llm_qkv', 1274, 4608, 3584, 'none', True, dict()),
-    ('llm_o', 1274, 3584, 3584, 'resid', False, dict()),
+    ('llm_o', 1274, 3584, 3584, 'resid', False, dict(tiles=448)),                       # 160-row tiles: 8 x 56 blocks, two per CU in one round (128-row tiles: 560)
+    ('llm_o_13_frames', 637, 3584, 3584, 'resid', False, dict(tiles=224)),
+    ('llm_o_tail', 1303, 3584, 3584, 'resid', True, dict(tiles=504)),                    # M % 160 != 0: masked rows of the last tile
     ('llm_gate_up_tail', 1303, 37888, 3584, 'swiglu', False, dict(min_tiles=257)),      # chunk + text prefix: M % 256 != 0 and M % 16 != 0
 ]
 
@@ -103,6 +105,8 @@ def test_production_gemm_shapes_take_the_production_kernel_and_match_fp32(ops, n
     _record(f'gemm_{name}', M=M, N=N, K=K, epi=epi, rel_err=err, **plan)
     assert torch.isfinite(Y.float()).all()
     assert err <= 1.2e-2 * (2.0 if epi != 'none' else 1.0), (name, err, plan)
+    if 'tiles' in expect:
+        assert plan['kernel'] == 4 and plan['tiles'] == expect['tiles'], plan                                                    # GEMM_K_BIG64 in its 160-row form
     if 'min_tiles' in expect:
         assert plan['kernel'] in RING and plan['tiles'] >= expect['min_tiles'] and plan['blocks'] < plan['tiles'], plan      # persistent multi-tile loop ran
     if 'min_splits' in expect:
