@@ -1250,7 +1250,13 @@ __global__ __launch_bounds__(256, 2) void attn_rowmajor_kernel(AttnP p) {
 //            distinct banks).  With the blocked [d-tile][quad][4][16] image of attn_rowmajor_kernel a 1 KB DMA block touches 32 cache lines and uses a quarter
 //            of each; row-major it touches 7-8 (measured: 153 -> 145 us).
 // Waves 0-1 bring K, waves 2-3 V: five 1 KB blocks each per tile.
+// What bounds it (profiles/r05_vit_attention.md, timing-only builds -DD72_DBG=n): the exponentials -- quarter rate on the vector port, a third of the matrix time at head_dim 72,
+// -21 % without them; every other component is 3-9 %, and the savings add up (vector-issue-bound).  The ten transposing V reads of a half tile MUST be issued as one group:
+// interleaved with the P.V MFMAs (hipcc does that as soon as the half tile is behind a branch) the kernel returns different results from run to run.
 // ------------------------------------------------------------------------------------------------------------------
+#ifndef D72_DBG
+#define D72_DBG 0
+#endif
 template <bool F16>
 __global__ __launch_bounds__(256, 4) void attn_d72_ring_kernel(AttnP p) {
     constexpr int WAVES = 4, RT = 2, NC = 2, DVT = 5, D = 72, KT = 64, NSLOT = 2;
@@ -1344,8 +1350,8 @@ __global__ __launch_bounds__(256, 4) void attn_d72_ring_kernel(AttnP p) {
     for (int i = 0; i < ntile; ++i) {
         const int k0 = i * KT;
         // this wave's five blocks of tile i have landed (nothing younger is in flight yet); the barrier publishes everybody's and retires the slot of tile i - 1
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if (D72_DBG != 8) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier(); }
         if (i + NSLOT - 1 < ntile) stage((i + NSLOT - 1) % NSLOT, k0 + (NSLOT - 1) * KT);
         if (!wave_active) continue;
         const bf16_t* Ks = ring72 + (i % NSLOT) * (2 * IMG);
@@ -1353,6 +1359,7 @@ __global__ __launch_bounds__(256, 4) void attn_d72_ring_kernel(AttnP p) {
         const bool need_mask = k0 + KT > kend;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
+            if (h == 1 && k0 + 32 >= kend) break;          // the second half of the last tile lies wholly behind the keys (729 = 11 tiles + 25 keys): its P is 0, its exponentials -- the limiter of this kernel -- are not computed
             f32x4_t st[RT][2];
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) { st[rt][0] = f32x4_t{0, 0, 0, 0}; st[rt][1] = f32x4_t{0, 0, 0, 0}; }
@@ -1360,16 +1367,16 @@ __global__ __launch_bounds__(256, 4) void attn_d72_ring_kernel(AttnP p) {
             for (int t = 0; t < 2; ++t) {
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
-                    bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + (h * 32 + t * 16 + lr) * KLD + c * 32 + lq * 8);
+                    bf16x8_t kf = D72_DBG == 6 ? qf[0][c] : *reinterpret_cast<const bf16x8_t*>(Ks + (h * 32 + t * 16 + lr) * KLD + c * 32 + lq * 8);
 #pragma unroll
-                    for (int rt = 0; rt < RT; ++rt) st[rt][t] = mfma16<F16>(kf, qf[rt][c], st[rt][t]);
+                    for (int rt = 0; rt < RT; ++rt) { if (D72_DBG == 3) { st[rt][t][0] += (float)kf[0] * (float)qf[rt][c][0]; } else st[rt][t] = mfma16<F16>(kf, qf[rt][c], st[rt][t]); }
                 }
                 // (rows lr >= 8 read the tail from the DUPLICATE in the tenth place: rows lr and lr + 8 are 1280 B = 0 banks apart, the duplicate sits 4 banks further -- the b64 reads of a
                 //  32-lane group then fall on distinct banks; lq >= 2 reads the other copy's bytes: finite, against zeros)
-                const s16x4_t kt = *reinterpret_cast<const s16x4_t*>(Ks + (h * 32 + t * 16 + lr) * KLD + 64 + ((lr >> 3) & 1) * 8 + lq * 4);
+                const s16x4_t kt = D72_DBG == 6 ? qt[0] : *reinterpret_cast<const s16x4_t*>(Ks + (h * 32 + t * 16 + lr) * KLD + 64 + ((lr >> 3) & 1) * 8 + lq * 4);
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) {
-                    if constexpr (F16) st[rt][t] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4_t, kt), __builtin_bit_cast(f16x4_t, qt[rt]), st[rt][t], 0, 0, 0);
+                    if (D72_DBG == 3) { st[rt][t][1] += (float)kt[0]; } else if constexpr (F16) st[rt][t] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4_t, kt), __builtin_bit_cast(f16x4_t, qt[rt]), st[rt][t], 0, 0, 0);
                     else st[rt][t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kt, qt[rt], st[rt][t], 0, 0, 0);
                 }
             }
@@ -1391,8 +1398,8 @@ __global__ __launch_bounds__(256, 4) void attn_d72_ring_kernel(AttnP p) {
                             if (!(t * 16 + r < lim)) sv[t * 4 + r] = -INFINITY;
                 }
                 // (a chain, not a tree: every step but the last folds into a three-input v_max3_f32 -- 4 instructions for the 8 values instead of 7; max is exact in any order)
-                float mx = fmaxf(fmaxf(fmaxf(fmaxf(fmaxf(fmaxf(fmaxf(sv[0], sv[1]), sv[2]), sv[3]), sv[4]), sv[5]), sv[6]), sv[7]);
-                mx = quad_lanes_max(mx);
+                float mx = D72_DBG == 7 ? sv[0] : fmaxf(fmaxf(fmaxf(fmaxf(fmaxf(fmaxf(fmaxf(sv[0], sv[1]), sv[2]), sv[3]), sv[4]), sv[5]), sv[6]), sv[7]);
+                if (D72_DBG != 7) mx = quad_lanes_max(mx);
                 mx *= p.scale_log2;
                 if (mx > m_run[rt] + ATTN_DEFER) {
                     const float alpha = __builtin_amdgcn_exp2f(m_run[rt] - mx);
@@ -1407,8 +1414,8 @@ __global__ __launch_bounds__(256, 4) void attn_d72_ring_kernel(AttnP p) {
 #pragma unroll
                 for (int e = 0; e < 8; e += 2) {          // the scale-and-shift FMA two elements at a time (v_pk_fma_f32: the same fused operation per element)
                     const f32x2_t a = __builtin_elementwise_fma(f32x2_t{sv[e], sv[e + 1]}, f32x2_t{p.scale_log2, p.scale_log2}, f32x2_t{neg_m, neg_m});
-                    const float p0 = __builtin_amdgcn_exp2f(a[0]), p1 = __builtin_amdgcn_exp2f(a[1]);
-                    psum += p0; psum += p1;
+                    const float p0 = D72_DBG == 1 ? a[0] : __builtin_amdgcn_exp2f(a[0]), p1 = D72_DBG == 1 ? a[1] : __builtin_amdgcn_exp2f(a[1]);
+                    if (D72_DBG != 2) { psum += p0; psum += p1; }
                     pk[e] = (short)f2raw<F16>(p0); pk[e + 1] = (short)f2raw<F16>(p1);
                 }
                 l_run[rt] += psum;
@@ -1419,21 +1426,24 @@ __global__ __launch_bounds__(256, 4) void attn_d72_ring_kernel(AttnP p) {
             // tile to land instead of the whole tile.  With four blocks per CU that costs nothing measurable -- and the alternative, issuing the reads from an inline-asm
             // block the compiler cannot see into, gave run-to-run DIFFERENT results as soon as the score MFMAs were reordered (profiles/r03_attention_experiments.md): kept visible
             s16x4_t vlo[DVT], vhi[DVT];
+            __builtin_amdgcn_sched_barrier(0);          // (the ten transpose reads stay ONE group between the softmax and the P.V MFMAs: see above)
             {
                 const char __attribute__((address_space(3)))* vb = (const char __attribute__((address_space(3)))*)Vs + ((h * 32 + lq * 4 + (lr >> 2)) * 160 + (lr & 3) * 8);
 #pragma unroll
                 for (int t = 0; t < DVT; ++t) {
+                    if (D72_DBG == 5) { vlo[t] = qt[0]; vhi[t] = qt[1]; continue; }
                     vlo[t] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(vb + t * 32));
                     vhi[t] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(vb + t * 32 + 2560));
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < DVT; ++t) {
                 const s16x4_t lo = vlo[t], hi = vhi[t];
                 s16x8_t vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 bf16x8_t vfb = __builtin_bit_cast(bf16x8_t, vf);
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt) oacc[rt][t] = mfma16<F16>(vfb, pf[rt], oacc[rt][t]);
+                for (int rt = 0; rt < RT; ++rt) { if (D72_DBG == 4) { oacc[rt][t][0] += (float)vfb[0] * (float)pf[rt][0]; } else oacc[rt][t] = mfma16<F16>(vfb, pf[rt], oacc[rt][t]); }
             }
         }
     }

@@ -21,6 +21,7 @@ fl = 4.0 * 35 * 729 * 729 * 1152
 us = sorted(ts)[len(ts) // 2]
 res['vit_attention_35_frames'] = dict(us_per_layer=round(us, 1), tflops=round(fl / us / 1e6, 1), frac_of_2500=round(fl / us / 1e6 / 2500, 3))
 print('ViT attention, 35 frames x 16 heads x 729^2 x 72:', res['vit_attention_35_frames'], flush=True)
+if os.environ.get('VIT_ONLY'): sys.exit(0)
 # chunk attention: 26-frame chunks at growing context
 x = (torch.randn(1, 1274, cfg.hidden_size, device=dev) * 0.5).to(torch.bfloat16)
 cache = None
