@@ -18,6 +18,9 @@
 
 // unit geometry: start[bx] = key tiles of the units 0 .. bx - 1 of one kv head (start[qblocks] = tiles per kv head); built on the host once per launch, rides in the
 // kernel argument (the attention kernel and the merge read it with scalar loads: recomputing it per wave cost the merge 280 us at 35 k rows)
+#ifndef CHUNK_DBG
+#define CHUNK_DBG 0          // timing-only ablations (wrong results): tools/probes/chunk_ablate.sh
+#endif
 constexpr int CHUNK_TAB = 128, CHUNK_UNITS = 512;
 struct ChunkTab { int qblocks; int start[CHUNK_TAB + 1]; unsigned short b0[CHUNK_UNITS], b1[CHUNK_UNITS]; };          // b0 / b1[kvh * qblocks + bx]: first / last block that shares the unit
 // block b of nb owns linear tiles [b * W / nb, (b + 1) * W / nb)
@@ -82,6 +85,7 @@ __global__ __launch_bounds__(512, 1) void attn_gqa128_chunk_kernel(AttnP p, Chun
         first_seg = false;
 
         auto stage = [&](int slot, long long k0) {
+            if (CHUNK_DBG == 9) return;
             bf16_t* ks = kv + slot * 2 * TILE;
             bf16_t* vt = ks + TILE;
             const char* kb = (const char*)(Kg + k0 * D);
@@ -135,9 +139,10 @@ __global__ __launch_bounds__(512, 1) void attn_gqa128_chunk_kernel(AttnP p, Chun
         // start of global segment sg: this wave's pieces of tile k have landed (tile k + 1 may stay in flight), every LDS read of the previous interval is done, block barrier,
         // then (group 1 here, group 0 behind its softmax) tile k + 2 goes out into the slot of tile k - 2
         auto seg_barrier = [&](int k) {
+            if (CHUNK_DBG != 8) {
             if (k < ntile) { if (k + 1 < ntile) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_barrier(); }
             if (grp == 1 && k + 2 < ntile) stage((k + 2) & (NSLOT - 1), kbeg + (long long)(k + 2) * KT);
         };
         auto stage_after_softmax = [&](int i) { if (grp == 0 && i + 2 < ntile) stage((i + 2) & (NSLOT - 1), kbeg + (long long)(i + 2) * KT); };
@@ -174,12 +179,12 @@ __global__ __launch_bounds__(512, 1) void attn_gqa128_chunk_kernel(AttnP p, Chun
             if constexpr (g < 4) {
                 constexpr int h = g >> 1, tq = (g & 1) * 4;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) fr[u] = *reinterpret_cast<const bf16x8_t*>(Vt + ((tq + u) * 16 + lr) * KT + (((h * 4 + lq) ^ vsw) * 8));
+                for (int u = 0; u < 4; ++u) fr[u] = CHUNK_DBG == 5 ? qf[0][u] : *reinterpret_cast<const bf16x8_t*>(Vt + ((tq + u) * 16 + lr) * KT + (((h * 4 + lq) ^ vsw) * 8));
             } else {
                 constexpr int h = (g - 4) >> 1, c0 = ((g - 4) & 1) * 2;
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
-                    fr[u] = *reinterpret_cast<const bf16x8_t*>(Ks + (h * 32 + (lr >> 2) * 8 + (u & 1) * 4 + (lr & 3)) * D + ((((c0 + (u >> 1)) * 4 + lq) ^ lr) * 8));
+                    fr[u] = CHUNK_DBG == 6 ? qf[1][u] : *reinterpret_cast<const bf16x8_t*>(Ks + (h * 32 + (lr >> 2) * 8 + (u & 1) * 4 + (lr & 3)) * D + ((((c0 + (u >> 1)) * 4 + lq) ^ lr) * 8));
             }
         };
         auto a_mma = [&](auto G_, const bf16x8_t (&fr)[4]) {
@@ -189,7 +194,7 @@ __global__ __launch_bounds__(512, 1) void attn_gqa128_chunk_kernel(AttnP p, Chun
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
-                    for (int rt = 0; rt < RT; ++rt) oacc[rt][tq + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[u], pf[rt][h], oacc[rt][tq + u], 0, 0, 0);
+                    for (int rt = 0; rt < RT; ++rt) { if (CHUNK_DBG == 4) oacc[rt][tq + u][0] += (float)fr[u][0] * (float)pf[rt][h][0]; else oacc[rt][tq + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[u], pf[rt][h], oacc[rt][tq + u], 0, 0, 0); }
             } else {
                 constexpr int h = (g - 4) >> 1, c0 = ((g - 4) & 1) * 2;
 #pragma unroll
@@ -197,7 +202,8 @@ __global__ __launch_bounds__(512, 1) void attn_gqa128_chunk_kernel(AttnP p, Chun
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt) {
                         const int c = c0 + (u >> 1), t = u & 1;
-                        st[rt][h][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[u], qf[rt][c], c == 0 ? f32x4_t{0, 0, 0, 0} : st[rt][h][t], 0, 0, 0);
+                        if (CHUNK_DBG == 3) { if (c == 0) st[rt][h][t] = f32x4_t{0, 0, 0, 0}; st[rt][h][t][0] += (float)fr[u][0] * (float)qf[rt][c][0]; }
+                        else st[rt][h][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[u], qf[rt][c], c == 0 ? f32x4_t{0, 0, 0, 0} : st[rt][h][t], 0, 0, 0);
                     }
             }
         };
@@ -229,9 +235,9 @@ __global__ __launch_bounds__(512, 1) void attn_gqa128_chunk_kernel(AttnP p, Chun
                             for (int r = 0; r < 4; ++r)
                                 if (!(h * 32 + t * 4 + r < rel)) SV(h, t, r) = -INFINITY;
                 }
-                float mx = fmaxf(fmaxf(fmaxf(fmaxf(SV(0, 0, 0), SV(0, 0, 1)), fmaxf(SV(0, 0, 2), SV(0, 0, 3))), fmaxf(fmaxf(SV(0, 1, 0), SV(0, 1, 1)), fmaxf(SV(0, 1, 2), SV(0, 1, 3)))),
+                float mx = CHUNK_DBG == 7 ? SV(0, 0, 0) : fmaxf(fmaxf(fmaxf(fmaxf(SV(0, 0, 0), SV(0, 0, 1)), fmaxf(SV(0, 0, 2), SV(0, 0, 3))), fmaxf(fmaxf(SV(0, 1, 0), SV(0, 1, 1)), fmaxf(SV(0, 1, 2), SV(0, 1, 3)))),
                                  fmaxf(fmaxf(fmaxf(SV(1, 0, 0), SV(1, 0, 1)), fmaxf(SV(1, 0, 2), SV(1, 0, 3))), fmaxf(fmaxf(SV(1, 1, 0), SV(1, 1, 1)), fmaxf(SV(1, 1, 2), SV(1, 1, 3)))));
-                mx = quad_lanes_max(mx);
+                if (CHUNK_DBG != 7) mx = quad_lanes_max(mx);
                 mx *= p.scale_log2;
                 if (mx > m_run[rt] + ATTN_DEFER) {
                     const float alpha = __builtin_amdgcn_exp2f(m_run[rt] - mx);
@@ -246,7 +252,7 @@ __global__ __launch_bounds__(512, 1) void attn_gqa128_chunk_kernel(AttnP p, Chun
                 for (int h = 0; h < 2; ++h) {
                     s16x8_t pk;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { float pv = __builtin_amdgcn_exp2f(fmaf(SV(h, e >> 2, e & 3), p.scale_log2, neg_m)); psum += pv; pk[e] = (short)f2bf(pv); }
+                    for (int e = 0; e < 8; ++e) { const float a_ = fmaf(SV(h, e >> 2, e & 3), p.scale_log2, neg_m); float pv = CHUNK_DBG == 1 ? a_ : __builtin_amdgcn_exp2f(a_); if (CHUNK_DBG != 2) psum += pv; pk[e] = (short)f2bf(pv); }
                     pf[rt][h] = __builtin_bit_cast(bf16x8_t, pk);
                 }
 #undef SV
