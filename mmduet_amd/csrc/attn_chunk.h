@@ -88,8 +88,12 @@ __global__ __launch_bounds__(512, 1) void attn_gqa128_chunk_kernel(AttnP p, Chun
             if (CHUNK_DBG == 9) return;
             bf16_t* ks = kv + slot * 2 * TILE;
             bf16_t* vt = ks + TILE;
-            const char* kb = (const char*)(Kg + k0 * D);
-            const char* vb = (const char*)(Vg + (((k0 >> 6) * D) << 6));
+            // (the tile's two bases as OPAQUE scalar pairs: left visible, hipcc re-associates base + tile offset + lane offset inside the tile loop and falls back to 64-bit
+            //  per-lane addresses -- two v_lshl_add_u64 + two moves per DMA; opaque, every DMA is `global_load_lds_dwordx4 v_off32, s[base]`)
+            unsigned long long kbu = (unsigned long long)(Kg + k0 * D), vbu = (unsigned long long)(Vg + (((k0 >> 6) * D) << 6));
+            asm volatile("" : "+s"(kbu), "+s"(vbu));
+            const char* kb = (const char*)kbu;
+            const char* vb = (const char*)vbu;
 #pragma unroll
             for (int j = 0; j < NPC; ++j) {
                 const int pc = wave + WAVES * j;
