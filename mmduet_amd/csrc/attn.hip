@@ -317,7 +317,9 @@ extern "C" int mmd_debug_attn_timing(unsigned long long* out8, int reset) {
 //     of its kv head from L2 with one 32 KB tile in flight (tools/attn_timing.py: 43-59 % of every wave's cycles sit in the per-tile wait + barrier; 2.1 GB per
 //     launch at 15 k keys = 5.7 TB/s).  256 rows halve that traffic per flop and three tiles in flight cover the L2 latency.
 template <int RT, int NSLOT = 2, int WAVES = 4>
-__global__ __launch_bounds__(WAVES * 64, (NSLOT == 2 && WAVES == 4) ? 2 : 1) void attn_gqa128_kernel(AttnP p) {
+// (launch bound: the four-wave forms are compiled for TWO blocks per CU although the decode ring's 128 KB of LDS admit one -- at one wave per SIMD hipcc has 512 registers, moves the
+//  MFMA accumulators to AGPRs and pays a v_accvgpr move for every score it reads back: 276 of them and a dead 68-byte scratch frame in the decode form; bounded to 256 there are none)
+__global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void attn_gqa128_kernel(AttnP p) {
     constexpr int D = 128, KT = 64, TILE = KT * D;              // one K tile = one V^T tile = 8192 elements = 16 KB, contiguous in the arena
     constexpr int PF = NSLOT - 1;                                // tiles in flight beyond the one being consumed
     constexpr int BR = WAVES * 16 * RT;                          // query rows per block
@@ -449,21 +451,37 @@ __global__ __launch_bounds__(WAVES * 64, (NSLOT == 2 && WAVES == 4) ? 2 : 1) voi
     // counted waits; wave 0 issues no DMA at all, so the compiler's vmcnt(0) in front of its q prologue (slab sum + RoPE) covers the q loads only and the
     // prologue runs under the ring's first three tiles.  (A plain VGPR load next to LDS-DMAs in ONE wave always gets vmcnt(0) from hipcc.)
     const int ldr = wave - 1;
-    auto stage3 = [&](int slot, long long k0) {
-        bf16_t* ks = kv + slot * 2 * TILE;
-        bf16_t* vt = ks + TILE;
-        const long long blk = k0 >> 6;
+    // (per-lane byte offsets of the loader's 11 pieces, fixed for the kernel; per tile two opaque scalar bases: every DMA in the scalar-base + 32-bit-offset form -- the loaders'
+    //  address arithmetic sits on the kernel's critical path, in front of the first three tiles)
+    unsigned off3[11];
+    if constexpr (NSLOT == 4 && !ALLRING) {
 #pragma unroll
         for (int j = 0; j < 11; ++j) {
             const int pp = ldr + 3 * j;
             if (pp < 16) {
                 const int key = pp * 4 + (lane >> 4);
-                const bf16_t* src = Kg + (k0 + key) * p.k_ts + (((lane & 15) ^ ((((key >> 3) & 3) << 2) | (key & 3))) * 8);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(ks + pp * 512), 16, 0, 2);
-            } else if (pp < 32) {
+                off3[j] = (unsigned)((key * (int)p.k_ts + (((lane & 15) ^ ((((key >> 3) & 3) << 2) | (key & 3))) * 8)) * 2);
+            } else {
                 const int pc = pp - 16, dim = pc * 8 + (lane >> 3);
-                const bf16_t* vsrc = Vg + ((blk * D + dim) << 6) + (((lane & 7) ^ ((dim >> 1) & 7)) * 8);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)vsrc, (__attribute__((address_space(3))) void*)(vt + pc * 512), 16, 0, 2);
+                off3[j] = (unsigned)(((dim << 6) + (((lane & 7) ^ ((dim >> 1) & 7)) * 8)) * 2);
+            }
+        }
+    }
+    auto stage3 = [&](int slot, long long k0) {
+        bf16_t* ks = kv + slot * 2 * TILE;
+        bf16_t* vt = ks + TILE;
+        unsigned long long kbu = (unsigned long long)(Kg + k0 * p.k_ts), vbu = (unsigned long long)(Vg + (((k0 >> 6) * D) << 6));
+        asm volatile("" : "+s"(kbu), "+s"(vbu));
+        const char* kb = (const char*)kbu; const char* vb = (const char*)vbu;
+#pragma unroll
+        for (int j = 0; j < 11; ++j) {
+            const int pp = ldr + 3 * j;
+            unsigned o = off3[j];
+            asm volatile("" : "+v"(o));
+            if (pp < 16) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kb + o), (__attribute__((address_space(3))) void*)(ks + pp * 512), 16, 0, 2);
+            } else if (pp < 32) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vb + o), (__attribute__((address_space(3))) void*)(vt + (pp - 16) * 512), 16, 0, 2);
             }
         }
     };
