@@ -1275,6 +1275,11 @@ __global__ __launch_bounds__(256, 2) void attn_rowmajor_kernel(AttnP p) {
 #ifndef D72_DBG
 #define D72_DBG 0
 #endif
+// The 16-deep MFMA that finishes a score tile (dims 64..71) reads the 32-deep MFMA's result as SrcC.  Issued DIRECTLY behind its producer (hipcc does that whenever its schedule of
+// the half tile shifts: twice this round, with a branch and with a scalar FMA in the softmax) the first row tile of every wave came back wrong and different from run to run -- with
+// one independent MFMA between the two it is right (the order of the source: rt 0, rt 1, tail rt 0, tail rt 1).  The barriers below pin exactly that order of the matrix instructions
+// (mask: everything but MFMAs may still cross); tests/test_attn_isa.py checks the distance in the listing.
+#define D72_MFMA_PIN 0x7F6
 template <bool F16>
 __global__ __launch_bounds__(256, 4) void attn_d72_ring_kernel(AttnP p) {
     constexpr int WAVES = 4, RT = 2, NC = 2, DVT = 5, D = 72, KT = 64, NSLOT = 2;
@@ -1387,7 +1392,10 @@ __global__ __launch_bounds__(256, 4) void attn_d72_ring_kernel(AttnP p) {
                 for (int c = 0; c < NC; ++c) {
                     bf16x8_t kf = D72_DBG == 6 ? qf[0][c] : *reinterpret_cast<const bf16x8_t*>(Ks + (h * 32 + t * 16 + lr) * KLD + c * 32 + lq * 8);
 #pragma unroll
-                    for (int rt = 0; rt < RT; ++rt) { if (D72_DBG == 3) { st[rt][t][0] += (float)kf[0] * (float)qf[rt][c][0]; } else st[rt][t] = mfma16<F16>(kf, qf[rt][c], st[rt][t]); }
+                    for (int rt = 0; rt < RT; ++rt) {
+                        if (D72_DBG == 3) { st[rt][t][0] += (float)kf[0] * (float)qf[rt][c][0]; } else st[rt][t] = mfma16<F16>(kf, qf[rt][c], st[rt][t]);
+                        if (c == NC - 1) __builtin_amdgcn_sched_barrier(D72_MFMA_PIN);
+                    }
                 }
                 // (rows lr >= 8 read the tail from the DUPLICATE in the tenth place: rows lr and lr + 8 are 1280 B = 0 banks apart, the duplicate sits 4 banks further -- the b64 reads of a
                 //  32-lane group then fall on distinct banks; lq >= 2 reads the other copy's bytes: finite, against zeros)
@@ -1396,6 +1404,7 @@ __global__ __launch_bounds__(256, 4) void attn_d72_ring_kernel(AttnP p) {
                 for (int rt = 0; rt < RT; ++rt) {
                     if (D72_DBG == 3) { st[rt][t][1] += (float)kt[0]; } else if constexpr (F16) st[rt][t] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4_t, kt), __builtin_bit_cast(f16x4_t, qt[rt]), st[rt][t], 0, 0, 0);
                     else st[rt][t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kt, qt[rt], st[rt][t], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(D72_MFMA_PIN);
                 }
             }
             bf16x8_t pf[RT];
@@ -1430,9 +1439,9 @@ __global__ __launch_bounds__(256, 4) void attn_d72_ring_kernel(AttnP p) {
                 float psum = 0.f;
                 s16x8_t pk;
 #pragma unroll
-                for (int e = 0; e < 8; e += 2) {          // the scale-and-shift FMA two elements at a time (v_pk_fma_f32: the same fused operation per element)
-                    const f32x2_t a = __builtin_elementwise_fma(f32x2_t{sv[e], sv[e + 1]}, f32x2_t{p.scale_log2, p.scale_log2}, f32x2_t{neg_m, neg_m});
-                    const float p0 = D72_DBG == 1 ? a[0] : __builtin_amdgcn_exp2f(a[0]), p1 = D72_DBG == 1 ? a[1] : __builtin_amdgcn_exp2f(a[1]);
+                for (int e = 0; e < 8; e += 2) {          // (two scalar FMAs: v_pk_fma_f32 is the same fused operation per element but measures SLOWER here -- 147.6 vs 145.0 us per layer)
+                    const float a0 = fmaf(sv[e], p.scale_log2, neg_m), a1 = fmaf(sv[e + 1], p.scale_log2, neg_m);
+                    const float p0 = D72_DBG == 1 ? a0 : __builtin_amdgcn_exp2f(a0), p1 = D72_DBG == 1 ? a1 : __builtin_amdgcn_exp2f(a1);
                     if (D72_DBG != 2) { psum += p0; psum += p1; }
                     pk[e] = (short)f2raw<F16>(p0); pk[e + 1] = (short)f2raw<F16>(p1);
                 }

@@ -93,11 +93,26 @@ def test_vit_ring_kernel_fits_four_blocks_and_keeps_its_dma_in_flight(attn_isa, 
     first_tr = min(i for i, l in enumerate(loop) if 'ds_read_b64_tr_b16' in l)
     assert waits[0][0] < first_tr and waits[1][0] < first_tr                 # both in front of the tile's first V read: nothing waits on the NEXT tile's DMA behind it
     assert not any(re.match(r'\s*global_load_dword', l) for l in loop), 'an ordinary global load inside the ring loop'
-    # the ten transposing V reads of a half tile are ISSUED as one group (sched_barrier fences in the source): with P.V MFMAs issued between them the kernel returned different
-    # results from run to run although every counted wait in the listing was right (seen in round 3 with an asm block, again in round 5 when a branch changed hipcc's schedule)
+    # the ten transposing V reads of a half tile are issued as one group (sched_barrier fences in the source; not a correctness condition, see below)
     tr = [i for i, l in enumerate(loop) if 'ds_read_b64_tr_b16' in l]
     for grp in (tr[:10], tr[10:]):
         assert not any('v_mfma' in l for l in loop[grp[0]:grp[-1] + 1]), 'an MFMA between the transposing V reads of one half tile'
+    # THE correctness condition found in round 5: the 16-deep MFMA that finishes a score tile reads a 32-deep MFMA's result as SrcC; issued directly behind its producer the
+    # first row tile of every wave came back wrong and different from run to run.  At least one other MFMA has to sit between producer and consumer (D72_MFMA_PIN in the source).
+    mf = [(i, l.strip()) for i, l in enumerate(loop) if 'v_mfma' in l]
+    def _regs(tok):
+        m = re.match(r'v\[(\d+):(\d+)\]', tok.strip())
+        return set(range(int(m.group(1)), int(m.group(2)) + 1)) if m else set()
+    checked = 0
+    for k, (i, l) in enumerate(mf):
+        if 'v_mfma_f32_16x16x16' not in l: continue
+        ops_ = [x.strip() for x in l.split(None, 1)[1].split(',')]
+        srcc = _regs(ops_[3])
+        prev = mf[k - 1][1]
+        pdst = _regs(prev.split(None, 1)[1].split(',')[0])
+        assert not (srcc & pdst and 'v_mfma_f32_16x16x32' in prev), f'16-deep MFMA directly behind the 32-deep MFMA that produces its SrcC: {prev} -> {l}'
+        checked += 1
+    assert checked == 8
 
 
 def test_w1_kernel_has_no_spills_vgpr_form_mfmas_and_only_counted_waits(attn_isa):
