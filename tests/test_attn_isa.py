@@ -162,3 +162,18 @@ def test_chunk_kernel_contiguous_form_has_no_spills_and_only_counted_waits(attn_
         if 'vmcnt' in l and not l.strip().startswith(';'):
             assert l.strip() in ('s_waitcnt vmcnt(0)', 's_waitcnt vmcnt(4)') and 'ASMSTART' in loop[i - 1], l
     assert not any(re.match(r'\s*global_load_dword', l) for l in loop), 'an ordinary global load inside the ring loop'
+
+
+@pytest.mark.parametrize('mangled', ['_Z24attn_gqa128_chunk_kernel5AttnP8ChunkTab', '_Z18attn_gqa128_kernelILi2ELi4ELi8EEv5AttnP', '_Z18attn_gqa128_kernelILi1ELi4ELi4EEv5AttnP',
+                                     '_Z18attn_gqa128_kernelILi1ELi2ELi4EEv5AttnP', '_Z18attn_gqa128_kernelILi2ELi2ELi4EEv5AttnP', '_Z21attn_gqa128_w1_kernelILi2ELi8EEv5AttnP',
+                                     '_Z20attn_d72_ring_kernelILb1EEv5AttnP', '_Z20attn_d72_ring_kernelILb0EEv5AttnP'])
+def test_ring_attention_dmas_take_the_scalar_base_form_and_no_agpr_moves(attn_isa, mangled):
+    """Round 5: inside the chunk and decode loops hipcc had re-associated (scalar base + tile offset + lane offset) into 64-bit per-lane addresses -- two v_lshl_add_u64 + two moves
+    per LDS-DMA of loops that are bound by the vector issue port; the bases are opaque scalar pairs now and every DMA is `global_load_lds_dwordx4 v_off32, s[base:base+1]`.  And the
+    decode form, compiled for one wave per SIMD, kept its accumulators in AGPRs (a v_accvgpr move per score read back): all attention forms are bounded to <= 256 registers."""
+    body = attn_isa[re.search(r'^' + mangled + r':', attn_isa, re.M).start():]
+    lines = body[:body.index('.Lfunc_end')].split('\n')
+    dma = [l.strip() for l in lines if 'global_load_lds_dwordx4' in l]
+    form = r'global_load_lds_dwordx4 v\d+, (s\[|vcc)'          # (the scalar pair may be vcc)
+    assert dma and all(re.match(form, l) for l in dma), [l for l in dma if not re.match(form, l)][:3]
+    assert not any('v_accvgpr' in l for l in lines)
