@@ -190,6 +190,29 @@ int mmd_frame_step_multi(mmd_ctx* ctx, mmd_stream* const* streams, const int32_t
                          const int32_t* head_rows, int n_head_rows, float* heads_out_host,
                          const int32_t* hidden_rows, int n_hidden_rows, void* hidden_rows_out, float* logits_out);
 
+/* Scheduler rounds with the greedy sampling on the device (the multi-stream form of fast_greedy_generate, models/modeling_live.py:51-77; the offline drivers
+ * test/inference.py:257-274 call it once per response).  With several streams per GPU the token loops of all talking streams advance together, one token per round,
+ * inside the forward that also carries the watching streams' frame chunks; per round the host sees the head logits and ONE token id per talking stream -- no logits
+ * tensor, no host arg-max, no embedding call.
+ * mmd_sampler = greedy sampling state of one stream on the device: the token drawn last and the repetition-penalty list that persists across the turns of a video
+ * (models/modeling_live.py:60-66).  mmd_sampler_begin starts a response: eos id, penalty (<= 0: none), the ids generated so far in this video (host), the most tokens
+ * this response may add.  The sampler then grows the list itself: a drawn token joins it unless it is EOS (EOS is returned but neither fed back nor penalised).
+ * mmd_round_multi = mmd_frame_step_multi with, per segment j, its input rows seg_embeds[j] [seg_rows[j], hidden] (device, ctx dtype) and flags:
+ *   MMD_SEG_FEED    the segment is ONE row, the embedding of the token samplers[j] drew in an earlier round (gathered on the device; seg_embeds[j] is ignored);
+ *   MMD_SEG_SAMPLE  after the step: lm_head over the segment's last row, repetition penalty over samplers[j]'s list, arg-max (first maximal index) -> tokens_out_host[j]
+ *                   and samplers[j]'s token slot.
+ * tokens_out_host [n_segs] receives -1 for the other segments; heads as in mmd_frame_step_multi.  ONE stream synchronisation per round (none when nothing is read).
+ * At most 32 feed and 32 sampling segments per round. */
+typedef struct mmd_sampler mmd_sampler;
+#define MMD_SEG_FEED 1
+#define MMD_SEG_SAMPLE 2
+int mmd_sampler_create(mmd_ctx* ctx, mmd_sampler** out);
+void mmd_sampler_destroy(mmd_sampler* sp);
+int mmd_sampler_begin(mmd_sampler* sp, int64_t eos_id, float rep_penalty, const int64_t* prev_ids_host, int n_prev, int max_new);
+int mmd_sampler_prev_len(const mmd_sampler* sp);          /* entries of the penalty list that count */
+int mmd_round_multi(mmd_ctx* ctx, mmd_stream* const* streams, const int32_t* seg_rows, int n_segs, const void* const* seg_embeds, mmd_sampler* const* samplers,
+                    const int32_t* seg_flags, const int32_t* head_rows, int n_head_rows, float* heads_out_host, int64_t* tokens_out_host);
+
 /* replaces fast_greedy_generate (models/modeling_live.py:51-77): feeds prompt_embeds [S,hidden], then up to max_new
  * greedy steps.  prev_ids_host / n_prev: the repetition-penalty list persisted across turns (grown in place, capacity
  * prev_cap); rep_penalty <= 0 disables the penalty (and the list is not updated, like the reference).  EOS is written

@@ -86,6 +86,11 @@ _SIGS = {
     'mmd_frame_step': (_I, [_VP, _VP, _VP, _I, _VP, _I, _VP]),
     'mmd_llm_step_multi': (_I, [_VP, C.POINTER(_VP), C.POINTER(C.c_int32), _I, _VP, _VP]),
     'mmd_frame_step_multi': (_I, [_VP, C.POINTER(_VP), C.POINTER(C.c_int32), _I, _VP, C.POINTER(C.c_int32), _I, C.POINTER(_F), C.POINTER(C.c_int32), _I, _VP, _VP]),
+    'mmd_sampler_create': (_I, [_VP, C.POINTER(_VP)]),
+    'mmd_sampler_destroy': (None, [_VP]),
+    'mmd_sampler_begin': (_I, [_VP, _I64, _F, _VP, _I, _I]),
+    'mmd_sampler_prev_len': (_I, [_VP]),
+    'mmd_round_multi': (_I, [_VP, C.POINTER(_VP), C.POINTER(C.c_int32), _I, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, C.POINTER(_F), C.POINTER(_I64)]),
     'mmd_greedy_generate': (_I, [_VP, _VP, _VP, _I, _I64, _F, _VP, C.POINTER(_I), _I, _VP, _I, C.POINTER(_I)]),
     'mmd_prof_enable': (_I, [_VP, _I]),
     'mmd_prof_set_stride': (_I, [_VP, _I]),

@@ -30,6 +30,7 @@ struct AttnP {
     int v_tr;          // V stored transposed in 64-token blocks: (tok, e) at ((tok>>6)*d + e)*64 + (tok&63) inside the head region
     float scale_log2;
     const float* slabs; int n_slabs; const void* qkv_bias; const float2* rope_tab;     // AttnArgs::qkv_slabs (attn_gqa128<1> only)
+    int slab_rows;      // rows of one slab (the GEMV's M: >= S when the step carries other streams' rows too, mmd_round_multi)
     int block_rows;     // attn_gqa128_w1_kernel: query rows per block (multiple of 16)
 };
 
@@ -414,7 +415,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void attn_gqa128_ke
         // that tile.  Stores are write-through; vmcnt(0) + barrier (the loop's own, per tile) orders them before this block's DMA reads; nobody else reads them in this launch.
         if (bx == 0) {
             const int row_w = (p.nh + 2 * p.nkv) * D;
-            const long long MN = (long long)p.S * row_w;
+            const long long MN = (long long)p.slab_rows * row_w;
             bool in_first_tile = false;
             for (int tok = 0; tok < p.S; ++tok) {
                 const long long pos = n_ctx + tok;
@@ -511,7 +512,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void attn_gqa128_ke
             // q row from the projection's K-slabs: rnd(sum + bias), rotate-half RoPE with the unfused kernels' rounding points (ops.hip
             // slab_rope_append_kernel).  A lane's chunks c and c + 2 hold the partner elements i and i + 64.
             const int row_w = (p.nh + 2 * p.nkv) * D;
-            const long long MN = (long long)p.S * row_w;
+            const long long MN = (long long)p.slab_rows * row_w;
             const float* sp = p.slabs + (long long)my_tok[rt] * row_w + my_head[rt] * D + lq * 8;
             const bf16_t* bp = (const bf16_t*)p.qkv_bias + my_head[rt] * D + lq * 8;
             const float2* tp = p.rope_tab + my_tok[rt] * (D / 2) + lq * 8;
@@ -1548,7 +1549,7 @@ static hipError_t launch_attention_(int dtype, const AttnArgs& a, hipStream_t st
     p.n_ctx = a.n_ctx; p.S = a.S; p.nh = a.nh; p.nkv = a.nkv; p.d = a.d; p.causal = a.causal;
     p.splits = 1; p.kv_per_split = 0; p.v_tr = a.v_transposed; p.dyn = a.dyn; p.layer = a.layer;
     p.scale_log2 = (1.0f / sqrtf((float)a.d)) * 1.4426950408889634f;
-    p.slabs = a.qkv_slabs; p.n_slabs = a.n_slabs; p.qkv_bias = a.qkv_bias; p.rope_tab = (const float2*)a.rope_tab;
+    p.slabs = a.qkv_slabs; p.n_slabs = a.n_slabs; p.qkv_bias = a.qkv_bias; p.rope_tab = (const float2*)a.rope_tab; p.slab_rows = a.slab_rows > 0 ? a.slab_rows : a.S;
     const bool f16 = dtype == MMD_F16;          // the fp16 vision tower: the row-major kernel only
     bool can_mfma = (dtype == MMD_BF16 || f16) && (a.d % 8) == 0 && a.d <= 128 && (a.ldq % 8) == 0 && (a.k_ts % 8) == 0 && (a.v_ts % 8) == 0 &&
                     (a.k_hs % 8) == 0 && (a.v_hs % 8) == 0 && (a.kv_bstride % 8) == 0 && (a.q_bstride % 8) == 0;

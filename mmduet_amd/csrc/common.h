@@ -164,7 +164,8 @@ hipError_t launch_resid32_layernorm(const void* y16, float* h32, const void* pos
 hipError_t launch_slab_resid_rmsnorm(const float* slabs, int splits, int M, int H, const void* resid_in, void* h_out, const void* norm_w, float eps,
                                      void* xn_out, hipStream_t st, const float* wscale = nullptr);
 hipError_t launch_slab_rope_append(const float* slabs, int splits, const void* bias, int S, int nh, int nkv, int d, const float* inv_freq_dev,
-                                   int64_t pos0, void* q_out, void* Kc, void* Vc, int64_t cap, hipStream_t st, const StepState* dyn = nullptr, int layer = 0);
+                                   int64_t pos0, void* q_out, void* Kc, void* Vc, int64_t cap, hipStream_t st, const StepState* dyn = nullptr, int layer = 0,
+                                   int slab_rows = 0);          // slab_rows: rows of one slab when the projection ran over more rows than this stream's S (0 = S); `slabs` points at the stream's first row
 hipError_t launch_rope_table(void* tab, int S, int half, const float* inv_freq_dev, int64_t pos0, hipStream_t st, const StepState* dyn = nullptr);   // float2 [S][half], bf16-rounded
 hipError_t launch_advance_state(StepState* st_dev, const int64_t* tok_dev, int64_t* prev_dev, int prev_cap, int64_t eos, int use_penalty, hipStream_t st);
 hipError_t launch_add_rows(int dtype, void* x, const void* add, int M, int H, int period, hipStream_t st);   // x[m,:] += add[m % period,:]
@@ -182,6 +183,13 @@ hipError_t launch_heads(int dtype, const void* hidden, int64_t ldh, const int32_
                         hipStream_t st);
 hipError_t launch_argmax_penalty(const float* logits, int V, const int64_t* prev_ids_dev, int n_prev, float penalty, int64_t* out_id,
                                  hipStream_t st, const StepState* dyn, void* scratch512);
+// greedy sampling / token feed of several streams at once (mmd_round_multi): per-stream pointers ride in the kernel argument
+constexpr int MMD_ROUND_MAX_SAMPLERS = 32;
+struct SampleBatch { const int64_t* prev[MMD_ROUND_MAX_SAMPLERS]; int64_t* tok[MMD_ROUND_MAX_SAMPLERS]; int64_t* append[MMD_ROUND_MAX_SAMPLERS]; int n_prev[MMD_ROUND_MAX_SAMPLERS]; float penalty[MMD_ROUND_MAX_SAMPLERS]; };
+struct FeedBatch { const int64_t* tok[MMD_ROUND_MAX_SAMPLERS]; int32_t row[MMD_ROUND_MAX_SAMPLERS]; };
+hipError_t launch_sample_batch(const float* logits /*[n, V]*/, int V, const SampleBatch& b, int n, int64_t* toks_out_dev, void* scratch, hipStream_t st);
+size_t sample_batch_scratch_bytes();
+hipError_t launch_embed_feed(int dtype, const void* table, const FeedBatch& f, int n, int H, int64_t vocab, void* out, hipStream_t st);
 hipError_t launch_convert(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, hipStream_t st);
 hipError_t launch_copy_rows(int dtype, const void* src, int64_t lds_, void* dst, int64_t ldd, int rows, int cols, hipStream_t st);
 hipError_t launch_interleave16(int dtype, const void* a, const void* b, void* out, int rows, int cols, hipStream_t st);
@@ -213,6 +221,7 @@ struct AttnArgs {
     // decode steps (rows <= 64, attn_gqa128<1> only): q / k / v are still the qkv projection's fp32 K-slabs.  The attention kernel itself reduces
     // them (+ bias), applies RoPE from the step's (cos, sin) table, builds its q fragments in registers and -- the block whose key range holds a new
     // position -- appends that token's K row / V column to the arena before staging the tile: no slab_rope_append launch, no q buffer.
-    const float* qkv_slabs = nullptr; int n_slabs = 0; const void* qkv_bias = nullptr; const void* rope_tab = nullptr;   // slabs [n][S][(nh+2nkv)*d]; tab float2 [S][d/2]
+    const float* qkv_slabs = nullptr; int n_slabs = 0; const void* qkv_bias = nullptr; const void* rope_tab = nullptr;   // slabs [n][slab_rows][(nh+2nkv)*d] (this step's first row); tab float2 [S][d/2]
+    int slab_rows = 0;               // rows of one slab = the projection's M (0: S); larger than S when one GEMV served several streams' rows (mmd_round_multi)
 };
 hipError_t launch_attention(int dtype, const AttnArgs& a, hipStream_t st);

@@ -102,6 +102,8 @@ struct mmd_ctx {
     void* rope_tab = 0;                // (cos, sin) of a decode step's positions (launch_rope_table), read by the attention kernel's fused q/k/v preparation
     bool no_rope_fuse = false;         // MMDUET_NO_ROPE_FUSE=1: decode steps keep the slab_rope_append launch (A/B)
     float* chain_ssq = 0;              // GemvChain scratch: per-row, per-n-tile sums of squares
+    // mmd_round_multi (allocated at its first use): logits of the sampling rows, their gathered hidden rows, the two-stage argmax candidates, the drawn tokens
+    float* round_logits = 0; void* round_hidden = 0; void* round_scratch = 0; int64_t* round_toks_dev = 0; int64_t* round_toks_host = 0;
     Prof prof;
 };
 
@@ -1231,16 +1233,16 @@ static int llm_step_segs(mmd_ctx* c, const StepSeg* segs, int nseg, const void* 
     if (dyn && nseg != 1) FAIL(c, MMD_EINVAL, "graph decode is single-stream");
     if (!dyn) for (int j = 0; j < nseg; ++j) { rc = kv_reserve(c, segs[j].s, segs[j].s->len + segs[j].rows); if (rc) return rc; }
     const int H = g.hidden_size, I = g.intermediate_size, nh = g.num_heads, nkv = g.num_kv_heads, d = g.head_dim;
-    mmd_stream* s = segs[0].s;                   // the single-stream (fused) schedule below works on segment 0
-    const int64_t n = s->len;
     if (embeds != c->l_h) HIPCHK(c, hipMemcpyAsync(c->l_h, embeds, (size_t)S * H * e, hipMemcpyDeviceToDevice, st));
-    const size_t layer_elems = kv_layer_elems(c, s->cap);
 
     // Fused schedule for the weight-streaming regime (S <= 256, packed bf16 weights): the skinny / streaming GEMMs leave fp32 split-K
     // slabs and the NEXT operator consumes them (reduce + bias + RoPE + KV append; reduce + residual + RMSNorm):
     // 9 launches per layer instead of 12, identical rounding points.
     bool fused = false;
-    if (nseg == 1 && dt == MMD_BF16 && S <= 256 && H <= 4096 && (H & 3) == 0 && !c->no_fuse) {          // (S > 64: gemm_stream_kernel's slabs -- gemm_can_slab says whether the shapes qualify)
+    // (several streams in one step -- mmd_round_multi's decode rounds: every talking stream's row, a few short segments -- take the same schedule: the GEMVs and the
+    //  slab consumers are row-wise, RoPE + KV append + attention read each stream's rows of the slabs at its row offset; MMDUET_NO_MULTI_FUSE=1 keeps the unfused form, A/B)
+    static const bool no_multi_fuse = getenv("MMDUET_NO_MULTI_FUSE") != nullptr;
+    if ((nseg == 1 || !no_multi_fuse) && dt == MMD_BF16 && S <= 256 && H <= 4096 && (H & 3) == 0 && !c->no_fuse) {          // (S > 64: gemm_stream_kernel's slabs -- gemm_can_slab says whether the shapes qualify)
         GemmArgs probe; memset(&probe, 0, sizeof(probe));
         probe.X = c->l_xn; probe.ldx = H; probe.Wp = c->L[0].wqkv_p; probe.M = S; probe.N = c->qkv_w; probe.K = H; probe.epi = EPI_NONE;
         probe.splitk_ws = c->splitk_ws; probe.splitk_ws_bytes = c->splitk_bytes;
@@ -1268,7 +1270,7 @@ static int llm_step_segs(mmd_ctx* c, const StepSeg* segs, int nseg, const void* 
 
     // rows <= 4, head_dim 128: the attention kernel prepares q / k / v from the qkv slabs itself (AttnArgs::qkv_slabs)
     const bool rope_fused = chain && d == 128 && !c->no_rope_fuse;
-    if (rope_fused) HIPCHK(c, launch_rope_table(c->rope_tab, S, 64, c->inv_freq, n, st, dyn));
+    if (rope_fused) for (int j = 0; j < nseg; ++j) HIPCHK(c, launch_rope_table((char*)c->rope_tab + (size_t)segs[j].row0 * 64 * 8, segs[j].rows, 64, c->inv_freq, segs[j].s->len, st, dyn));
     // chunks (bf16, head_dim 128): one (cos, sin) table per step and segment, read by the vectorised RoPE + append kernel of every layer; MMDUET_NO_CHUNK_ROPE=1 keeps the scalar kernel
     static const bool no_chunk_rope = getenv("MMDUET_NO_CHUNK_ROPE") != nullptr;
     const bool chunk_rope = !fused && dt == MMD_BF16 && d == 128 && S >= 64 && !no_chunk_rope && !c->no_fuse;
@@ -1292,15 +1294,18 @@ static int llm_step_segs(mmd_ctx* c, const StepSeg* segs, int nseg, const void* 
     bool xn_ready = false;             // the previous layer's fused slab consumer already left this layer's normalised input in l_xn
     for (int i = 0; i < g.num_layers; ++i) {
         LlmLayer& L = c->L[i];
-        void* Kl = (char*)s->K + (size_t)i * layer_elems * e;
-        void* Vl = (char*)s->V + (size_t)i * layer_elems * e;
         int splits = 1;
         if (fused) {
             ch_xn.xn_gamma = L.ln1;
             rc = slab_gemm(c->l_xn, H, L.wqkv_p, c->qkv_w, H, &splits, L.wqkv_8, L.sqkv, chain && i > 0 ? &ch_xn : nullptr); if (rc) return rc;
             if (!rope_fused) {
                 ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * S * c->qkv_w * e, 0);
-                HIPCHK(c, launch_slab_rope_append(c->splitk_ws, splits, L.bqkv, S, nh, nkv, d, c->inv_freq, n, c->l_q, Kl, Vl, s->cap, st, dyn, i));
+                for (int j = 0; j < nseg; ++j) {
+                    mmd_stream* sj = segs[j].s;
+                    const size_t le = kv_layer_elems(c, sj->cap);
+                    HIPCHK(c, launch_slab_rope_append(c->splitk_ws + (size_t)segs[j].row0 * c->qkv_w, splits, L.bqkv, segs[j].rows, nh, nkv, d, c->inv_freq, sj->len,
+                                                      (char*)c->l_q + (size_t)segs[j].row0 * nh * d * e, (char*)sj->K + (size_t)i * le * e, (char*)sj->V + (size_t)i * le * e, sj->cap, st, dyn, i, S));
+                }
             }
         } else {
             if (!xn_ready) { ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * S * H * e, 0); HIPCHK(c, launch_rmsnorm(dt, c->l_h, L.ln1, c->l_xn, S, H, g.rms_norm_eps, st)); }
@@ -1332,7 +1337,7 @@ static int llm_step_segs(mmd_ctx* c, const StepSeg* segs, int nseg, const void* 
             a.S = Sj; a.nh = nh; a.nkv = nkv; a.d = d; a.n_ctx = nj; a.causal = 1; a.v_transposed = 1;
             a.batch = 1; a.ws = c->attn_ws; a.ws_bytes = c->attn_bytes; a.variant = 0;
             a.dyn = dyn; a.layer = i; a.dyn_splits = 64;
-            if (rope_fused) { a.qkv_slabs = c->splitk_ws; a.n_slabs = splits; a.qkv_bias = L.bqkv; a.rope_tab = c->rope_tab; }
+            if (rope_fused) { a.qkv_slabs = c->splitk_ws + (size_t)segs[j].row0 * c->qkv_w; a.slab_rows = S; a.n_slabs = splits; a.qkv_bias = L.bqkv; a.rope_tab = (char*)c->rope_tab + (size_t)segs[j].row0 * 64 * 8; }
             double kvb = 2.0 * (double)(nj + Sj) * nkv * d * e;
             ProfScope ps(c, MMD_K_ATTN_LLM, kvb + 2.0 * Sj * nh * d * e, 4.0 * Sj * (double)(nj + Sj) * nh * d);
             HIPCHK(c, launch_attention(dt, a, st));
@@ -1453,6 +1458,138 @@ extern "C" int mmd_frame_step_multi(mmd_ctx* c, mmd_stream* const* streams, cons
         HIPCHK(c, hipMemcpyAsync(c->heads_host, c->heads_dev, sizeof(float) * 4 * n_head_rows, hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipStreamSynchronize(st));
         memcpy(heads_out_host, c->heads_host, sizeof(float) * 4 * n_head_rows);
+    }
+    return MMD_OK;
+}
+
+// ---- scheduler rounds of several streams with the greedy sampling on the device ---------------------------------------------------------------
+// models/modeling_live.py:51-77 is a per-stream token loop; with several streams per GPU (mmduet_amd/multistream.py) the loops of all talking streams advance together,
+// one token per round, inside the forwards that also carry the watching streams' frame chunks.
+struct mmd_sampler {
+    mmd_ctx* ctx;
+    int64_t* tok_dev = nullptr;                  // the token drawn last (fed back by the next round's embedding gather)
+    int64_t* prev_dev = nullptr; int prev_cap = 0; int n_prev = 0;          // repetition-penalty list (device) and the number of entries that count
+    int64_t eos = -1; float penalty = 0.f;
+};
+
+extern "C" int mmd_sampler_create(mmd_ctx* c, mmd_sampler** out) {
+    NEED_FINAL(c);
+    if (!out) FAIL(c, MMD_EINVAL, "null out pointer");
+    mmd_sampler* sp = new (std::nothrow) mmd_sampler();
+    if (!sp) FAIL(c, MMD_ENOMEM, "out of host memory");
+    sp->ctx = c;
+    if (hipMalloc((void**)&sp->tok_dev, 64) != hipSuccess) { delete sp; FAIL(c, MMD_ENOMEM, "hipMalloc of a sampler failed"); }
+    hipMemsetAsync(sp->tok_dev, 0, 64, c->stream);
+    *out = sp;
+    return MMD_OK;
+}
+extern "C" void mmd_sampler_destroy(mmd_sampler* sp) {
+    if (!sp) return;
+    hipSetDevice(sp->ctx->device);
+    hipStreamSynchronize(sp->ctx->stream);
+    if (sp->tok_dev) hipFree(sp->tok_dev);
+    if (sp->prev_dev) hipFree(sp->prev_dev);
+    delete sp;
+}
+extern "C" int mmd_sampler_begin(mmd_sampler* sp, int64_t eos_id, float rep_penalty, const int64_t* prev_ids_host, int n_prev, int max_new) {
+    if (!sp) return MMD_EINVAL;
+    mmd_ctx* c = sp->ctx; hipSetDevice(c->device);
+    if (n_prev < 0 || max_new < 0 || (n_prev > 0 && !prev_ids_host)) FAIL(c, MMD_EINVAL, "bad sampler arguments");
+    sp->eos = eos_id; sp->penalty = rep_penalty > 0.f ? rep_penalty : 0.f; sp->n_prev = 0;
+    if (sp->penalty <= 0.f) return MMD_OK;
+    const int need = n_prev + max_new + 1;          // (the slot behind the list receives every drawn token; it counts only when the token is not EOS)
+    if (need > sp->prev_cap) {
+        int ncap = sp->prev_cap > 0 ? sp->prev_cap : 1024;
+        while (ncap < need) ncap *= 2;
+        HIPCHK(c, hipStreamSynchronize(c->stream));          // (a round in flight may still read the old list)
+        if (sp->prev_dev) { hipFree(sp->prev_dev); sp->prev_dev = nullptr; sp->prev_cap = 0; }
+        if (hipMalloc((void**)&sp->prev_dev, (size_t)ncap * sizeof(int64_t)) != hipSuccess) FAIL(c, MMD_ENOMEM, "hipMalloc of a %d-entry penalty list failed", ncap);
+        sp->prev_cap = ncap;
+    }
+    // (pageable host memory: the copy is staged before the call returns, the caller's list may change afterwards)
+    if (n_prev > 0) HIPCHK(c, hipMemcpyAsync(sp->prev_dev, prev_ids_host, sizeof(int64_t) * n_prev, hipMemcpyHostToDevice, c->stream));
+    sp->n_prev = n_prev;
+    return MMD_OK;
+}
+extern "C" int mmd_sampler_prev_len(const mmd_sampler* sp) { return sp ? sp->n_prev : MMD_EINVAL; }
+
+extern "C" int mmd_round_multi(mmd_ctx* c, mmd_stream* const* streams, const int32_t* seg_rows, int n_segs, const void* const* seg_embeds, mmd_sampler* const* samplers,
+                               const int32_t* seg_flags, const int32_t* head_rows, int n_head_rows, float* heads_out_host, int64_t* tokens_out_host) {
+    if (!c) return MMD_EINVAL;
+    NEED_FINAL(c);
+    std::vector<StepSeg> segs; int S = 0;
+    int rc = build_segs(c, streams, seg_rows, n_segs, segs, &S); if (rc) return rc;
+    if (S > c->cfg.max_step_tokens) FAIL(c, MMD_ERANGE, "round of %d tokens exceeds max_step_tokens %d", S, c->cfg.max_step_tokens);
+    if (n_head_rows < 0 || n_head_rows > S || (n_head_rows && (!head_rows || !heads_out_host))) FAIL(c, MMD_EINVAL, "bad head rows");
+    for (int i = 0; i < n_head_rows; ++i) if (head_rows[i] < 0 || head_rows[i] >= S) FAIL(c, MMD_ERANGE, "head row %d outside the round", head_rows[i]);
+    hipStream_t st = c->stream; const int H = c->cfg.hidden_size, V = c->cfg.vocab_size; const size_t e = es(c);
+    // the round's input rows: embeddings handed in per segment, or -- FEED -- the embedding of the token the segment's sampler drew in the round before
+    FeedBatch feed; int n_feed = 0;
+    SampleBatch sb; int n_sample = 0; int32_t sample_row[MMD_ROUND_MAX_SAMPLERS]; int sample_seg[MMD_ROUND_MAX_SAMPLERS];
+    for (int j = 0; j < n_segs; ++j) {
+        const int fl = seg_flags ? seg_flags[j] : 0;
+        mmd_sampler* sp = samplers ? samplers[j] : nullptr;
+        if ((fl & (MMD_SEG_FEED | MMD_SEG_SAMPLE)) && (!sp || sp->ctx != c)) FAIL(c, MMD_EINVAL, "segment %d feeds / samples without a sampler of this context", j);
+        if (fl & MMD_SEG_FEED) {
+            if (segs[j].rows != 1) FAIL(c, MMD_EINVAL, "a feed segment is one row (segment %d has %d)", j, segs[j].rows);
+            if (n_feed >= MMD_ROUND_MAX_SAMPLERS) FAIL(c, MMD_ERANGE, "more than %d feed segments", MMD_ROUND_MAX_SAMPLERS);
+            feed.tok[n_feed] = sp->tok_dev; feed.row[n_feed] = segs[j].row0; ++n_feed;
+        } else {
+            if (!seg_embeds || !seg_embeds[j]) FAIL(c, MMD_EINVAL, "segment %d has no input rows", j);
+            void* dst = (char*)c->l_h + (size_t)segs[j].row0 * H * e;
+            if (seg_embeds[j] != dst) HIPCHK(c, hipMemcpyAsync(dst, seg_embeds[j], (size_t)segs[j].rows * H * e, hipMemcpyDeviceToDevice, st));
+        }
+        if (fl & MMD_SEG_SAMPLE) {
+            if (n_sample >= MMD_ROUND_MAX_SAMPLERS) FAIL(c, MMD_ERANGE, "more than %d sampling segments", MMD_ROUND_MAX_SAMPLERS);
+            for (int k = 0; k < n_sample; ++k) if (samplers[sample_seg[k]] == sp) FAIL(c, MMD_EINVAL, "a sampler may appear once per round");
+            const bool pen = sp->penalty > 0.f;
+            sb.prev[n_sample] = sp->prev_dev; sb.n_prev[n_sample] = pen ? sp->n_prev : 0; sb.penalty[n_sample] = pen ? sp->penalty : 1.f;
+            sb.tok[n_sample] = sp->tok_dev; sb.append[n_sample] = (pen && sp->n_prev < sp->prev_cap) ? sp->prev_dev + sp->n_prev : nullptr;
+            sample_row[n_sample] = segs[j].row0 + segs[j].rows - 1; sample_seg[n_sample] = j; ++n_sample;
+        }
+    }
+    if (n_sample && !tokens_out_host) FAIL(c, MMD_EINVAL, "sampling segments need tokens_out_host");
+    if (n_feed) { ProfScope ps(c, MMD_K_OTHER, 0, 0); HIPCHK(c, launch_embed_feed(c->cfg.dtype, c->embed, feed, n_feed, H, V, c->l_h, st)); }
+    if (n_sample && !c->round_logits) {
+        rc = dev_alloc(c, (void**)&c->round_logits, (size_t)MMD_ROUND_MAX_SAMPLERS * V * sizeof(float), false); if (rc) return rc;
+        rc = dev_alloc(c, &c->round_hidden, (size_t)MMD_ROUND_MAX_SAMPLERS * H * e); if (rc) return rc;
+        rc = dev_alloc(c, &c->round_scratch, sample_batch_scratch_bytes()); if (rc) return rc;
+        rc = dev_alloc(c, (void**)&c->round_toks_dev, MMD_ROUND_MAX_SAMPLERS * sizeof(int64_t)); if (rc) return rc;
+        HIPCHK(c, hipHostMalloc((void**)&c->round_toks_host, MMD_ROUND_MAX_SAMPLERS * sizeof(int64_t)));
+    }
+    // rows whose final hidden state is read: the heads' rows first, then the sampling rows (llm_step_segs may leave l_hid compact, in this order)
+    int32_t need[64]; int n_need = 0;
+    if (n_head_rows + n_sample <= 64) { for (int i = 0; i < n_head_rows; ++i) need[n_need++] = head_rows[i]; for (int i = 0; i < n_sample; ++i) need[n_need++] = sample_row[i]; }
+    rc = llm_step_segs(c, segs.data(), n_segs, c->l_h, S, nullptr, nullptr, n_need ? need : nullptr, n_need); if (rc) return rc;
+    const bool compact = c->hid_compact > 0;
+    if (n_sample) {
+        const void* rows = nullptr;
+        if (compact) rows = (const char*)c->l_hid + (size_t)n_head_rows * H * e;          // already gathered, in the order of the need list
+        else if (n_sample == 1) rows = (const char*)c->l_hid + (size_t)sample_row[0] * H * e;
+        else {
+            ProfScope ps(c, MMD_K_OTHER, 0, 0);
+            HIPCHK(c, launch_gather_rows2(c->l_hid, (int64_t)H * (int64_t)(e / 2), c->round_hidden, H * (int)(e / 2), c->l_hid, (int64_t)H * (int64_t)(e / 2), c->l_xn, H * (int)(e / 2), sample_row, n_sample, st));
+            rows = c->round_hidden;
+        }
+        rc = gemm(c, rows, H, c->lm_head, H, nullptr, nullptr, 0, c->round_logits, V, n_sample, V, H, EPI_NONE, 1, GEMM_AUTO, c->lm_head_p); if (rc) return rc;
+        { ProfScope ps(c, MMD_K_OTHER, 0, 0); HIPCHK(c, launch_sample_batch(c->round_logits, V, sb, n_sample, c->round_toks_dev, c->round_scratch, st)); }
+        HIPCHK(c, hipMemcpyAsync(c->round_toks_host, c->round_toks_dev, sizeof(int64_t) * n_sample, hipMemcpyDeviceToHost, st));
+    }
+    if (n_head_rows) {
+        for (int i = 0; i < n_head_rows; ++i) c->rows_host[i] = compact ? i : head_rows[i];
+        HIPCHK(c, hipMemcpyAsync(c->rows_dev, c->rows_host, sizeof(int32_t) * n_head_rows, hipMemcpyHostToDevice, st));
+        { ProfScope ps(c, MMD_K_OTHER, 0, 0);
+          HIPCHK(c, launch_heads(c->cfg.dtype, c->l_hid, H, c->rows_dev, n_head_rows, c->heads4, H, c->heads_dev, st)); }
+        HIPCHK(c, hipMemcpyAsync(c->heads_host, c->heads_dev, sizeof(float) * 4 * n_head_rows, hipMemcpyDeviceToHost, st));
+    }
+    if (n_head_rows || n_sample) HIPCHK(c, hipStreamSynchronize(st));          // the round's ONE synchronisation: head logits and drawn tokens cross together
+    if (n_head_rows) memcpy(heads_out_host, c->heads_host, sizeof(float) * 4 * n_head_rows);
+    if (tokens_out_host) for (int j = 0; j < n_segs; ++j) tokens_out_host[j] = -1;
+    for (int i = 0; i < n_sample; ++i) {
+        const int64_t tok = c->round_toks_host[i];
+        mmd_sampler* sp = samplers[sample_seg[i]];
+        tokens_out_host[sample_seg[i]] = tok;
+        if (sp->penalty > 0.f && tok != sp->eos && sp->n_prev < sp->prev_cap) sp->n_prev += 1;          // (EOS is neither fed back nor penalised: models/modeling_live.py:66-72)
     }
     return MMD_OK;
 }

@@ -298,7 +298,7 @@ hipError_t launch_slab_resid_rmsnorm(const float* slabs, int splits, int M, int 
 
 __global__ void slab_rope_append_kernel(const float* __restrict__ slabs, int splits, const bf16_t* __restrict__ bias, int S, int nh, int nkv, int d,
                                         const float* __restrict__ inv_freq_tab, long long pos0, bf16_t* __restrict__ q_out, bf16_t* __restrict__ Kc,
-                                        bf16_t* __restrict__ Vc, long long cap, const StepState* __restrict__ dyn, int layer) {
+                                        bf16_t* __restrict__ Vc, long long cap, const StepState* __restrict__ dyn, int layer, int slab_rows) {
     if (dyn) {                                     // graph replay: position / arena come from device state
         pos0 = dyn->n_ctx; cap = dyn->cap;
         const long long le = (long long)nkv * cap * d;
@@ -306,7 +306,7 @@ __global__ void slab_rope_append_kernel(const float* __restrict__ slabs, int spl
     }
     const int s = blockIdx.x, head = blockIdx.y, half = d >> 1;
     const int row_w = (nh + 2 * nkv) * d;
-    const long long MN = (long long)S * row_w;
+    const long long MN = (long long)slab_rows * row_w;
     const long long base = (long long)s * row_w + (long long)head * d;
     const long long pos = pos0 + s;
     auto val = [&](int i) {                            // rnd(sum of slabs + bias): the bf16 output of the q/k/v projection
@@ -351,10 +351,10 @@ hipError_t launch_rope_table(void* tab, int S, int half, const float* inv_freq_d
     return hipGetLastError();
 }
 hipError_t launch_slab_rope_append(const float* slabs, int splits, const void* bias, int S, int nh, int nkv, int d, const float* inv_freq_dev,
-                                   int64_t pos0, void* q_out, void* Kc, void* Vc, int64_t cap, hipStream_t st, const StepState* dyn, int layer) {
+                                   int64_t pos0, void* q_out, void* Kc, void* Vc, int64_t cap, hipStream_t st, const StepState* dyn, int layer, int slab_rows) {
     if (S <= 0) return hipSuccess;
     hipLaunchKernelGGL(slab_rope_append_kernel, dim3(S, nh + 2 * nkv), dim3(64), 0, st, slabs, splits, (const bf16_t*)bias, S, nh, nkv, d, inv_freq_dev,
-                       (long long)pos0, (bf16_t*)q_out, (bf16_t*)Kc, (bf16_t*)Vc, (long long)cap, dyn, layer);
+                       (long long)pos0, (bf16_t*)q_out, (bf16_t*)Kc, (bf16_t*)Vc, (long long)cap, dyn, layer, slab_rows > 0 ? slab_rows : S);
     return hipGetLastError();
 }
 
@@ -755,6 +755,81 @@ hipError_t launch_argmax_penalty(const float* logits, int V, const int64_t* prev
     float* cand_v = (float*)scratch; int* cand_i = (int*)((char*)scratch + ARGMAX_BLOCKS * sizeof(float));      // >= 512 bytes of context scratch
     hipLaunchKernelGGL(argmax_penalty_kernel, dim3(ARGMAX_BLOCKS), dim3(256), 0, st, logits, V, prev_ids_dev, n_prev, penalty, cand_v, cand_i, dyn);
     hipLaunchKernelGGL(argmax_final_kernel, dim3(1), dim3(64), 0, st, cand_v, cand_i, ARGMAX_BLOCKS, out_id);
+    return hipGetLastError();
+}
+
+// The same for several streams in ONE pass (mmd_round_multi): row r of logits [n, V] against sampler r's own penalty list.  The winner goes to the sampler's token slot
+// (the next round's embedding gather reads it there), to toks_out[r] (one host copy for all streams) and -- penalty on -- behind the sampler's list: the host counts that
+// entry only when the token was not EOS (models/modeling_live.py:66-72), a stale entry beyond the count is never read.
+__global__ __launch_bounds__(256) void argmax_penalty_multi_kernel(const float* __restrict__ logits, int V, SampleBatch b, float* __restrict__ cand_v, int* __restrict__ cand_i) {
+    __shared__ float sv[4]; __shared__ int si[4];
+    const int r = blockIdx.y;
+    const float* lg = logits + (long long)r * V;
+    const int64_t* prev = b.prev[r]; const int n_prev = b.n_prev[r]; const float penalty = b.penalty[r];
+    const int per = (V + gridDim.x - 1) / gridDim.x;
+    const int beg = blockIdx.x * per, end = min(V, beg + per);
+    float best = -INFINITY; int bi = 0x7fffffff;
+    for (int i = beg + threadIdx.x; i < end; i += blockDim.x) {
+        float v = lg[i];
+        if (n_prev > 0) {
+            bool seen = false;
+            for (int j = 0; j < n_prev; ++j) if (prev[j] == i) { seen = true; break; }
+            if (seen) v = v < 0.f ? v * penalty : v / penalty;
+        }
+        if (better(v, i, best, bi)) { best = v; bi = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float ov = __shfl_xor(best, o, 64); int oi = __shfl_xor(bi, o, 64);
+        if (better(ov, oi, best, bi)) { best = ov; bi = oi; }
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sv[w] = best; si[w] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; ++k) if (better(sv[k], si[k], best, bi)) { best = sv[k]; bi = si[k]; }
+        cand_v[r * ARGMAX_BLOCKS + blockIdx.x] = best; cand_i[r * ARGMAX_BLOCKS + blockIdx.x] = bi;
+    }
+}
+__global__ void argmax_final_multi_kernel(const float* __restrict__ cand_v, const int* __restrict__ cand_i, SampleBatch b, int64_t* __restrict__ toks_out) {
+    const int r = blockIdx.x, lane = threadIdx.x;
+    float best = -INFINITY; int bi = 0x7fffffff;
+    if (lane < ARGMAX_BLOCKS) { best = cand_v[r * ARGMAX_BLOCKS + lane]; bi = cand_i[r * ARGMAX_BLOCKS + lane]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float ov = __shfl_xor(best, o, 64); int oi = __shfl_xor(bi, o, 64);
+        if (better(ov, oi, best, bi)) { best = ov; bi = oi; }
+    }
+    if (lane == 0) {
+        *b.tok[r] = bi; toks_out[r] = bi;
+        if (b.append[r]) *b.append[r] = bi;
+    }
+}
+hipError_t launch_sample_batch(const float* logits, int V, const SampleBatch& b, int n, int64_t* toks_out_dev, void* scratch, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    if (n > MMD_ROUND_MAX_SAMPLERS) return hipErrorInvalidValue;
+    float* cand_v = (float*)scratch; int* cand_i = (int*)((char*)scratch + (size_t)MMD_ROUND_MAX_SAMPLERS * ARGMAX_BLOCKS * sizeof(float));
+    hipLaunchKernelGGL(argmax_penalty_multi_kernel, dim3(ARGMAX_BLOCKS, n), dim3(256), 0, st, logits, V, b, cand_v, cand_i);
+    hipLaunchKernelGGL(argmax_final_multi_kernel, dim3(n), dim3(64), 0, st, cand_v, cand_i, b, toks_out_dev);
+    return hipGetLastError();
+}
+size_t sample_batch_scratch_bytes() { return (size_t)MMD_ROUND_MAX_SAMPLERS * ARGMAX_BLOCKS * (sizeof(float) + sizeof(int)); }
+
+// rows of a step that are the embedding of the token a sampler drew last (the feed rows of mmd_round_multi): out[row[r], :] = table[*tok[r], :]
+template <typename T>
+__global__ void embed_feed_kernel(const T* __restrict__ table, FeedBatch f, int H, long long vocab, T* __restrict__ out) {
+    long long id = *f.tok[blockIdx.x];
+    if (id < 0) id = 0;
+    if (id >= vocab) id = vocab - 1;
+    const T* src = table + id * H;
+    T* dst = out + (long long)f.row[blockIdx.x] * H;
+    for (int c = threadIdx.x; c < H; c += blockDim.x) dst[c] = src[c];
+}
+hipError_t launch_embed_feed(int dtype, const void* table, const FeedBatch& f, int n, int H, int64_t vocab, void* out, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    if (n > MMD_ROUND_MAX_SAMPLERS) return hipErrorInvalidValue;
+    if (dtype == MMD_F32) hipLaunchKernelGGL(embed_feed_kernel<float>, dim3(n), dim3(256), 0, st, (const float*)table, f, H, (long long)vocab, (float*)out);
+    else hipLaunchKernelGGL(embed_feed_kernel<bf16_t>, dim3(n), dim3(256), 0, st, (const bf16_t*)table, f, H, (long long)vocab, (bf16_t*)out);
     return hipGetLastError();
 }
 

@@ -101,6 +101,34 @@ class KVCacheHandle:
         return self.length
 
 
+class SamplerHandle:
+    """mmd_sampler: greedy sampling state of one stream on the device (models/modeling_live.py:51-77 run by mmd_round_multi)."""
+
+    def __init__(self, model):
+        self.model = model
+        h = C.c_void_p()
+        with model._lock:
+            check(lib().mmd_sampler_create(model._ctx, C.byref(h)), model._ctx, 'mmd_sampler_create')
+        self.h = h.value
+
+    def begin(self, eos_token_id, repetition_penalty, generated_token_ids, max_new_tokens):
+        """Start of a response: the penalty list is every id generated so far in this video (it persists across turns, models/modeling_live.py:60-66)."""
+        pen = float(repetition_penalty) if repetition_penalty is not None else 0.0
+        prev = list(generated_token_ids) if (generated_token_ids is not None and pen > 0) else []
+        arr = (C.c_int64 * max(1, len(prev)))(*prev)
+        with self.model._lock:
+            self.model._bind_stream()
+            check(lib().mmd_sampler_begin(self.h, int(eos_token_id if eos_token_id is not None else -1), pen, arr, len(prev), int(max_new_tokens)), self.model._ctx, 'mmd_sampler_begin')
+
+    def __del__(self):
+        try:
+            if getattr(self, 'h', None) and getattr(self.model, '_ctx', None):
+                lib().mmd_sampler_destroy(self.h)
+        except Exception:
+            pass
+        self.h = None
+
+
 class VideoHeadCausalLMOutputWithPast:
     """Output of the model call.  `.logits` (lm_head) is computed lazily and, unless
     `config.all_position_logits` is set, only for the LAST position ([1,1,V]): the streaming loop reads nothing else
@@ -627,6 +655,68 @@ class VideoHeadLiveLlavaQwenForCausalLM:
                 lg = logits[o:o + 1] if logits is not None else self.lm_head(hid)
             out.append(dict(heads=heads_all[hp:hp + nh] if nh else None, hidden=hid, logits=lg, cache=caches[i]))
             hp += nh
+        return out
+
+    def new_sampler(self):
+        """Device-resident greedy sampling state of one stream (mmd_sampler): the token drawn last + the repetition-penalty list."""
+        return SamplerHandle(self)
+
+    def round_multi(self, segments):
+        """ONE scheduler round over several video streams with the sampling on the device (mmd_round_multi): `multi_step` for the rows, plus -- for the streams that are
+        talking -- lm_head, repetition penalty, arg-max and the next round's embedding gather without a host round trip.  One synchronisation per round.
+
+        segments: list of dicts with
+            x          [S_i, H] / [1, S_i, H] input rows, or None with feed=True
+            cache      the stream's KV handle (or None)
+            head_rows  row indices (relative to the segment) whose 4 video-head logits are wanted
+            sampler    a SamplerHandle (needed for feed / sample)
+            feed       the segment is the ONE row of the token `sampler` drew in an earlier round
+            sample     draw the next token from the segment's last row
+        Returns per segment dict(heads=[n,4] fp32 CPU tensor | None, token=int | None, cache=new handle)."""
+        H = self.config.hidden_size
+        n_seg = len(segments)
+        seg_rows, head_rows, ptrs, flags, samplers, keep = [], [], [], [], [], []
+        at = 0
+        for sg in segments:
+            feed, smp = bool(sg.get('feed')), sg.get('sampler')
+            if feed:
+                S = 1; ptrs.append(None)
+            else:
+                x = sg['x'].reshape(-1, H)
+                if x.dtype != self.dtype or x.device != self.device or not x.is_contiguous():
+                    x = x.to(device=self.device, dtype=self.dtype).contiguous()
+                S = x.shape[0]
+                if S == 0:
+                    raise ValueError('empty segment')
+                keep.append(x); ptrs.append(x.data_ptr())
+            seg_rows.append(S)
+            head_rows += [at + int(r) for r in sg.get('head_rows', ())]
+            flags.append((1 if feed else 0) | (2 if sg.get('sample') else 0))
+            samplers.append(smp.h if smp is not None else None)
+            at += S
+        if at > self.max_step_tokens:
+            raise ValueError(f'round of {at} tokens exceeds max_step_tokens={self.max_step_tokens}')
+        nh = len(head_rows)
+        res = (C.c_float * (4 * max(1, nh)))()
+        toks = (C.c_int64 * n_seg)()
+        arenas = []
+        with self._lock:
+            for sg in segments:
+                arena, n = self._resolve_cache(sg.get('cache'))
+                if any(a is arena for a, _ in arenas):
+                    raise ValueError('a KV arena may appear once per round')
+                arenas.append((arena, n))
+            self._bind_stream()
+            check(lib().mmd_round_multi(self._ctx, (C.c_void_p * n_seg)(*[a.h for a, _ in arenas]), (C.c_int32 * n_seg)(*seg_rows), n_seg, (C.c_void_p * n_seg)(*ptrs),
+                                        (C.c_void_p * n_seg)(*samplers), (C.c_int32 * n_seg)(*flags), (C.c_int32 * max(1, nh))(*head_rows), nh, res, toks),
+                  self._ctx, 'mmd_round_multi')
+            caches = [KVCacheHandle(a, n + S) for (a, n), S in zip(arenas, seg_rows)]
+        heads_all = torch.tensor(res[:4 * nh], dtype=torch.float32).view(-1, 4) if nh else None
+        out, hp = [], 0
+        for i, sg in enumerate(segments):
+            k = len(sg.get('head_rows', ()))
+            out.append(dict(heads=heads_all[hp:hp + k] if k else None, token=int(toks[i]) if flags[i] & 2 else None, cache=caches[i]))
+            hp += k
         return out
 
     def greedy_generate(self, inputs_embeds, past_key_values, eos_token_id, max_new_tokens, repetition_penalty=None,

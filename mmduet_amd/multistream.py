@@ -23,13 +23,15 @@ from .modeling_live import VideoHeadCausalLMOutputWithPast
 
 
 class _Request:
-    __slots__ = ('kind', 'x', 'cache', 'head_rows', 'result')
+    __slots__ = ('kind', 'x', 'cache', 'head_rows', 'result', 'gen')
 
-    def __init__(self, kind, x, cache, head_rows=()):
-        self.kind, self.x, self.cache, self.head_rows, self.result = kind, x, cache, list(head_rows), None
+    def __init__(self, kind, x, cache, head_rows=(), gen=None):
+        self.kind, self.x, self.cache, self.head_rows, self.result, self.gen = kind, x, cache, list(head_rows), None, gen
 
     @property
     def rows(self):
+        if self.kind == 'generate' and self.gen['ids']:          # a response in progress: the row of the token drawn last
+            return 1
         return self.x.reshape(-1, self.x.shape[-1]).shape[0]
 
 
@@ -60,6 +62,14 @@ class _ModelProxy:
     def greedy_generate(self, inputs_embeds, past_key_values, eos_token_id, max_new_tokens, repetition_penalty=None, generated_token_ids=None):
         """models/modeling_live.py:51-77 with one scheduler round per token (same rule as mmd_greedy_generate: the EOS token is
         written but neither fed back nor penalised; HF repetition penalty over every token generated so far in this video)."""
+        if hasattr(self._real, 'round_multi') and not self._slot.sched.python_decode:
+            # the whole response is ONE request: the scheduler advances it a token per round (mmd_round_multi samples on the device) and wakes this slot when it is complete
+            gen = dict(slot=self._slot, eos=eos_token_id, max_new=int(max_new_tokens), ids=[], penalty=repetition_penalty,
+                       prev=list(generated_token_ids) if (generated_token_ids is not None and repetition_penalty is not None) else None)
+            r = self._slot.post(_Request('generate', inputs_embeds, past_key_values, gen=gen))
+            if generated_token_ids is not None and repetition_penalty is not None:
+                generated_token_ids.extend(t for t in r['ids'] if t != eos_token_id)
+            return r['ids'], r['cache']
         pen = float(repetition_penalty) if repetition_penalty is not None else 0.0
         seen = generated_token_ids if (generated_token_ids is not None and pen > 0) else None
         x, cache, ids = inputs_embeds, past_key_values, []
@@ -89,6 +99,7 @@ class _Slot(threading.Thread):
         self.go = threading.Semaphore(0)
         self.request, self.finished, self.error = None, False, None
         self.driver = None
+        self.sampler = None                  # mmd_sampler of this slot (created at its first response)
 
     # -- called on the slot's thread ---------------------------------------------------------------------------------
     def post(self, request):
@@ -161,8 +172,10 @@ class MultiStreamInfer:
         self.per_slot_rows = max(256, model.max_step_tokens // n_slots)
         self.keep_drivers = False             # True: a finished video's driver (and its KV handle) stays reachable as slot.driver (tests that read the arena afterwards)
         self.rounds = self.merged_rows = 0
-        self.round_log = None                 # set to a list to record (segments, rows, seconds) per merged forward
+        self.round_log = None                 # set to a list to record (kinds, rows, t_start, t_end) per merged forward (kinds: one letter per segment, f / a / d)
         self.exec_seconds = 0.0               # time inside the merged forwards (launch + the one sync), the rest is driver host work
+        self.python_decode = False            # True: responses decode through per-token Python (logits tensor, host arg-max, embedding call per slot and token) -- the
+                                              # round-5 form, kept as the cross-check of the native rounds and for duck-typed models without `round_multi`
         self._vit_stream = None
 
     def _make_driver(self, slot, args):
@@ -187,7 +200,16 @@ class MultiStreamInfer:
         if group:
             groups.append(group)
         t0 = time.perf_counter()
+        native = hasattr(self.model, 'round_multi') and not self.python_decode
         for group in groups:
+            tg = time.perf_counter()
+            if native:
+                self._round_native(group)
+                self.rounds += 1
+                self.merged_rows += sum(r.rows for r in group)
+                if self.round_log is not None:
+                    self.round_log.append((''.join(r.kind[0] for r in group), [r.rows for r in group], tg, time.perf_counter()))
+                continue
             segs = [dict(x=r.x, cache=r.cache, head_rows=r.head_rows, hidden={'frames': 'none', 'forward': 'all', 'decode': 'last'}[r.kind]) for r in group]
             try:
                 out = self.model.multi_step(segs)
@@ -199,8 +221,66 @@ class MultiStreamInfer:
             self.rounds += 1
             self.merged_rows += sum(r.rows for r in group)
             if self.round_log is not None:
-                self.round_log.append((len(group), sum(r.rows for r in group), time.perf_counter() - t0))
+                self.round_log.append((''.join(r.kind[0] for r in group), [r.rows for r in group], tg, time.perf_counter()))
         self.exec_seconds += time.perf_counter() - t0
+
+    def _round_native(self, group):
+        """One merged forward through mmd_round_multi.  A 'generate' request stays posted for the whole response: its first round carries the prompt rows, every later
+        round the ONE row of the token drawn in the round before (gathered on the device); the request completes -- `result` set, `gen['done']` -- at EOS or the cap."""
+        segs = []
+        for r in group:
+            if r.kind == 'generate':
+                g = r.gen
+                if 'sampler' not in g:           # first round of this response
+                    slot = g['slot']
+                    if slot.sampler is None:
+                        slot.sampler = self.model.new_sampler()
+                    g['sampler'] = slot.sampler
+                    g['sampler'].begin(g['eos'], g['penalty'], g['prev'], g['max_new'])
+                    segs.append(dict(x=r.x, cache=r.cache, sampler=g['sampler'], sample=True))
+                else:
+                    segs.append(dict(x=None, cache=g['cache'], sampler=g['sampler'], feed=True, sample=True))
+            else:
+                segs.append(dict(x=r.x, cache=r.cache, head_rows=r.head_rows))
+        try:
+            if any(r.kind == 'forward' for r in group):          # a query turn wants every hidden row back (lazy logits): the general entry point, rare
+                out = self._round_with_hidden(group, segs)
+            else:
+                out = self.model.round_multi(segs)
+        except BaseException as e:
+            for r in group:
+                r.result = e
+                if r.kind == 'generate':
+                    r.gen['done'] = True
+            return
+        for r, o in zip(group, out):
+            if r.kind == 'generate':
+                g = r.gen
+                g['cache'] = o['cache']
+                g['ids'].append(o['token'])
+                if o['token'] == g['eos'] or len(g['ids']) >= g['max_new']:
+                    g['done'] = True
+                    r.result = dict(ids=g['ids'], cache=g['cache'])
+            elif r.kind == 'forward':
+                r.result = dict(hidden=o['hidden'], cache=o['cache'])
+            else:
+                r.result = dict(heads=o['heads'], cache=o['cache'])
+
+    def _round_with_hidden(self, group, segs):
+        """A round that contains a 'forward' request (all hidden rows of a query turn wanted): the forwards go through multi_step; talking streams sit the round out
+        (their requests stay posted)."""
+        out = [None] * len(group)
+        idx = [i for i, r in enumerate(group) if r.kind != 'generate']
+        res = self.model.multi_step([dict(x=group[i].x, cache=group[i].cache, head_rows=group[i].head_rows, hidden='all' if group[i].kind == 'forward' else 'none') for i in idx],
+                                    want_logits=False)
+        for i, o in zip(idx, res):
+            out[i] = o
+        gi = [i for i, r in enumerate(group) if r.kind == 'generate']
+        if gi:
+            res = self.model.round_multi([segs[i] for i in gi])
+            for i, o in zip(gi, res):
+                out[i] = o
+        return out
 
     def run(self, videos, on_result=None):
         """`videos` entries may be callables returning the dict (or None to skip): they are evaluated when a slot takes them, so a long test
@@ -224,5 +304,8 @@ class MultiStreamInfer:
                 break
             self._execute([s.request for s in running])
             for s in running:                  # strictly one thread at a time: resume, wait until it parks again or ends
+                rq = s.request
+                if rq is not None and rq.kind == 'generate' and rq.result is None and not rq.gen.get('done'):
+                    continue                   # mid-response: the slot stays parked, the scheduler feeds its next token itself
                 s.go.release(); self.parked.acquire()
         return self.results

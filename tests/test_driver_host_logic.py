@@ -111,12 +111,50 @@ class _OracleWithMultiStep:
         return out
 
 
+class _OracleSampler:
+    def begin(self, eos, penalty, prev, max_new):
+        self.eos, self.penalty, self.prev, self.tok = eos, penalty, list(prev or []), None
+
+
+class _OracleWithRounds(_OracleWithMultiStep):
+    """... plus `round_multi` / `new_sampler` with the semantics of mmd_round_multi / mmd_sampler (sampling inside the round, feed rows gathered from the sampler's last
+    token): the scheduler then keeps a talking slot parked for the whole response."""
+
+    def new_sampler(self):
+        return _OracleSampler()
+
+    def round_multi(self, segments):
+        self.multi_calls.append([1 if s.get('feed') else s['x'].reshape(-1, s['x'].shape[-1]).shape[0] for s in segments])
+        out = []
+        for s in segments:
+            sp = s.get('sampler')
+            x = self._m.get_input_embeddings()(torch.tensor([[sp.tok]])) if s.get('feed') else s['x']
+            x = x.reshape(1, -1, x.shape[-1])
+            r = self._m(inputs_embeds=x, past_key_values=s['cache'], use_cache=True, return_dict=True)
+            rows = list(s.get('head_rows', ()))
+            heads = torch.cat([r.informative_logits[0, rows], r.relevance_logits[0, rows]], dim=-1).float() if rows else None
+            tok = None
+            if s.get('sample'):
+                scores = r.logits[0, -1].float().clone()
+                if sp.penalty is not None and sp.prev:
+                    idx = torch.as_tensor(sp.prev, dtype=torch.long)
+                    picked = scores[idx]
+                    scores[idx] = torch.where(picked < 0, picked * sp.penalty, picked / sp.penalty)
+                tok = int(scores.argmax(-1))
+                sp.tok = tok
+                if sp.penalty is not None and tok != sp.eos:
+                    sp.prev.append(tok)
+            out.append(dict(heads=heads, token=tok, cache=r.past_key_values))
+        return out
+
+
+@pytest.mark.parametrize('native_rounds', [False, True], ids=['python_decode', 'round_multi'])
 @pytest.mark.parametrize('n_slots,k', [(1, 1), (3, 1), (6, 3), (4, 2)])
-def test_multistream_scheduler_matches_reference_driver(n_slots, k):
+def test_multistream_scheduler_matches_reference_driver(n_slots, k, native_rounds):
     from mmduet_amd.multistream import MultiStreamInfer
     from helpers import stream_frames
     base, _, _ = oracle_model('A')
-    model = _OracleWithMultiStep(base)
+    model = (_OracleWithRounds if native_rounds else _OracleWithMultiStep)(base)
     tok = tokenizer_for(base.config)
     base.config.eos_token_id = META['eos_token_id']
     names = list(META['cases'])
@@ -141,7 +179,10 @@ def test_multistream_scheduler_matches_reference_driver(n_slots, k):
     assert max(widths) == min(n_slots, len(names))                       # the forwards really carried one segment per live slot
     if n_slots > 1:
         assert any(1 in c and max(c) > 1 for c in model.multi_calls)     # a generating stream (1 row) rode with other streams' rows
-    assert ms.rounds == len(model.multi_calls)
+    if native_rounds:          # (a round that carries a query turn -- all hidden rows wanted -- next to a talking stream is two model calls)
+        assert ms.rounds <= len(model.multi_calls) <= ms.rounds + len(names)
+    else:
+        assert ms.rounds == len(model.multi_calls)
 
 
 def test_multistream_scheduler_propagates_errors():

@@ -29,12 +29,16 @@ def model_f32():
     return m
 
 
+@pytest.mark.parametrize('python_decode', [False, True], ids=['native_rounds', 'python_decode'])
 @pytest.mark.parametrize('n_slots', [2, 6])
 @pytest.mark.parametrize('k', [1, 4])
-def test_concurrent_streams_match_reference_fixtures(model_f32, n_slots, k):
+def test_concurrent_streams_match_reference_fixtures(model_f32, n_slots, k, python_decode):
+    """(native_rounds: responses decode inside mmd_round_multi -- sampling, repetition penalty and the next token's embedding on the device, a talking slot parked for
+    the whole response; python_decode: the per-token host loop over mmd_frame_step_multi, the cross-check.)"""
     names = list(META['cases'])
     videos = [dict(frames=stream_frames(n), conversation=META['cases'][n]['conversation'], args=_args_for(META['cases'][n], k)) for n in names]
     ms = MultiStreamInfer(videos[0]['args'], model=model_f32, tokenizer=model_f32.tok, n_slots=n_slots)
+    ms.python_decode = python_decode
     results = ms.run(videos)
     for name, res in zip(names, results):
         case = META['cases'][name]

@@ -420,6 +420,62 @@ def test_ring_attention_repeats_bit_identical_beside_a_copy_stream(ops, S, n_ctx
     torch.cuda.synchronize()
 
 
+def _ref_attention_rows(q, K, V, nh, nkv, d, n_ctx, rows):
+    """fp32 attention of the query rows `rows` only (row r sees keys 0 .. n_ctx + r), one kv group and 256 Ki keys at a time with a running (max, sum) --
+    the 1 M-key contexts never materialise an [S, n] score matrix.  q [S, nh*d]; K / V [nkv, cap, d] row-major."""
+    rep = nh // nkv
+    rows_t = torch.as_tensor(rows, device=q.device)
+    qh = q.float().view(q.shape[0], nh, d)[rows_t].transpose(0, 1)              # [nh, R, d]
+    out = torch.empty(nh, len(rows), d, device=q.device)
+    n_max = n_ctx + max(rows) + 1
+    for h in range(nkv):
+        qq = qh[h * rep:(h + 1) * rep] * d ** -0.5
+        m = torch.full((rep, len(rows), 1), float('-inf'), device=q.device); l = torch.zeros_like(m); acc = torch.zeros(rep, len(rows), d, device=q.device)
+        for k0 in range(0, n_max, 1 << 18):
+            k1 = min(n_max, k0 + (1 << 18))
+            s = qq @ K[h, k0:k1].float().T
+            dead = torch.arange(k0, k1, device=q.device)[None, :] > (rows_t[:, None] + n_ctx)
+            s = s.masked_fill(dead[None], float('-inf'))
+            m2 = torch.maximum(m, s.amax(-1, keepdim=True))
+            p = torch.exp(s - m2); sc = torch.exp(m - m2)
+            l = l * sc + p.sum(-1, keepdim=True); acc = acc * sc + p @ V[h, k0:k1].float(); m = m2
+        out[h * rep:(h + 1) * rep] = acc / l
+    return out.transpose(0, 1).reshape(len(rows), nh * d)
+
+
+@pytest.mark.parametrize('S,variant,form', [(49, 5, 5), (1, 3, 3), (1274, 6, 8)], ids=['frame_step', 'decode_row', 'chunk_26_frames'])
+def test_attention_over_a_million_keys(ops, S, variant, form):
+    """BASELINE configs[2] names "KV-cache growth to HBM limit" (test/inference.py:239 over the growing cache): the three LLM attention forms of the stream -- a 49-row frame
+    step (attn_gqa128_w1_kernel), a decode row (the loader / compute ring) and a 26-frame chunk (attn_gqa128_chunk_kernel) -- over 1 000 037 keys (57 GB of a 7B stream's
+    arena, 20 000 frames) against fp32 math on sampled query rows; same bound as at the production sizes.  Also: unused slots behind the context never reach the result."""
+    import ctypes as C
+    from mmduet_amd._lib import lib
+    nh, nkv, d = 28, 4, 128
+    n_ctx = 1_000_037
+    dev = ops.dev
+    g = torch.Generator(device=dev).manual_seed(S + 7)
+    cap = (n_ctx + S + 100 + 63) // 64 * 64
+    q = torch.randn(S, nh * d, generator=g, device=dev).to(torch.bfloat16)
+    K = torch.randn(nkv, cap, d, generator=g, device=dev).to(torch.bfloat16)
+    V = torch.randn(nkv, cap, d, generator=g, device=dev).to(torch.bfloat16)
+    K[:, n_ctx + S:] = 1e4; V[:, n_ctx + S:] = 1e4
+    # make a handful of keys spread over the whole context matter (random scores over 1 M keys are nearly flat): every sampled row gets keys it strongly prefers
+    rows = sorted({0, S - 1, S // 2, S // 3, (2 * S) // 3})
+    hot = torch.randint(0, n_ctx, (24,), generator=g, device=dev)
+    qf = q.float().view(S, nh, d)
+    for j, r in enumerate(rows):
+        for h in range(nkv):
+            K[h, hot[(j * nkv + h) % 24]] = (qf[r, h * (nh // nkv)] * 1.5).to(torch.bfloat16)          # score ~ 17 against ln(sum of a million e^N(0,1)) ~ 14.3
+    o = ops.attention(q, K, V, nh, nkv, d, n_ctx, True, variant)
+    got_form = (C.c_int * 2)(); lib().mmd_op_attention_last_form(got_form)
+    assert got_form[0] == form, list(got_form)
+    ref = _ref_attention_rows(q, K, V, nh, nkv, d, n_ctx, rows)
+    err = _rel_err(o[torch.as_tensor(rows, device=dev)], ref)
+    _record(f'attn_1M_S{S}', rel_err=err, form=got_form[0], splits=got_form[1])
+    assert torch.isfinite(o.float()).all() and err <= 1.8e-2, err
+    assert ref.abs().max().item() > 0.05          # the sampled rows are not the flat average of a million values
+
+
 # ---- true-width models ---------------------------------------------------------------------------------------------------------------
 def _build(llm_layers, vit_layers, dtype, vocab=2048, max_vit_batch=35, max_step_tokens=1536, seed=3, tower_dtype=None):
     """(HIP model, oracle weights dict on the device in `dtype`-rounded fp32, oracle config)."""
@@ -552,6 +608,82 @@ def test_chunk_of_26_frames_equals_26_frame_steps_true_width(width2):
     _record('chunk26_2_layers', chunk_vs_fp32=maxerr(chunk, want), per_frame_vs_fp32=maxerr(per, want), chunk_vs_per_frame=maxerr(chunk, per),
             bf16_oracle_vs_fp32=maxerr(want16, want))
     assert maxerr(chunk, want) < 6e-2 and maxerr(per, want) < 6e-2 and maxerr(chunk, per) < 6e-2
+
+
+def test_native_decode_rounds_equal_single_stream_generate_true_width(width2):
+    """mmd_round_multi (several streams per forward, sampling on the device; the multi-stream form of models/modeling_live.py:51-77) against mmd_greedy_generate run
+    stream by stream on the same contexts, at true widths in bf16.  The rounds cover the three schedules a round can take: every talking stream's row alone (<= 4 rows:
+    the GEMV chain with the q / k / v preparation inside the attention kernel, each stream's rows of the qkv slabs at its row offset), talking rows next to a 98-row
+    frame chunk (the fused slab schedule, <= 256 rows) and next to a 637-row chunk (tile GEMMs).  Token ids equal, the repetition-penalty list carried over a second
+    response, KV lengths equal, and the arenas continue to the same head logits afterwards."""
+    m = width2[0]
+    H = m.config.hidden_size
+    g = torch.Generator(device=m.device).manual_seed(11)
+    rnd = lambda n: (torch.randn(n, H, generator=g, device=m.device) * 0.5).to(torch.bfloat16)
+    ctx_x = [rnd(5000), rnd(700), rnd(300), rnd(1200)]              # the four streams' pasts (5000: the attention runs its long-context forms)
+    prompts = [rnd(4), rnd(6), rnd(4), rnd(5)]
+    chunk98, chunk637, probe = rnd(98), rnd(637), rnd(49)
+    N = 10
+
+    def build():
+        caches = []
+        for x in ctx_x:
+            c = None
+            for s0 in range(0, x.shape[0], 1024):
+                c = m(inputs_embeds=x[None, s0:s0 + 1024], past_key_values=c).past_key_values
+            caches.append(c)
+        return caches
+
+    # reference: one stream at a time through the single-stream native loop (two responses each: the penalty list persists)
+    ref_ids, ref_len, ref_probe, ref_seen = [], [], [], []
+    caches = build()
+    for c, p in zip(caches, prompts):
+        seen = [3, 5]
+        ids1, c1 = m.greedy_generate(p, c, -1, N, 1.15, seen)
+        ids2, c2 = m.greedy_generate(p, c1, -1, N, 1.15, seen)
+        ref_ids.append((ids1, ids2)); ref_len.append(len(c2)); ref_seen.append(list(seen))
+        ref_probe.append(m.frame_step(probe[None], c2, [48])[0])
+    # the same through rounds: streams 0 / 1 start together, stream 2 two rounds later, stream 3 five rounds later; a 98-row chunk of a watching stream rides in
+    # rounds 3-4, a 637-row chunk in round 6
+    caches = build()
+    smp = [m.new_sampler() for _ in range(4)]
+    watcher = m.new_cache()
+    got = [([], []) for _ in range(4)]
+    seen = [[3, 5] for _ in range(4)]
+    for resp in range(2):
+        state = [dict(start=st, n=0) for st in (0, 0, 2, 5)]
+        rnd_i = 0
+        while any(s['n'] < N for s in state):
+            segs, who = [], []
+            for i, s in enumerate(state):
+                if rnd_i < s['start'] or s['n'] >= N:
+                    continue
+                if s['n'] == 0:
+                    smp[i].begin(-1, 1.15, seen[i], N)
+                    segs.append(dict(x=prompts[i], cache=caches[i], sampler=smp[i], sample=True))
+                else:
+                    segs.append(dict(x=None, cache=caches[i], sampler=smp[i], feed=True, sample=True))
+                who.append(i)
+            if rnd_i in (3, 4):
+                segs.append(dict(x=chunk98, cache=watcher, head_rows=[48, 97]))
+            if rnd_i == 6:
+                segs.insert(1, dict(x=chunk637, cache=watcher, head_rows=[636])); who.insert(1, None)
+            out = m.round_multi(segs)
+            for i, o in zip(who + [None] * (len(segs) - len(who)), out):
+                if i is None:
+                    if o['heads'] is not None:
+                        watcher = o['cache']; assert torch.isfinite(o['heads']).all()
+                    continue
+                caches[i] = o['cache']; got[i][resp].append(o['token']); state[i]['n'] += 1
+                seen[i].append(o['token'])
+            rnd_i += 1
+    for i in range(4):
+        assert (got[i][0], got[i][1]) == (ref_ids[i][0], ref_ids[i][1]), i
+        assert seen[i] == ref_seen[i]
+        assert len(caches[i]) == ref_len[i]
+        pr = m.frame_step(probe[None], caches[i], [48])[0]
+        assert maxerr(pr, ref_probe[i]) <= 0.06 * max(1.0, ref_probe[i].abs().max().item()), i          # (bf16: the rounds' GEMVs ran over 1 .. 640 rows, other accumulation order)
+    assert len(watcher) == 2 * (98 * 2 + 637)
 
 
 def test_per_frame_steps_over_a_long_context_true_width(width2):
