@@ -32,6 +32,8 @@ struct AttnP {
     const float* slabs; int n_slabs; const void* qkv_bias; const float2* rope_tab;     // AttnArgs::qkv_slabs (attn_gqa128<1> only)
     int slab_rows;      // rows of one slab (the GEMV's M: >= S when the step carries other streams' rows too, mmd_round_multi)
     int block_rows;     // attn_gqa128_w1_kernel: query rows per block (multiple of 16)
+    int nseg;           // > 0 (decode form only): grid.x = nseg independent streams of S rows each (consecutive rows of q / out / slabs / rope_tab), stream j's context, capacity
+                        // and arena base in dyn[j] (AttnArgs::segs); partials [seg][split][rows]
 };
 
 static int g_last_form[2] = {0, 0};          // (diagnostic only: which form the most recent launch took, mmd_op_attention_last_form)
@@ -332,6 +334,17 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void attn_gqa128_ke
     int bx, by, bz; xcd_block_id(bx, by, bz);
     const int G = p.nh / p.nkv, kvh = by;
     const int rows_total = p.S * G;
+    if constexpr (RT == 1 && NSLOT == 4 && WAVES == 4) {
+        if (p.nseg > 0) {                          // several streams' decode rows in one launch (mmd_round_multi): block column bx = stream; its rows, slabs and partials by offset
+            const int seg = bx; bx = 0;
+            p.dyn += seg;
+            p.q = (const bf16_t*)p.q + (long long)seg * p.S * p.ldq;
+            p.out = (bf16_t*)p.out + (long long)seg * p.S * p.ldo;
+            if (p.slabs) { p.slabs += (long long)seg * p.S * ((p.nh + 2 * p.nkv) * D); p.rope_tab += seg * p.S * (D / 2); }
+            const long long part = (long long)gridDim.z * gridDim.y * rows_total;
+            p.ws_o += seg * part * D; p.ws_ml += seg * part * 2;
+        }
+    }
     const int row_base = bx * BR + wave * (16 * RT);
     long long n_ctx = p.n_ctx, k_hs = p.k_hs, v_hs = p.v_hs;
     const bf16_t* Kb = (const bf16_t*)p.K; const bf16_t* Vb = (const bf16_t*)p.V;
@@ -891,7 +904,14 @@ __global__ __launch_bounds__(256) void attn_combine128_kernel(AttnP p, int nrows
 // independent 512-byte loads per wave instead of a chain of four) and meet in LDS.  7.0 -> ~4 us per layer at 15 k keys.
 __global__ __launch_bounds__(256) void attn_combine128_rows_kernel(AttnP p, int nrows_all) {
     __shared__ float sm[4][130];
-    const int grow = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int grow = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (p.nseg > 0) {                              // batched decode rows: nrows_all rows per stream, partials [seg][split][rows]
+        const int seg = grow / nrows_all; grow -= seg * nrows_all;
+        p.out = (bf16_t*)p.out + (long long)seg * p.S * p.ldo;
+        const long long part = (long long)p.splits * nrows_all;
+        p.ws_o += seg * part * 128; p.ws_ml += seg * part * 2;
+    }
     const int G = p.nh / p.nkv, rows_total = p.S * G;
     const int row = grow % rows_total, kvh = grow / rows_total;
     const int tok = row / G, head = kvh * G + row % G;
@@ -1531,6 +1551,43 @@ static hipError_t launch_mfma(AttnP& p, const AttnArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
+// Decode rows of SEVERAL streams in one launch (mmd_round_multi's talking streams): grid.x = stream, each stream's keys cut into the same number of splits so that
+// nseg x nkv x splits blocks fill the chip once (one stream alone: 64 splits of ~4 tiles at 15 k keys; four streams: 16 splits of ~15 tiles -- a quarter of the
+// launches, partial rows and merge work per token).  a = the FIRST stream's rows (q / out / slabs / rope_tab; the others follow at S-row steps); a.segs (device)
+// holds every stream's context length, capacity and arena base.  bf16, head_dim 128, S x G <= 16.
+hipError_t launch_attention_decode_multi(const AttnArgs& a, hipStream_t st) {
+    const int G = a.nh / a.nkv, rows_total = a.S * G;
+    if (a.nseg < 1 || a.nseg > 64 || !a.segs || a.d != 128 || !a.v_transposed || a.k_ts != 128 || rows_total > 16 || !a.ws || a.nseg * a.nkv > 256) return hipErrorInvalidValue;
+    if (a.qkv_slabs && (a.n_slabs < 1 || a.n_slabs > 4)) return hipErrorInvalidValue;
+    AttnP p;
+    p.q = a.q; p.K = nullptr; p.V = nullptr; p.out = a.out; p.ldq = a.ldq; p.ldo = a.ldo;
+    p.k_hs = 0; p.k_ts = a.k_ts; p.v_hs = 0; p.v_ts = a.v_ts; p.q_bs = 0; p.kv_bs = 0; p.o_bs = 0;
+    p.n_ctx = 0; p.S = a.S; p.nh = a.nh; p.nkv = a.nkv; p.d = a.d; p.causal = 1; p.v_tr = 1; p.dyn = a.segs; p.layer = a.layer;
+    p.scale_log2 = (1.0f / sqrtf((float)a.d)) * 1.4426950408889634f;
+    p.slabs = a.qkv_slabs; p.n_slabs = a.n_slabs; p.qkv_bias = a.qkv_bias; p.rope_tab = (const float2*)a.rope_tab; p.slab_rows = a.slab_rows > 0 ? a.slab_rows : a.S * a.nseg;
+    p.block_rows = 0; p.nseg = a.nseg;
+    int splits = 256 / (a.nseg * a.nkv);
+    if (splits > 64) splits = 64;
+    if (splits < 2) splits = 2;                    // (the merge kernel writes the output: at least two partials keep one code path; > 32 streams per round never occur)
+    const int nrows_all = a.nkv * rows_total;
+    while (splits > 2 && (size_t)a.nseg * splits * nrows_all * (128 + 2) * sizeof(float) > a.ws_bytes) --splits;
+    if ((size_t)a.nseg * splits * nrows_all * (128 + 2) * sizeof(float) > a.ws_bytes || a.nseg * a.nkv * splits > 512) return hipErrorInvalidValue;
+    p.splits = splits; p.kv_per_split = 0;         // (per stream, computed in the kernel from its own context length -- the dyn path)
+    p.ws_o = a.ws;
+    p.ws_ml = a.ws + (size_t)a.nseg * splits * nrows_all * 128;
+    static bool attr_set[64] = {};
+    int dev = 0; hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        hipError_t e = hipFuncSetAttribute((const void*)attn_gqa128_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
+        if (e != hipSuccess) return e;
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL((attn_gqa128_kernel<1, 4>), dim3(a.nseg, a.nkv, splits), dim3(256), 4 * 32768, st, p);
+    hipLaunchKernelGGL(attn_combine128_rows_kernel, dim3(a.nseg * nrows_all), dim3(256), 0, st, p, nrows_all);
+    g_last_form[0] = 9; g_last_form[1] = splits;
+    return hipGetLastError();
+}
+
 extern "C" int mmd_op_attention_last_form(int* out2) { if (!out2) return MMD_EINVAL; out2[0] = g_last_form[0]; out2[1] = g_last_form[1]; return MMD_OK; }
 static hipError_t launch_attention_(int dtype, const AttnArgs& a, hipStream_t st, AttnP& p);
 hipError_t launch_attention(int dtype, const AttnArgs& a, hipStream_t st) {
@@ -1549,7 +1606,7 @@ static hipError_t launch_attention_(int dtype, const AttnArgs& a, hipStream_t st
     p.n_ctx = a.n_ctx; p.S = a.S; p.nh = a.nh; p.nkv = a.nkv; p.d = a.d; p.causal = a.causal;
     p.splits = 1; p.kv_per_split = 0; p.v_tr = a.v_transposed; p.dyn = a.dyn; p.layer = a.layer;
     p.scale_log2 = (1.0f / sqrtf((float)a.d)) * 1.4426950408889634f;
-    p.slabs = a.qkv_slabs; p.n_slabs = a.n_slabs; p.qkv_bias = a.qkv_bias; p.rope_tab = (const float2*)a.rope_tab; p.slab_rows = a.slab_rows > 0 ? a.slab_rows : a.S;
+    p.slabs = a.qkv_slabs; p.n_slabs = a.n_slabs; p.qkv_bias = a.qkv_bias; p.rope_tab = (const float2*)a.rope_tab; p.slab_rows = a.slab_rows > 0 ? a.slab_rows : a.S; p.nseg = 0;
     const bool f16 = dtype == MMD_F16;          // the fp16 vision tower: the row-major kernel only
     bool can_mfma = (dtype == MMD_BF16 || f16) && (a.d % 8) == 0 && a.d <= 128 && (a.ldq % 8) == 0 && (a.k_ts % 8) == 0 && (a.v_ts % 8) == 0 &&
                     (a.k_hs % 8) == 0 && (a.v_hs % 8) == 0 && (a.kv_bstride % 8) == 0 && (a.q_bstride % 8) == 0;

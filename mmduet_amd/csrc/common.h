@@ -223,5 +223,7 @@ struct AttnArgs {
     // position -- appends that token's K row / V column to the arena before staging the tile: no slab_rope_append launch, no q buffer.
     const float* qkv_slabs = nullptr; int n_slabs = 0; const void* qkv_bias = nullptr; const void* rope_tab = nullptr;   // slabs [n][slab_rows][(nh+2nkv)*d] (this step's first row); tab float2 [S][d/2]
     int slab_rows = 0;               // rows of one slab = the projection's M (0: S); larger than S when one GEMV served several streams' rows (mmd_round_multi)
+    const StepState* segs = nullptr; int nseg = 0;   // launch_attention_decode_multi: the streams' (context length, capacity, arena base), device
 };
 hipError_t launch_attention(int dtype, const AttnArgs& a, hipStream_t st);
+hipError_t launch_attention_decode_multi(const AttnArgs& a, hipStream_t st);     // decode rows of a.nseg streams in one launch (attn.hip)

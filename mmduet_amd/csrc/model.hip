@@ -102,6 +102,7 @@ struct mmd_ctx {
     void* rope_tab = 0;                // (cos, sin) of a decode step's positions (launch_rope_table), read by the attention kernel's fused q/k/v preparation
     bool no_rope_fuse = false;         // MMDUET_NO_ROPE_FUSE=1: decode steps keep the slab_rope_append launch (A/B)
     float* chain_ssq = 0;              // GemvChain scratch: per-row, per-n-tile sums of squares
+    StepState* seg_dev = nullptr; StepState* seg_host = nullptr; int seg_slot = 0;          // per-stream (context, capacity, arena) of a step's batched decode attention: 8 slots of 64, rotated per step
     // mmd_round_multi (allocated at its first use): logits of the sampling rows, their gathered hidden rows, the two-stage argmax candidates, the drawn tokens
     float* round_logits = 0; void* round_hidden = 0; void* round_scratch = 0; int64_t* round_toks_dev = 0; int64_t* round_toks_host = 0;
     Prof prof;
@@ -596,6 +597,8 @@ static int alloc_workspaces(mmd_ctx* c) {
     HIPCHK(c, hipHostMalloc((void**)&c->rows_host, (size_t)S * sizeof(int32_t)));
     HIPCHK(c, hipHostMalloc((void**)&c->tok_host, 64));
     HIPCHK(c, hipHostMalloc((void**)&c->step_host, sizeof(StepState)));
+    HIPCHK(c, hipHostMalloc((void**)&c->seg_host, 8 * 64 * sizeof(StepState)));
+    rc = dev_alloc(c, (void**)&c->seg_dev, 8 * 64 * sizeof(StepState)); if (rc) return rc;
     rc = dev_alloc(c, (void**)&c->step_dev, sizeof(StepState)); if (rc) return rc;
     return MMD_OK;
 }
@@ -1268,8 +1271,21 @@ static int llm_step_segs(mmd_ctx* c, const StepSeg* segs, int nseg, const void* 
     if (dyn && !fused) FAIL(c, MMD_EINVAL, "graph decode needs the fused bf16 schedule");
     if (fused) { ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * S * H * e, 0); HIPCHK(c, launch_rmsnorm(dt, c->l_h, c->L[0].ln1, c->l_xn, S, H, g.rms_norm_eps, st)); }
 
+    // Several streams, each with the same one or two rows (the talking streams of a scheduler round): ONE attention launch for all of them (launch_attention_decode_multi) -- a
+    // quarter of the launches, partials and merge work of four per-stream launches whose 64-way key splits each fill the chip alone.  MMDUET_NO_MULTI_ATTN=1: per stream (A/B)
+    static const bool no_multi_attn = getenv("MMDUET_NO_MULTI_ATTN") != nullptr;
+    bool multi_attn = fused && nseg > 1 && nseg <= 64 && d == 128 && !no_multi_attn && !dyn && segs[0].rows * (nh / nkv) <= 16 && nseg * nkv <= 256;
+    for (int j = 1; multi_attn && j < nseg; ++j) multi_attn = segs[j].rows == segs[0].rows;
+    const StepState* seg_states = nullptr;
+    if (multi_attn) {
+        StepState* hs = c->seg_host + (size_t)c->seg_slot * 64; StepState* ds = c->seg_dev + (size_t)c->seg_slot * 64;
+        c->seg_slot = (c->seg_slot + 1) & 7;
+        for (int j = 0; j < nseg; ++j) { hs[j].n_ctx = segs[j].s->len; hs[j].cap = segs[j].s->cap; hs[j].K = segs[j].s->K; hs[j].V = segs[j].s->V; hs[j].n_prev = 0; hs[j].pad = 0; }
+        HIPCHK(c, hipMemcpyAsync(ds, hs, sizeof(StepState) * nseg, hipMemcpyHostToDevice, st));
+        seg_states = ds;
+    }
     // rows <= 4, head_dim 128: the attention kernel prepares q / k / v from the qkv slabs itself (AttnArgs::qkv_slabs)
-    const bool rope_fused = chain && d == 128 && !c->no_rope_fuse;
+    const bool rope_fused = (chain || (multi_attn && S <= 16)) && d == 128 && !c->no_rope_fuse;
     if (rope_fused) for (int j = 0; j < nseg; ++j) HIPCHK(c, launch_rope_table((char*)c->rope_tab + (size_t)segs[j].row0 * 64 * 8, segs[j].rows, 64, c->inv_freq, segs[j].s->len, st, dyn));
     // chunks (bf16, head_dim 128): one (cos, sin) table per step and segment, read by the vectorised RoPE + append kernel of every layer; MMDUET_NO_CHUNK_ROPE=1 keeps the scalar kernel
     static const bool no_chunk_rope = getenv("MMDUET_NO_CHUNK_ROPE") != nullptr;
@@ -1298,7 +1314,7 @@ static int llm_step_segs(mmd_ctx* c, const StepSeg* segs, int nseg, const void* 
         if (fused) {
             ch_xn.xn_gamma = L.ln1;
             rc = slab_gemm(c->l_xn, H, L.wqkv_p, c->qkv_w, H, &splits, L.wqkv_8, L.sqkv, chain && i > 0 ? &ch_xn : nullptr); if (rc) return rc;
-            if (!rope_fused) {
+            if (!rope_fused || splits > 4) {          // (the attention kernel's own q / k / v preparation sums at most four slabs)
                 ProfScope ps(c, MMD_K_NORM_ROPE, 2.0 * S * c->qkv_w * e, 0);
                 for (int j = 0; j < nseg; ++j) {
                     mmd_stream* sj = segs[j].s;
@@ -1325,7 +1341,18 @@ static int llm_step_segs(mmd_ctx* c, const StepSeg* segs, int nseg, const void* 
                                              sj->cap, 1, st));
             }
         }
-        for (int j = 0; j < nseg; ++j) {
+        if (multi_attn) {
+            AttnArgs a; memset(&a, 0, sizeof(a));
+            a.q = c->l_q; a.ldq = (int64_t)nh * d; a.out = c->l_attn; a.ldo = (int64_t)nh * d; a.k_ts = d; a.v_ts = d; a.v_transposed = 1;
+            a.S = segs[0].rows; a.nh = nh; a.nkv = nkv; a.d = d; a.causal = 1; a.batch = 1; a.ws = c->attn_ws; a.ws_bytes = c->attn_bytes; a.layer = i;
+            a.segs = seg_states; a.nseg = nseg;
+            if (rope_fused && splits <= 4) { a.qkv_slabs = c->splitk_ws; a.slab_rows = S; a.n_slabs = splits; a.qkv_bias = L.bqkv; a.rope_tab = c->rope_tab; }
+            double kvb = 0, fl = 0;
+            for (int j = 0; j < nseg; ++j) { const double nk = (double)(segs[j].s->len + segs[j].rows); kvb += 2.0 * nk * nkv * d * e; fl += 4.0 * segs[j].rows * nk * nh * d; }
+            ProfScope ps(c, MMD_K_ATTN_LLM, kvb + 2.0 * S * nh * d * e, fl);
+            HIPCHK(c, launch_attention_decode_multi(a, st));
+        }
+        for (int j = 0; j < nseg && !multi_attn; ++j) {
             mmd_stream* sj = segs[j].s;
             const size_t le = kv_layer_elems(c, sj->cap);
             const int Sj = segs[j].rows; const int64_t nj = sj->len;
@@ -1337,7 +1364,7 @@ static int llm_step_segs(mmd_ctx* c, const StepSeg* segs, int nseg, const void* 
             a.S = Sj; a.nh = nh; a.nkv = nkv; a.d = d; a.n_ctx = nj; a.causal = 1; a.v_transposed = 1;
             a.batch = 1; a.ws = c->attn_ws; a.ws_bytes = c->attn_bytes; a.variant = 0;
             a.dyn = dyn; a.layer = i; a.dyn_splits = 64;
-            if (rope_fused) { a.qkv_slabs = c->splitk_ws + (size_t)segs[j].row0 * c->qkv_w; a.slab_rows = S; a.n_slabs = splits; a.qkv_bias = L.bqkv; a.rope_tab = (char*)c->rope_tab + (size_t)segs[j].row0 * 64 * 8; }
+            if (rope_fused && splits <= 4) { a.qkv_slabs = c->splitk_ws + (size_t)segs[j].row0 * c->qkv_w; a.slab_rows = S; a.n_slabs = splits; a.qkv_bias = L.bqkv; a.rope_tab = (char*)c->rope_tab + (size_t)segs[j].row0 * 64 * 8; }
             double kvb = 2.0 * (double)(nj + Sj) * nkv * d * e;
             ProfScope ps(c, MMD_K_ATTN_LLM, kvb + 2.0 * Sj * nh * d * e, 4.0 * Sj * (double)(nj + Sj) * nh * d);
             HIPCHK(c, launch_attention(dt, a, st));

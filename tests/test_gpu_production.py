@@ -610,7 +610,8 @@ def test_chunk_of_26_frames_equals_26_frame_steps_true_width(width2):
     assert maxerr(chunk, want) < 6e-2 and maxerr(per, want) < 6e-2 and maxerr(chunk, per) < 6e-2
 
 
-def test_native_decode_rounds_equal_single_stream_generate_true_width(width2):
+@pytest.mark.parametrize('layout', ['four_staggered_with_chunks', 'six_together'])
+def test_native_decode_rounds_equal_single_stream_generate_true_width(width2, layout):
     """mmd_round_multi (several streams per forward, sampling on the device; the multi-stream form of models/modeling_live.py:51-77) against mmd_greedy_generate run
     stream by stream on the same contexts, at true widths in bf16.  The rounds cover the three schedules a round can take: every talking stream's row alone (<= 4 rows:
     the GEMV chain with the q / k / v preparation inside the attention kernel, each stream's rows of the qkv slabs at its row offset), talking rows next to a 98-row
@@ -622,8 +623,15 @@ def test_native_decode_rounds_equal_single_stream_generate_true_width(width2):
     rnd = lambda n: (torch.randn(n, H, generator=g, device=m.device) * 0.5).to(torch.bfloat16)
     ctx_x = [rnd(5000), rnd(700), rnd(300), rnd(1200)]              # the four streams' pasts (5000: the attention runs its long-context forms)
     prompts = [rnd(4), rnd(6), rnd(4), rnd(5)]
+    starts = (0, 0, 2, 5)
+    if layout == 'six_together':          # six talking streams from the first round on: 6 rows per round = the slab schedule (not the GEMV chain) with the batched decode attention
+        ctx_x += [rnd(64), rnd(4100)]; prompts = [rnd(4) for _ in range(6)]; starts = (0,) * 6
+    n_str = len(ctx_x)
     chunk98, chunk637, probe = rnd(98), rnd(637), rnd(49)
     N = 10
+    import ctypes as C
+    from mmduet_amd._lib import lib
+    forms = set()
 
     def build():
         caches = []
@@ -646,12 +654,12 @@ def test_native_decode_rounds_equal_single_stream_generate_true_width(width2):
     # the same through rounds: streams 0 / 1 start together, stream 2 two rounds later, stream 3 five rounds later; a 98-row chunk of a watching stream rides in
     # rounds 3-4, a 637-row chunk in round 6
     caches = build()
-    smp = [m.new_sampler() for _ in range(4)]
+    smp = [m.new_sampler() for _ in range(n_str)]
     watcher = m.new_cache()
-    got = [([], []) for _ in range(4)]
-    seen = [[3, 5] for _ in range(4)]
+    got = [([], []) for _ in range(n_str)]
+    seen = [[3, 5] for _ in range(n_str)]
     for resp in range(2):
-        state = [dict(start=st, n=0) for st in (0, 0, 2, 5)]
+        state = [dict(start=st, n=0) for st in starts]
         rnd_i = 0
         while any(s['n'] < N for s in state):
             segs, who = [], []
@@ -664,11 +672,12 @@ def test_native_decode_rounds_equal_single_stream_generate_true_width(width2):
                 else:
                     segs.append(dict(x=None, cache=caches[i], sampler=smp[i], feed=True, sample=True))
                 who.append(i)
-            if rnd_i in (3, 4):
+            if rnd_i in (3, 4) and layout != 'six_together':
                 segs.append(dict(x=chunk98, cache=watcher, head_rows=[48, 97]))
-            if rnd_i == 6:
+            if rnd_i == 6 and layout != 'six_together':
                 segs.insert(1, dict(x=chunk637, cache=watcher, head_rows=[636])); who.insert(1, None)
             out = m.round_multi(segs)
+            f = (C.c_int * 2)(); lib().mmd_op_attention_last_form(f); forms.add(f[0])
             for i, o in zip(who + [None] * (len(segs) - len(who)), out):
                 if i is None:
                     if o['heads'] is not None:
@@ -677,13 +686,14 @@ def test_native_decode_rounds_equal_single_stream_generate_true_width(width2):
                 caches[i] = o['cache']; got[i][resp].append(o['token']); state[i]['n'] += 1
                 seen[i].append(o['token'])
             rnd_i += 1
-    for i in range(4):
+    assert 9 in forms                      # the talking streams' rows really shared one attention launch (launch_attention_decode_multi)
+    for i in range(n_str):
         assert (got[i][0], got[i][1]) == (ref_ids[i][0], ref_ids[i][1]), i
         assert seen[i] == ref_seen[i]
         assert len(caches[i]) == ref_len[i]
         pr = m.frame_step(probe[None], caches[i], [48])[0]
         assert maxerr(pr, ref_probe[i]) <= 0.06 * max(1.0, ref_probe[i].abs().max().item()), i          # (bf16: the rounds' GEMVs ran over 1 .. 640 rows, other accumulation order)
-    assert len(watcher) == 2 * (98 * 2 + 637)
+    assert len(watcher) == (0 if layout == 'six_together' else 2 * (98 * 2 + 637))
 
 
 def test_per_frame_steps_over_a_long_context_true_width(width2):
