@@ -1274,18 +1274,29 @@ static int llm_step_segs(mmd_ctx* c, const StepSeg* segs, int nseg, const void* 
     // Several streams, each with the same one or two rows (the talking streams of a scheduler round): ONE attention launch for all of them (launch_attention_decode_multi) -- a
     // quarter of the launches, partials and merge work of four per-stream launches whose 64-way key splits each fill the chip alone.  MMDUET_NO_MULTI_ATTN=1: per stream (A/B)
     static const bool no_multi_attn = getenv("MMDUET_NO_MULTI_ATTN") != nullptr;
-    bool multi_attn = fused && nseg > 1 && nseg <= 64 && d == 128 && !no_multi_attn && !dyn && segs[0].rows * (nh / nkv) <= 16 && nseg * nkv <= 256;
-    for (int j = 1; multi_attn && j < nseg; ++j) multi_attn = segs[j].rows == segs[0].rows;
+    // (the longest run of consecutive segments with the same one or two rows: the scheduler puts the talking streams' rows behind the watching streams' chunks)
+    int run0 = 0, run_n = 0;
+    if (nseg > 1 && dt == MMD_BF16 && d == 128 && !no_multi_attn && !dyn && !c->no_fuse && c->attn_ws) {
+        for (int j = 0; j < nseg;) {
+            int k = j + 1;
+            while (k < nseg && segs[k].rows == segs[j].rows) ++k;
+            if (segs[j].rows * (nh / nkv) <= 16 && k - j > run_n) { run0 = j; run_n = k - j; }
+            j = k;
+        }
+        if (run_n < 2 || run_n > 64 || run_n * nkv > 256) run_n = 0;
+    }
+    const bool multi_attn = run_n > 0;
+    const bool all_multi = multi_attn && run_n == nseg;          // every segment of the step is in the run (a round of talking streams only)
     const StepState* seg_states = nullptr;
     if (multi_attn) {
         StepState* hs = c->seg_host + (size_t)c->seg_slot * 64; StepState* ds = c->seg_dev + (size_t)c->seg_slot * 64;
         c->seg_slot = (c->seg_slot + 1) & 7;
-        for (int j = 0; j < nseg; ++j) { hs[j].n_ctx = segs[j].s->len; hs[j].cap = segs[j].s->cap; hs[j].K = segs[j].s->K; hs[j].V = segs[j].s->V; hs[j].n_prev = 0; hs[j].pad = 0; }
-        HIPCHK(c, hipMemcpyAsync(ds, hs, sizeof(StepState) * nseg, hipMemcpyHostToDevice, st));
+        for (int j = 0; j < run_n; ++j) { mmd_stream* sj = segs[run0 + j].s; hs[j].n_ctx = sj->len; hs[j].cap = sj->cap; hs[j].K = sj->K; hs[j].V = sj->V; hs[j].n_prev = 0; hs[j].pad = 0; }
+        HIPCHK(c, hipMemcpyAsync(ds, hs, sizeof(StepState) * run_n, hipMemcpyHostToDevice, st));
         seg_states = ds;
     }
     // rows <= 4, head_dim 128: the attention kernel prepares q / k / v from the qkv slabs itself (AttnArgs::qkv_slabs)
-    const bool rope_fused = (chain || (multi_attn && S <= 16)) && d == 128 && !c->no_rope_fuse;
+    const bool rope_fused = (chain || (fused && all_multi && S <= 16)) && d == 128 && !c->no_rope_fuse;
     if (rope_fused) for (int j = 0; j < nseg; ++j) HIPCHK(c, launch_rope_table((char*)c->rope_tab + (size_t)segs[j].row0 * 64 * 8, segs[j].rows, 64, c->inv_freq, segs[j].s->len, st, dyn));
     // chunks (bf16, head_dim 128): one (cos, sin) table per step and segment, read by the vectorised RoPE + append kernel of every layer; MMDUET_NO_CHUNK_ROPE=1 keeps the scalar kernel
     static const bool no_chunk_rope = getenv("MMDUET_NO_CHUNK_ROPE") != nullptr;
@@ -1342,17 +1353,20 @@ static int llm_step_segs(mmd_ctx* c, const StepSeg* segs, int nseg, const void* 
             }
         }
         if (multi_attn) {
+            const int r0 = segs[run0].row0, rr = segs[run0].rows;
             AttnArgs a; memset(&a, 0, sizeof(a));
-            a.q = c->l_q; a.ldq = (int64_t)nh * d; a.out = c->l_attn; a.ldo = (int64_t)nh * d; a.k_ts = d; a.v_ts = d; a.v_transposed = 1;
-            a.S = segs[0].rows; a.nh = nh; a.nkv = nkv; a.d = d; a.causal = 1; a.batch = 1; a.ws = c->attn_ws; a.ws_bytes = c->attn_bytes; a.layer = i;
-            a.segs = seg_states; a.nseg = nseg;
-            if (rope_fused && splits <= 4) { a.qkv_slabs = c->splitk_ws; a.slab_rows = S; a.n_slabs = splits; a.qkv_bias = L.bqkv; a.rope_tab = c->rope_tab; }
+            a.q = (char*)c->l_q + (size_t)r0 * nh * d * e; a.ldq = (int64_t)nh * d; a.out = (char*)c->l_attn + (size_t)r0 * nh * d * e; a.ldo = (int64_t)nh * d;
+            a.k_ts = d; a.v_ts = d; a.v_transposed = 1;
+            a.S = rr; a.nh = nh; a.nkv = nkv; a.d = d; a.causal = 1; a.batch = 1; a.ws = c->attn_ws; a.ws_bytes = c->attn_bytes; a.layer = i;
+            a.segs = seg_states; a.nseg = run_n;
+            if (fused && rope_fused && splits <= 4) { a.qkv_slabs = c->splitk_ws + (size_t)r0 * c->qkv_w; a.slab_rows = S; a.n_slabs = splits; a.qkv_bias = L.bqkv; a.rope_tab = (char*)c->rope_tab + (size_t)r0 * 64 * 8; }
             double kvb = 0, fl = 0;
-            for (int j = 0; j < nseg; ++j) { const double nk = (double)(segs[j].s->len + segs[j].rows); kvb += 2.0 * nk * nkv * d * e; fl += 4.0 * segs[j].rows * nk * nh * d; }
-            ProfScope ps(c, MMD_K_ATTN_LLM, kvb + 2.0 * S * nh * d * e, fl);
+            for (int j = run0; j < run0 + run_n; ++j) { const double nk = (double)(segs[j].s->len + segs[j].rows); kvb += 2.0 * nk * nkv * d * e; fl += 4.0 * segs[j].rows * nk * nh * d; }
+            ProfScope ps(c, MMD_K_ATTN_LLM, kvb + 2.0 * rr * run_n * nh * d * e, fl);
             HIPCHK(c, launch_attention_decode_multi(a, st));
         }
-        for (int j = 0; j < nseg && !multi_attn; ++j) {
+        for (int j = 0; j < nseg; ++j) {
+            if (multi_attn && j >= run0 && j < run0 + run_n) continue;
             mmd_stream* sj = segs[j].s;
             const size_t le = kv_layer_elems(c, sj->cap);
             const int Sj = segs[j].rows; const int64_t nj = sj->len;

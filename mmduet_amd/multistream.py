@@ -201,6 +201,9 @@ class MultiStreamInfer:
             groups.append(group)
         t0 = time.perf_counter()
         native = hasattr(self.model, 'round_multi') and not self.python_decode
+        if native:
+            # the talking streams' single rows go BEHIND the watching streams' chunks: consecutive equal-row segments share one attention launch per layer
+            groups = [sorted(g, key=lambda r: r.kind == 'generate' and bool(r.gen['ids'])) for g in groups]
         for group in groups:
             tg = time.perf_counter()
             if native:
