@@ -28,6 +28,7 @@ import torch
 
 HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_BF16_PEAK_TF = 2500.0      # dense bf16 MFMA peak
+PMC_CLOCK = ('profiles/r06_pmc_clock.json',)          # tools/pmc_clock.py over the committed SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE pass of this workload
 PMC_TRAFFIC = ('profiles/r05_pmc_traffic.json', 'profiles/history/r04_pmc_traffic.json', 'profiles/history/r03_pmc_traffic.json')      # newest first
 
 CONFIGS = {
@@ -647,6 +648,18 @@ def main():
                 if tr:
                     roof['traffic'] = round(tr['hbm_bytes_per_launch'])
                     roof['traffic_source'] = path
+                    break
+            except Exception:
+                pass
+        # the clock the chip granted and the share of its cycles the matrix pipe was busy (same committed pass; MI355X guide "DVFS give-back": the FLOP fraction of the
+        # 2.4 GHz peak mixes the two) -- not re-measured here
+        for path in PMC_CLOCK:
+            try:
+                ck = json.load(open(os.path.join(ROOT, path))).get(dom)
+                if ck and 'effective_clock_ghz' in ck:
+                    roof['effective_clock_ghz'] = ck['effective_clock_ghz']
+                    roof['mfma_busy_frac_of_cycles'] = ck['mfma_busy_frac_of_cycles']
+                    roof['clock_source'] = path + ' (GRBM_GUI_ACTIVE / 8 XCDs / duration; SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / cycles; frac is quoted against the 2.4 GHz peak)'
                     break
             except Exception:
                 pass

@@ -292,11 +292,12 @@ int mmd_op_rope_append(mmd_ctx* ctx, void* qkv, int S, int nh, int nkv, int d, f
 int mmd_op_attention(mmd_ctx* ctx, const void* q, const void* Kc, const void* Vc, void* out, int S, int nh, int nkv, int d,
                      int64_t n_ctx, int64_t cap, int causal, int variant);
 int mmd_op_attention_bench(mmd_ctx* ctx, int S, int nh, int nkv, int d, int64_t n_ctx, int variant, int iters, float* avg_ms_out);
-/* which attention form the most recent launch of this process took (what mmd_op_gemm_last_plan is for the GEMMs: parity tests assert that the production kernel really
- * ran): 1 one wave per row, 2 16-row MFMA tiles, 3 / 4 attn_gqa128_kernel with 16- / 32-row waves (decode and two-slot forms / 256-row phase-split chunks), 5
- * attn_gqa128_w1_kernel (per-frame steps, short chunks), 6 register-staged row-major (ViT), 7 attn_d72_ring_kernel (SigLIP-so400m), 8 attn_gqa128_chunk_kernel (multi-frame
- * chunks, contiguous decomposition); out2 = {form, key splits or the most blocks sharing a unit} */
-int mmd_op_attention_last_form(int* out2);
+/* which attention form the most recent LLM (or raw-operator) attention launch of THIS context took (what mmd_op_gemm_last_plan is for the GEMMs: parity tests assert that
+ * the production kernel really ran; the tower's launches and other contexts do not disturb it): 1 one wave per row, 2 16-row MFMA tiles, 3 / 4 attn_gqa128_kernel with 16- /
+ * 32-row waves (decode and two-slot forms / 256-row phase-split chunks), 5 attn_gqa128_w1_kernel (per-frame steps, short chunks), 6 register-staged row-major (ViT), 7
+ * attn_d72_ring_kernel (SigLIP-so400m), 8 attn_gqa128_chunk_kernel (multi-frame chunks, contiguous decomposition), 9 the decode rows of several streams in one launch
+ * (mmd_round_multi); out2 = {form, key splits or the most blocks sharing a unit} */
+int mmd_op_attention_last_form(mmd_ctx* ctx, int* out2);
 int mmd_op_pool(mmd_ctx* ctx, const void* x, void* y, int B, int grid, int H, int mode, int stride);
 
 #ifdef __cplusplus

@@ -124,7 +124,7 @@ def main(argv=None):
         local_ids[i] = [[int(t) for t in r] for r in token_ids]
 
     failure = None
-    pf = ClipPrefetcher(load_host, mine, workers=args.num_workers)
+    pf = ClipPrefetcher(load_host, mine, workers=args.num_workers, device=infer.device)
     try:
         with open(out_name, 'w') as f_out:
             if args.streams_per_gpu > 1:
@@ -174,41 +174,60 @@ def main(argv=None):
                             f_out.flush()
                         n += 1
                     cur = nxt if nxt is not None else pf.take()
-    except BaseException as e:          # (world > 1: this rank still joins the collective below with the scores it has, then re-raises -- the other ranks must not hang on it)
-        failure = e
+    except Exception as e:              # (world > 1: this rank still joins the collectives below with the scores it has, then re-raises -- the other ranks must not hang on it.
+        failure = e                     #  KeyboardInterrupt / SystemExit are not caught: the launcher tears the job down)
         if world == 1:
             raise
     finally:
         pf.close()
     if world > 1:
-        # the ONE collective of the path.  n_max is known without communication (deterministic assignment); the longest stream is not (frame counts come from
-        # the clips), so gather_scores precedes the block by its 16-byte shape exchange.  A skipped (unreadable) clip travels as a zero-length stream.
-        n_max, _ = shard_shape(len(data), world)
-        allsc, lens = gather_scores([torch.tensor(local_scores.get(i, []), dtype=torch.float32).view(-1, 2) for i in mine], n_max=n_max)
-        if rank == 0:
-            allsc, lens = allsc.cpu(), lens.cpu()
-            merged = {}
-            for i, ex in enumerate(data):
-                r, slot = i % world, i // world
-                key = str(ex['question_id'])
-                if key in merged:           # duplicate question ids must not collapse silently: later ones carry their dataset index
-                    key = f'{key}#{i}'
-                merged[key] = allsc[r, slot, :int(lens[r, slot])].tolist()
-            with open(f'{args.output_fname}.scores.json', 'w') as f:
-                json.dump(merged, f)
-        # response mode: the generated token ids travel too (their own padded block; skipped on every rank alike when nothing was generated)
-        allids = gather_responses([local_ids.get(i, []) for i in mine], n_max=n_max)
-        if rank == 0 and any(t for w in allids for t in w):
-            ids = {}
-            for i, ex in enumerate(data):
-                key = str(ex['question_id'])
-                ids[key if key not in ids else f'{key}#{i}'] = allids[i % world][i // world]
-            with open(f'{args.output_fname}.responses.json', 'w') as f:
-                json.dump(ids, f)
-        import torch.distributed as dist
-        dist.barrier()
-        if failure is not None:
-            raise failure
+        try:
+            _gather_and_write(args, data, mine, world, rank, local_scores, local_ids, failure, infer.device)
+        finally:
+            if failure is not None:     # the original error wins over anything the collectives raised after it
+                raise failure
+
+
+def _gather_and_write(args, data, mine, world, rank, local_scores, local_ids, failure, device):
+    """The collectives of a multi-rank run; rank 0 writes the merged files.  A rank that failed takes part with what it has and says so: the ranks exchange a failure flag
+    first, and when any is set the merged files carry the suffix `.partial` and list the failed ranks under "__failed_ranks__" (a failed rank's unprocessed clips would
+    otherwise look like unreadable ones: zero-length streams)."""
+    import torch.distributed as dist
+    from .distributed import gather_scores, gather_responses, shard_shape
+    flag = torch.tensor([1 if failure is not None else 0], dtype=torch.int32, device=device if dist.get_backend() == 'nccl' else 'cpu')
+    flags = [torch.zeros_like(flag) for _ in range(world)]
+    dist.all_gather(flags, flag)
+    failed = [r for r, f in enumerate(flags) if int(f.item())]
+    suffix = '.partial' if failed else ''
+    # the ONE collective of the path.  n_max is known without communication (deterministic assignment); the longest stream is not (frame counts come from
+    # the clips), so gather_scores precedes the block by its 16-byte shape exchange.  A skipped (unreadable) clip travels as a zero-length stream.
+    n_max, _ = shard_shape(len(data), world)
+    allsc, lens = gather_scores([torch.tensor(local_scores.get(i, []), dtype=torch.float32).view(-1, 2) for i in mine], n_max=n_max)
+    if rank == 0:
+        allsc, lens = allsc.cpu(), lens.cpu()
+        merged = {}
+        for i, ex in enumerate(data):
+            r, slot = i % world, i // world
+            key = str(ex['question_id'])
+            if key in merged:           # duplicate question ids must not collapse silently: later ones carry their dataset index
+                key = f'{key}#{i}'
+            merged[key] = allsc[r, slot, :int(lens[r, slot])].tolist()
+        if failed:
+            merged['__failed_ranks__'] = failed
+        with open(f'{args.output_fname}.scores.json{suffix}', 'w') as f:
+            json.dump(merged, f)
+    # response mode: the generated token ids travel too (their own padded block; skipped on every rank alike when nothing was generated)
+    allids = gather_responses([local_ids.get(i, []) for i in mine], n_max=n_max)
+    if rank == 0 and any(t for w in allids for t in w):
+        ids = {}
+        for i, ex in enumerate(data):
+            key = str(ex['question_id'])
+            ids[key if key not in ids else f'{key}#{i}'] = allids[i % world][i // world]
+        if failed:
+            ids['__failed_ranks__'] = failed
+        with open(f'{args.output_fname}.responses.json{suffix}', 'w') as f:
+            json.dump(ids, f)
+    dist.barrier()
 
 
 if __name__ == '__main__':

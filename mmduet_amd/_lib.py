@@ -109,7 +109,7 @@ _SIGS = {
     'mmd_op_rope_append': (_I, [_VP, _VP, _I, _I, _I, _I, _F, _I64, _VP, _VP, _VP, _I64]),
     'mmd_op_attention': (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I64, _I64, _I, _I]),
     'mmd_op_attention_bench': (_I, [_VP, _I, _I, _I, _I, _I64, _I, _I, C.POINTER(_F)]),
-    'mmd_op_attention_last_form': (_I, [C.POINTER(_I)]),
+    'mmd_op_attention_last_form': (_I, [_VP, C.POINTER(_I)]),
     'mmd_op_pool': (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _I]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGS)

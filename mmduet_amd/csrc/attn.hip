@@ -36,7 +36,7 @@ struct AttnP {
                         // and arena base in dyn[j] (AttnArgs::segs); partials [seg][split][rows]
 };
 
-static int g_last_form[2] = {0, 0};          // (diagnostic only: which form the most recent launch took, mmd_op_attention_last_form)
+static thread_local int g_last_form[2] = {0, 0};          // (diagnostic only: which form the most recent launch took, mmd_op_attention_last_form)
 
 __device__ __forceinline__ long long v_off(const AttnP& p, long long tok, int e) {
     return p.v_tr ? (((tok >> 6) * p.d + e) << 6) + (tok & 63) : tok * p.v_ts + e;
@@ -1588,7 +1588,7 @@ hipError_t launch_attention_decode_multi(const AttnArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
-extern "C" int mmd_op_attention_last_form(int* out2) { if (!out2) return MMD_EINVAL; out2[0] = g_last_form[0]; out2[1] = g_last_form[1]; return MMD_OK; }
+void attn_last_form(int* out2) { out2[0] = g_last_form[0]; out2[1] = g_last_form[1]; }          // (of the calling thread's most recent launch; model.hip copies it into the context right behind every LLM attention launch)
 static hipError_t launch_attention_(int dtype, const AttnArgs& a, hipStream_t st, AttnP& p);
 hipError_t launch_attention(int dtype, const AttnArgs& a, hipStream_t st) {
     if (a.S <= 0) return hipSuccess;

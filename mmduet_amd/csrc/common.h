@@ -103,8 +103,7 @@ struct StepState { long long n_ctx; long long cap; void* K; void* V; int n_prev;
 enum { EPI_NONE = 0, EPI_GELU_TANH = 1, EPI_GELU_ERF = 2, EPI_RESID = 3, EPI_SWIGLU = 4 };
 enum { GEMM_AUTO = 0, GEMM_GENERIC = 1, GEMM_SKINNY = 2, GEMM_LARGE = 3, GEMM_BIG = 4, GEMM_SLAB = 5, GEMM_RING256 = 6, GEMM_RING256_SPLIT = 7,
        GEMM_RINGX = 16 /* + 1: 4-wave 256x128 blocks, + 2: 32x32x16 MFMA, + 4: split K */,
-       GEMM_STREAM = 8 /* gemm_stream_kernel (32 < M <= 256, slabs or SwiGLU) */,
-       GEMM_RINGW = 200 /* gemm_ringw_kernel (W operand straight to registers): + 0 / 1 = (3,3) / (4,2) ring slots, W buffers; + 4: split K */ };
+       GEMM_STREAM = 8 /* gemm_stream_kernel (32 < M <= 256, slabs or SwiGLU) */ };
 
 // Decode chain of the weight-streaming GEMV (M <= 16, bf16): the residual add + RMSNorm between two GEMVs costs a launch and a cold, dependent
 // load chain of its own (5.5 us + a kernel boundary, twice per layer at decode).  Instead
@@ -147,7 +146,7 @@ struct GemmArgs {
 // which kernel the dispatcher chose (mmd_op_gemm_last_plan; parity tests assert the production kernel really ran)
 enum { GEMM_K_TILE64 = 0, GEMM_K_TILE128 = 1, GEMM_K_SKINNY = 2, GEMM_K_GEMV16 = 3, GEMM_K_BIG64 = 4, GEMM_K_BIG128 = 5, GEMM_K_RING256 = 6, GEMM_K_RING128X2 = 7, GEMM_K_STREAM = 8 };
 bool gemm_can_slab(int dtype, const GemmArgs& a);
-bool gemm_ring_auto(int dtype, const GemmArgs& a);          // would the automatic dispatch run this GEMM on gemm_ringx_kernel (plain or split-K)?  (what a piece-major operand needs)
+bool gemm_ring_auto(int dtype, const GemmArgs& a, bool plain_only = false);          // would the automatic dispatch run this GEMM on gemm_ringx_kernel (plain or split-K; plain_only: not the split-K form)?  (what a piece-major operand needs; a piece-major OUTPUT needs the plain form)
 
 // launchers (dtype = mmd_dtype).  All return hipError_t of the launch.
 hipError_t launch_gemm(int dtype, const GemmArgs& a, hipStream_t st, int* kind_out);
@@ -226,4 +225,5 @@ struct AttnArgs {
     const StepState* segs = nullptr; int nseg = 0;   // launch_attention_decode_multi: the streams' (context length, capacity, arena base), device
 };
 hipError_t launch_attention(int dtype, const AttnArgs& a, hipStream_t st);
+void attn_last_form(int* out2);          // {form, key splits} of the calling thread's most recent launch_attention* (attn.hip)
 hipError_t launch_attention_decode_multi(const AttnArgs& a, hipStream_t st);     // decode rows of a.nseg streams in one launch (attn.hip)

@@ -1241,7 +1241,7 @@ static hipError_t launch_ringx_t(const GemmP& p, const GemmArgs& a, hipStream_t 
     constexpr int BN = 64 * WN;
     const int tiles = cdiv(a.N, BN) * cdiv(a.M, 256);
     const int slots = (WN == 2 && NS == 3) ? 512 : 256;                      // resident blocks: two 4-wave blocks per CU (72 KB rings), else one
-    // ring_max_blocks: > 0 caps the persistent grid (tower share); < 0 (overlap experiments, MMDUET_TOWER_RING_BLOCKS=-1): NON-persistent, one tile per block, so that the
+    // ring_max_blocks: > 0 caps the persistent grid (tower share); < 0 (the overlap experiments of round 4, tools/probes/dropped/overlap_sweep.sh): NON-persistent, one tile per block, so that the
     // dispatcher can place another stream's blocks at every tile end
     const int cap = a.ring_max_blocks < 0 ? tiles : (a.ring_max_blocks > 0 && a.ring_max_blocks < slots ? a.ring_max_blocks : slots);
     dim3 grid(splits > 1 || tiles <= cap ? tiles : cap, 1, splits);
@@ -1339,11 +1339,11 @@ static bool ring256_split_auto(const GemmArgs& a) {
     while (sp > 1 && (size_t)sp * a.M * a.N * sizeof(float) > a.splitk_ws_bytes) --sp;
     return sp >= 2;
 }
-bool gemm_ring_auto(int dtype, const GemmArgs& a) {
+bool gemm_ring_auto(int dtype, const GemmArgs& a, bool plain_only) {
     if (dtype != MMD_BF16 && dtype != MMD_F16) return false;
     GemmArgs b = a; b.f16 = dtype == MMD_F16;
     if (b.variant != GEMM_AUTO || b.wscale) return false;
-    return ring256_auto(b) || ring256_split_auto(b);
+    return ring256_auto(b) || (!plain_only && ring256_split_auto(b));
 }
 template <typename T>
 static hipError_t launch_t(const GemmArgs& a, hipStream_t st, int* kind_out) {
@@ -1361,6 +1361,7 @@ static hipError_t launch_t(const GemmArgs& a, hipStream_t st, int* kind_out) {
     if ((a.x_pm || a.y_pm) && (sizeof(T) != 2 || variant != GEMM_AUTO || !(ring256_auto(a) || ring256_split_auto(a)) || a.wscale ||
                                (a.x_pm && (a.K % 32)) || (a.y_pm && ((a.epi == EPI_SWIGLU ? a.N / 2 : a.N) % 32))))
         return hipErrorInvalidValue;          // a piece-major operand exists for the ring kernel only (the caller asks gemm_ring_auto first)
+    if (a.y_pm && !ring256_auto(a)) return hipErrorInvalidValue;          // ... and a piece-major OUTPUT for its plain form only: the split-K form leaves fp32 slabs and splitk_reduce writes Y row-major
     if constexpr (sizeof(T) == 2) {
         // the weight-streaming regime above the GEMV's 16 rows: per-frame steps, short chunks (gemm_stream_kernel); slab consumers or the SwiGLU epilogue
         if ((variant == GEMM_AUTO || variant == GEMM_SKINNY || variant == GEMM_STREAM) && stream_ok(MMD_BF16, a)) {

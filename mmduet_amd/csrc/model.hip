@@ -86,6 +86,7 @@ struct mmd_ctx {
     StepState* step_dev = nullptr; StepState* step_host = nullptr;
     hipGraphExec_t dec_graph = nullptr; hipGraph_t dec_graph_src = nullptr;
     float dec_pen = 0.f; int64_t dec_eos = 0; bool no_graph = false;
+    int last_form[2] = {0, 0};          // form / splits of the most recent LLM / raw-operator attention launch of THIS context (mmd_op_attention_last_form)
     int last_plan[4] = {-1, 0, 0, 0};   // kernel / tiles / splits / blocks of the most recent gemm() (mmd_op_gemm_last_plan)
     bool no_fuse = false;              // MMDUET_NO_FUSE=1: keep the unfused launch schedule (A/B and parity cross-check)
     bool no_pm = false;                // MMDUET_NO_FUSE=1 | 2: MLP intermediates stay row-major (gemm_pair_pm)
@@ -215,7 +216,7 @@ static bool gemm_pair_pm(mmd_ctx* c, bool tower, const void* X1, int64_t ldx1, c
     a.splitk_ws = tower ? c->v_splitk_ws : c->splitk_ws; a.splitk_ws_bytes = tower ? c->v_splitk_bytes : c->splitk_bytes;
     GemmArgs b = a;
     b.X = T; b.ldx = ldt; b.Wp = W2p; b.bias = nullptr; b.R = R2; b.ldr = ldr2; b.Y = Y2; b.ldy = ldy2; b.N = N2; b.K = (int)ldt; b.epi = epi2;
-    return gemm_ring_auto(dt, a) && gemm_ring_auto(dt, b);
+    return gemm_ring_auto(dt, a, true) && gemm_ring_auto(dt, b);          // (the producer on the PLAIN ring: its split-K form writes row-major through splitk_reduce -- ADVICE r05)
 }
 
 // ---- create / destroy ------------------------------------------------------------------------------------------------
@@ -1363,7 +1364,7 @@ static int llm_step_segs(mmd_ctx* c, const StepSeg* segs, int nseg, const void* 
             double kvb = 0, fl = 0;
             for (int j = run0; j < run0 + run_n; ++j) { const double nk = (double)(segs[j].s->len + segs[j].rows); kvb += 2.0 * nk * nkv * d * e; fl += 4.0 * segs[j].rows * nk * nh * d; }
             ProfScope ps(c, MMD_K_ATTN_LLM, kvb + 2.0 * rr * run_n * nh * d * e, fl);
-            HIPCHK(c, launch_attention_decode_multi(a, st));
+            { const hipError_t le = launch_attention_decode_multi(a, st); attn_last_form(c->last_form); HIPCHK(c, le); }
         }
         for (int j = 0; j < nseg; ++j) {
             if (multi_attn && j >= run0 && j < run0 + run_n) continue;
@@ -1381,7 +1382,7 @@ static int llm_step_segs(mmd_ctx* c, const StepSeg* segs, int nseg, const void* 
             if (rope_fused && splits <= 4) { a.qkv_slabs = c->splitk_ws + (size_t)segs[j].row0 * c->qkv_w; a.slab_rows = S; a.n_slabs = splits; a.qkv_bias = L.bqkv; a.rope_tab = (char*)c->rope_tab + (size_t)segs[j].row0 * 64 * 8; }
             double kvb = 2.0 * (double)(nj + Sj) * nkv * d * e;
             ProfScope ps(c, MMD_K_ATTN_LLM, kvb + 2.0 * Sj * nh * d * e, 4.0 * Sj * (double)(nj + Sj) * nh * d);
-            HIPCHK(c, launch_attention(dt, a, st));
+            { const hipError_t le = launch_attention(dt, a, st); attn_last_form(c->last_form); HIPCHK(c, le); }
         }
         const void* next_norm = (i + 1 < g.num_layers) ? c->L[i + 1].ln1 : c->fnorm;
         void* next_xn = (i + 1 < g.num_layers) ? c->l_xn : c->l_hid;
@@ -1866,6 +1867,7 @@ extern "C" int mmd_op_gemm_pair(mmd_ctx* c, const void* X, const void* W1, const
     dev_free(c, W1p); dev_free(c, W2p); dev_free(c, mid);
     return rc;
 }
+extern "C" int mmd_op_attention_last_form(mmd_ctx* c, int* out2) { if (!c || !out2) return MMD_EINVAL; out2[0] = c->last_form[0]; out2[1] = c->last_form[1]; return MMD_OK; }
 extern "C" int mmd_op_gemm_last_plan(mmd_ctx* c, int* out4) {
     if (!c || !out4) return MMD_EINVAL;
     for (int i = 0; i < 4; ++i) out4[i] = c->last_plan[i];
@@ -1958,6 +1960,7 @@ extern "C" int mmd_op_attention(mmd_ctx* c, const void* q, const void* Kc, const
         a.V = vt; a.v_transposed = 1;
     }
     hipError_t le = launch_attention(c->cfg.dtype, a, c->stream);
+    attn_last_form(c->last_form);
     if (vt) { hipStreamSynchronize(c->stream); dev_free(c, vt); }
     HIPCHK(c, le);
     return MMD_OK;

@@ -30,14 +30,22 @@ class ClipPrefetcher:
     """`take()` returns `(index, load_host(index))` for `indices` IN ORDER (None at the end) while up to `depth` later clips are being loaded by
     `workers` threads; `next_ready()` says whether the next `take()` would return without waiting.  workers = 0 loads inline at `take()` (no prefetch)."""
 
-    def __init__(self, load_host, indices, workers=4, depth=None):
+    def __init__(self, load_host, indices, workers=4, depth=None, device=None):
+        """device: the rank's GPU.  torch's current device is thread-local and starts at 0 in a new thread, so loader threads that pin memory would otherwise open a context
+        (and allocate their page-locked buffers) on GPU 0 from every rank -- each loader thread selects the rank's device first, as torch's own DataLoader pin thread does."""
         self.load_host = load_host
+        self.device = device
         self._todo = collections.deque(indices)
         self.workers = max(0, int(workers))
         self.depth = max(1, int(depth if depth is not None else max(1, self.workers)))
         self._pending = collections.deque()
-        self._pool = ThreadPoolExecutor(max_workers=self.workers, thread_name_prefix='mmduet-clip') if self.workers else None
+        self._pool = ThreadPoolExecutor(max_workers=self.workers, thread_name_prefix='mmduet-clip', initializer=self._init_thread) if self.workers else None
         self._top_up()
+
+    def _init_thread(self):
+        dev = self.device
+        if dev is not None and getattr(dev, 'type', None) == 'cuda' and torch.cuda.is_available():
+            torch.cuda.set_device(dev)
 
     def _top_up(self):
         while self._pool is not None and self._todo and len(self._pending) < self.depth:

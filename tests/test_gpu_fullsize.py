@@ -87,6 +87,7 @@ def _run_oracle(args, oracle, tok, forced, dtype, ids, frames=None, feats=None):
 
 MAX_K, MAX_ABS = 1.5, 2e-2            # max  |ours - fp32| <= MAX_K  x max  |bf16 oracle - fp32| + MAX_ABS
 MEAN_K, MEAN_ABS = 1.15, 2e-3         # mean |ours - fp32| <= MEAN_K x mean |bf16 oracle - fp32| + MEAN_ABS
+EARLY_FRAMES = 26                     # the prefix bench.py's in-run parity check reads (one chunk of the headline schedule)
 
 
 def _check_stream(key, args, model, tok, w32, w16, forced, frames, feats, lg_h, ids_h, kv_h, cache_h, meta, e2e, e2e_bf16=False, max_bound=None):
@@ -118,6 +119,18 @@ def _check_stream(key, args, model, tok, w32, w16, forced, frames, feats, lg_h, 
                            ours_vs_fp32_mean=m_ours, bf16_oracle_vs_fp32_mean=m_ref,
                            worst_frame=int(per_frame.argmax()), last_50_frames_max=per_frame[-50:].max().item(), logit_scale=lg_32.abs().max().item(),
                            fp32_oracle_seconds=round(t32, 1), bf16_oracle_seconds=round(t16, 1))
+    # The early stream by itself (bench.py's in-run check reads the first 26 frames only and came out at 1.29 x the bf16 oracle's mean, above the
+    # stream-long bound, on 104 values).  Every 26-frame window of THIS stream gives the same statistic -- excess_w = mean|ours - fp32| - mean|bf16 oracle - fp32| over the
+    # window's 104 logits -- so the first window is held against the windows' own distribution: it must not stand out from the rest of the stream by more than three
+    # standard deviations of that statistic (a systematic early-stream error -- the prompt prefix, the short-context attention forms -- would; sampling noise does not).
+    if T >= 4 * EARLY_FRAMES:
+        e_o, e_r = (lg_h - lg_32).abs().mean(1), (lg_16 - lg_32).abs().mean(1)          # per frame
+        win_o, win_r = e_o.unfold(0, EARLY_FRAMES, 1).mean(1), e_r.unfold(0, EARLY_FRAMES, 1).mean(1)
+        exc = win_o - win_r
+        ratio = win_o / win_r
+        res['early_stream'] = dict(frames=EARLY_FRAMES, first_window_ours=win_o[0].item(), first_window_bf16_oracle=win_r[0].item(), first_window_ratio=ratio[0].item(),
+                                   windows=int(exc.numel()), excess_mean=exc.mean().item(), excess_std=exc.std().item(), ratio_min=ratio.min().item(),
+                                   ratio_median=ratio.median().item(), ratio_max=ratio.max().item(), first_window_excess_in_sigma=((exc[0] - exc.mean()) / exc.std()).item())
     flat = lambda tf, k: [v for r in tf for v in r[k]]
     if ids_h:
         res['tokens'] = dict(n=len(flat(tf32, 'agree')), equal_fp32_argmax=sum(flat(tf32, 'agree')), equal_bf16_oracle_argmax=sum(flat(tf16, 'agree')),
@@ -148,6 +161,8 @@ def _check_stream(key, args, model, tok, w32, w16, forced, frames, feats, lg_h, 
     if not pooled:
         assert d_ours <= mk * d_ref + ma, res['llm_side']
     assert m_ours <= MEAN_K * m_ref + MEAN_ABS, res['llm_side']
+    if 'early_stream' in res:
+        assert res['early_stream']['first_window_excess_in_sigma'] <= 3.0, res['early_stream']
     if ids_h:
         assert res['tokens']['max_deficit_vs_fp32'] <= 4 * E + 1e-3, res['tokens']
     if e2e and 'bf16_oracle_vs_fp32' in res['end_to_end']:

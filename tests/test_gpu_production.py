@@ -276,6 +276,32 @@ def test_piece_major_intermediate_gives_the_same_bits(ops, name, M, N1, K1, epi1
     assert torch.isfinite(outs[0].float()).all() and err <= 2.4e-2, (name, err)
 
 
+def test_piece_major_is_refused_for_a_split_k_producer(ops):
+    """a producer GEMM on the split-K ring (long K, few 256x256 tiles) leaves fp32 slabs and splitk_reduce writes its output ROW-major -- the pair must not
+    report a piece-major intermediate there (no model pair has such a producer: fc1 has K = 1152, gate_up is SwiGLU; the exported mmd_op_gemm_pair reaches it)."""
+    import ctypes as C
+    from mmduet_amd._lib import lib, check, EPI
+    from mmduet_amd.modeling_live import _ptr
+    dev = ops.dev
+    M, N1, K1, N2 = 1024, 2048, 8192, 12288
+    g = torch.Generator(device=dev).manual_seed(77)
+    X = (torch.randn(M, K1, generator=g, device=dev) * 0.7).to(torch.bfloat16)
+    W1 = (torch.randn(N1, K1, generator=g, device=dev) / math.sqrt(K1)).to(torch.bfloat16)
+    W2 = (torch.randn(N2, N1, generator=g, device=dev) / math.sqrt(N1)).to(torch.bfloat16)
+    outs = []
+    for pm in (1, 0):
+        Y = torch.empty(M, N2, device=dev, dtype=torch.bfloat16)
+        used = C.c_int(-1)
+        ops.m._bind_stream()
+        check(lib().mmd_op_gemm_pair(ops.ctx, _ptr(X), _ptr(W1), None, EPI['none'], _ptr(W2), None, _ptr(Y), M, N1, K1, N2, pm, C.byref(used)), ops.ctx, 'gemm_pair')
+        torch.cuda.synchronize()
+        assert used.value == 0, (pm, used.value)
+        outs.append(Y)
+    assert torch.equal(outs[0], outs[1])
+    ref = (X.float() @ W1.float().T).to(torch.bfloat16).float() @ W2.float().T
+    assert _rel_err(outs[0], ref) <= 2.4e-2
+
+
 # (per-frame steps and short chunks: attn_gqa128_w1_kernel, variant 5 = forced.  1 / 2 / 3 row blocks, blocks whose waves hold 2 / 1 / 0 row tiles, 1 .. 8 key tiles per split,
 #  new positions on tile boundaries, the masked diagonal inside the first / second half tile, a context too short for any split)
 W1_SHAPES = [(49, 15000), (49, 0), (49, 1), (49, 63), (49, 64), (49, 4047), (49, 30000), (24, 15000), (64, 4096), (98, 15000), (109, 8000), (131, 15000), (17, 300), (3, 70001),
@@ -319,14 +345,14 @@ def test_model_steps_take_the_attention_form_meant_for_them(width2):
         out = m(inputs_embeds=x, past_key_values=type(A)(A.arena, 15000))
         torch.cuda.synchronize()
         assert torch.isfinite(out.informative_logits).all()
-        lib().mmd_op_attention_last_form(form)
+        lib().mmd_op_attention_last_form(m._ctx, form)
         assert form[0] == want, (S, list(form))
         if want == 5:
             assert form[1] >= 8                      # key splits: two row blocks x 4 kv heads fill the chip
     B = m.new_cache(initial_tokens=8192)
     check(lib().mmd_kv_debug_set_len(B.arena.h, 1000), m._ctx, 'set_len')
     m(inputs_embeds=(torch.randn(1, 49, m.config.hidden_size, device=m.device) * 0.5).to(torch.bfloat16), past_key_values=type(B)(B.arena, 1000))
-    torch.cuda.synchronize(); lib().mmd_op_attention_last_form(form)
+    torch.cuda.synchronize(); lib().mmd_op_attention_last_form(m._ctx, form)
     assert form[0] == 4                              # under 4096 keys the two-slot form stays (shorter pipeline fill)
 
 
@@ -467,7 +493,7 @@ def test_attention_over_a_million_keys(ops, S, variant, form):
         for h in range(nkv):
             K[h, hot[(j * nkv + h) % 24]] = (qf[r, h * (nh // nkv)] * 1.5).to(torch.bfloat16)          # score ~ 17 against ln(sum of a million e^N(0,1)) ~ 14.3
     o = ops.attention(q, K, V, nh, nkv, d, n_ctx, True, variant)
-    got_form = (C.c_int * 2)(); lib().mmd_op_attention_last_form(got_form)
+    got_form = (C.c_int * 2)(); lib().mmd_op_attention_last_form(ops.ctx, got_form)
     assert got_form[0] == form, list(got_form)
     ref = _ref_attention_rows(q, K, V, nh, nkv, d, n_ctx, rows)
     err = _rel_err(o[torch.as_tensor(rows, device=dev)], ref)
@@ -677,7 +703,7 @@ def test_native_decode_rounds_equal_single_stream_generate_true_width(width2, la
             if rnd_i == 6 and layout != 'six_together':
                 segs.insert(1, dict(x=chunk637, cache=watcher, head_rows=[636])); who.insert(1, None)
             out = m.round_multi(segs)
-            f = (C.c_int * 2)(); lib().mmd_op_attention_last_form(f); forms.add(f[0])
+            f = (C.c_int * 2)(); lib().mmd_op_attention_last_form(m._ctx, f); forms.add(f[0])
             for i, o in zip(who + [None] * (len(segs) - len(who)), out):
                 if i is None:
                     if o['heads'] is not None:
@@ -744,7 +770,7 @@ def test_per_frame_steps_over_a_long_context_true_width(width2):
     for S in [49] * 8 + [98]:
         x = rnd(S)
         out = m(inputs_embeds=x, past_key_values=cache); cache = out.past_key_values
-        torch.cuda.synchronize(); lib().mmd_op_attention_last_form(form)
+        torch.cuda.synchronize(); lib().mmd_op_attention_last_form(m._ctx, form)
         assert form[0] == 5, (S, list(form))
         ref = o32(inputs_embeds=x.float(), past_key_values=oc); oc = ref.past_key_values
         r16 = o16(inputs_embeds=x, past_key_values=oc16); oc16 = r16.past_key_values

@@ -26,5 +26,5 @@ for shape in "49 15000" "1 15000"; do
 done
 tail -n +1 $O/${tag}_shapes.txt $O/${tag}_timing.log $O/${tag}_kernels_*.txt | cut -c1-220
 echo "--- ring form (attn_gqa128_kernel<2,4,8>) forced for rows >= 256" >> $O/${tag}_shapes.txt
-MMDUET_ATTN_CHUNK8_MIN=256 python3 $R/tools/bench_attn.py small 2>&1 | grep "S=  49\|S=  64" >> $O/${tag}_shapes.txt
+python3 $R/tools/bench_attn.py small 2>&1 | grep "S=  49\|S=  64" >> $O/${tag}_shapes.txt
 tail -12 $O/${tag}_shapes.txt

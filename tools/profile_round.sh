@@ -37,9 +37,11 @@ for pass in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY 
   rocprofv3 --kernel-trace --pmc $pass -d $O/pmc_$tag -o p -- $P > $O/${tag}_pmc_$t.log 2>&1
   db=$(ls $O/pmc_$tag/*.db 2>/dev/null | head -1)
   [ -n "$db" ] && python3 $R/tools/pmc_summary.py $db 2>/dev/null > $O/${tag}_pmc_$t.txt
+  [ -n "$db" ] && [ "$t" = "SQ_VALU_MFMA_BUSY_CYCLES" ] && python3 $R/tools/pmc_clock.py $db 2>/dev/null > $O/${tag}_pmc_clock.json          # effective clock + MFMA-busy share of cycles per class / kernel (same dispatches)
   rm -rf $O/pmc_$tag
 done
 python3 $R/tools/pmc_traffic.py $O/${tag}_pmc_FETCH_SIZE.txt $O/${tag}_pmc_WRITE_SIZE.txt > $O/${tag}_pmc_traffic.json 2>> $O/${tag}_bench.err
 python3 $R/tools/bench_gemm.py prod $O/${tag}_gemm_shapes.json auto,big,rx-8w-early,rx-4w-early,ring256-splitK > $O/${tag}_gemm.log 2>&1
+$R/tools/gemm_shapes_clock.sh $tag > $O/${tag}_gemm_shapes_clock.log 2>&1          # -> ${tag}_gemm_shapes_auto.json (per shape: wall, clock, MFMA-busy share)
 ATTN_LIBRARY=0 python3 $R/tools/vit_attn_bench.py 5 2>&1 | grep -E "ViT attention|chunk attention" > $O/${tag}_attention_shapes.txt
 tail -c 1500 $O/${tag}_bench.json
