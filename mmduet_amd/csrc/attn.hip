@@ -1301,6 +1301,12 @@ __global__ __launch_bounds__(256, 2) void attn_rowmajor_kernel(AttnP p) {
 // one independent MFMA between the two it is right (the order of the source: rt 0, rt 1, tail rt 0, tail rt 1).  The barriers below pin exactly that order of the matrix instructions
 // (mask: everything but MFMAs may still cross); tests/test_attn_isa.py checks the distance in the listing.
 #define D72_MFMA_PIN 0x7F6
+// Round 6: the hazard is removed structurally -- the tail's 16-deep MFMA no longer takes the 32-deep MFMA's result as SrcC at all: it accumulates onto ZERO in registers of its own
+// and one v_add_f32 per score register folds it in where the softmax reads the scores (D72_TAIL_SEPARATE 1).  No MFMA of the kernel then reads another MFMA's result of a different
+// depth, in any instruction order; the pin and the ISA test stay as the second line.  0 = the chained form of round 5 (A/B: `make EXTRA=-DD72_TAIL_SEPARATE=0`).
+#ifndef D72_TAIL_SEPARATE
+#define D72_TAIL_SEPARATE 1
+#endif
 template <bool F16>
 __global__ __launch_bounds__(256, 4) void attn_d72_ring_kernel(AttnP p) {
     constexpr int WAVES = 4, RT = 2, NC = 2, DVT = 5, D = 72, KT = 64, NSLOT = 2;
@@ -1405,6 +1411,9 @@ __global__ __launch_bounds__(256, 4) void attn_d72_ring_kernel(AttnP p) {
         for (int h = 0; h < 2; ++h) {
             if (h == 1 && k0 + 32 >= kend) break;          // the second half of the last tile lies wholly behind the keys (729 = 11 tiles + 25 keys): its P is 0, its exponentials -- the limiter of this kernel -- are not computed
             f32x4_t st[RT][2];
+#if D72_TAIL_SEPARATE
+            f32x4_t tt[RT][2];          // dims 64..71 of the scores: their own accumulators (see D72_TAIL_SEPARATE)
+#endif
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) { st[rt][0] = f32x4_t{0, 0, 0, 0}; st[rt][1] = f32x4_t{0, 0, 0, 0}; }
 #pragma unroll
@@ -1423,8 +1432,14 @@ __global__ __launch_bounds__(256, 4) void attn_d72_ring_kernel(AttnP p) {
                 const s16x4_t kt = D72_DBG == 6 ? qt[0] : *reinterpret_cast<const s16x4_t*>(Ks + (h * 32 + t * 16 + lr) * KLD + 64 + ((lr >> 3) & 1) * 8 + lq * 4);
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) {
+#if D72_TAIL_SEPARATE
+                    const f32x4_t z = {0, 0, 0, 0};
+                    if (D72_DBG == 3) { tt[rt][t] = z; tt[rt][t][1] = (float)kt[0]; } else if constexpr (F16) tt[rt][t] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4_t, kt), __builtin_bit_cast(f16x4_t, qt[rt]), z, 0, 0, 0);
+                    else tt[rt][t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kt, qt[rt], z, 0, 0, 0);
+#else
                     if (D72_DBG == 3) { st[rt][t][1] += (float)kt[0]; } else if constexpr (F16) st[rt][t] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4_t, kt), __builtin_bit_cast(f16x4_t, qt[rt]), st[rt][t], 0, 0, 0);
                     else st[rt][t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kt, qt[rt], st[rt][t], 0, 0, 0);
+#endif
                     __builtin_amdgcn_sched_barrier(D72_MFMA_PIN);
                 }
             }
@@ -1435,7 +1450,11 @@ __global__ __launch_bounds__(256, 4) void attn_d72_ring_kernel(AttnP p) {
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
+#if D72_TAIL_SEPARATE
+                    for (int r = 0; r < 4; ++r) sv[t * 4 + r] = st[rt][t][r] + tt[rt][t][r];
+#else
                     for (int r = 0; r < 4; ++r) sv[t * 4 + r] = st[rt][t][r];
+#endif
                 if (need_mask) {                  // wave-uniform: the tile at the end of the keys only
                     int lim = (row_ok[rt] ? kend : 0) - (k0 + h * 32 + lq * 4);
                     asm volatile("" : "+v"(lim));             // (keeps this a BRANCH and the compares inside it: hipcc otherwise evaluates 7 compares + 8 selects per row tile in EVERY tile)

@@ -1331,13 +1331,30 @@ static bool skinny_packed_ok(int dtype, const GemmArgs& a) {
 static bool ring256_auto(const GemmArgs& a) {
     return a.M >= 512 && (a.N % 32) == 0 && big_packed_ok(MMD_BF16, a, 16) && ring_size_ok(a) && ring_tiles_ok((long long)cdiv(a.M, 256) * cdiv(a.N, 256));
 }
-static bool ring256_split_auto(const GemmArgs& a) {
-    if (a.f16 || !(a.M >= 512 && a.K >= 8192 && big_packed_ok(MMD_BF16, a, 16) && (a.N % 32) == 0 && a.epi != EPI_SWIGLU && a.splitk_ws != nullptr && ring_size_ok(a))) return false;
+// K splits of the split-K ring for t256 output tiles.  Up to half a block wave of tiles: as many splits as fit one wave (down_proj of a chunk: 70 tiles x 3).  Between half a
+// wave and the plain ring's threshold (down_proj of several streams' merged chunks: M = 2548 -> 140 tiles, which left 116 CUs idle for the whole K on the plain ring and ran at
+// 0.28 of peak on the 128-row kernel) the split count comes from a small cost model: rounds of 256 blocks x K / sp steps of ~25 ns per unit of K, plus the fp32 slabs' write + read
+// at ~5 TB/s (140 tiles: 3 splits = 420 items in two rounds of K / 3 -- two thirds of the unsplit time).
+static int ring_split_choice(const GemmArgs& a) {
     const int t256 = cdiv(a.M, 256) * cdiv(a.N, 256);
     int sp = 256 / t256; if (sp < 1) sp = 1;
+    if (t256 > 128) {
+        double best = 1e30; int bsp = 1;
+        for (int s = 1; s <= 8; ++s) {
+            if (s > 1 && (a.K / s < 1024 || (size_t)s * a.M * a.N * sizeof(float) > a.splitk_ws_bytes)) break;
+            const double rounds = (double)cdiv(t256 * s, 256);
+            const double cost = rounds * ((double)a.K / s) * 0.025 + (s > 1 ? (double)s * a.M * a.N * 8.0 / 5e6 : 0.0);
+            if (cost < best * 0.97) { best = cost; bsp = s; }          // (a finer split has to buy 3 %)
+        }
+        return bsp;
+    }
     while (sp > 1 && a.K / sp < 1024) --sp;
     while (sp > 1 && (size_t)sp * a.M * a.N * sizeof(float) > a.splitk_ws_bytes) --sp;
-    return sp >= 2;
+    return sp;
+}
+static bool ring256_split_auto(const GemmArgs& a) {
+    if (a.f16 || !(a.M >= 512 && a.K >= 8192 && big_packed_ok(MMD_BF16, a, 16) && (a.N % 32) == 0 && a.epi != EPI_SWIGLU && a.splitk_ws != nullptr && ring_size_ok(a))) return false;
+    return ring_split_choice(a) >= 2;
 }
 bool gemm_ring_auto(int dtype, const GemmArgs& a, bool plain_only) {
     if (dtype != MMD_BF16 && dtype != MMD_F16) return false;
@@ -1402,10 +1419,7 @@ static hipError_t launch_t(const GemmArgs& a, hipStream_t st, int* kind_out) {
         const bool ring_split_ok = big_packed_ok(MMD_BF16, a, 16) && (a.N % 32) == 0 && a.epi != EPI_SWIGLU && a.splitk_ws != nullptr && ring_size_ok(a);
         if (!a.f16 && (variant == GEMM_RING256_SPLIT || (variant == GEMM_AUTO && a.M >= 512 && a.K >= 8192 && ring_split_ok))) {
             if (variant == GEMM_RING256_SPLIT && (!big_packed_ok(MMD_BF16, a, 16) || (a.N % 32) != 0 || !ring_size_ok(a))) return hipErrorInvalidValue;
-            const int t256 = cdiv(a.M, 256) * cdiv(a.N, 256);
-            int sp = 256 / t256; if (sp < 1) sp = 1;
-            while (sp > 1 && a.K / sp < 1024) --sp;
-            while (sp > 1 && (size_t)sp * a.M * a.N * sizeof(float) > a.splitk_ws_bytes) --sp;
+            const int sp = ring_split_choice(a);
             if (variant == GEMM_RING256_SPLIT || sp >= 2) {
                 p.W = a.Wp;
                 if (kind_out) *kind_out = MMD_K_GEMM_TILE;

@@ -586,7 +586,7 @@ static int alloc_workspaces(mmd_ctx* c) {
     WS(c->l_h, (size_t)S * H * e); WS(c->l_xn, (size_t)S * H * e); WS(c->l_qkv, (size_t)S * c->qkv_w * e);
     WS(c->l_q, (size_t)S * g.num_heads * g.head_dim * e); WS(c->l_attn, (size_t)S * g.num_heads * g.head_dim * e);
     WS(c->l_act, (size_t)round_up(S, 16) * g.intermediate_size * e); WS(c->l_hid, (size_t)S * H * e);          // (l_act rows padded to 16: whole pieces in its piece-major form)
-    c->splitk_bytes = (size_t)64 << 20; WS(c->splitk_ws, c->splitk_bytes);
+    c->splitk_bytes = (size_t)(g.max_step_tokens > 2048 ? 192 : 64) << 20; WS(c->splitk_ws, c->splitk_bytes);          // (several streams' merged chunks: three fp32 slabs of a 2548-row down_proj are 110 MB)
     WS(c->chain_ssq, (size_t)GEMV_CHAIN_ROWS * GEMV_SSQ_STRIDE * sizeof(float)); WS(c->rope_tab, (size_t)S * 64 * 2 * sizeof(float));          // (cos, sin) of a step's positions: decode steps and, since round 3, chunks
     c->attn_bytes = (size_t)128 << 20; WS(c->attn_ws, c->attn_bytes);
     WS(c->logits_ws, (size_t)g.vocab_size * sizeof(float));

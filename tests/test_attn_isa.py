@@ -111,6 +111,8 @@ def test_vit_ring_kernel_fits_four_blocks_and_keeps_its_dma_in_flight(attn_isa, 
         prev = mf[k - 1][1]
         pdst = _regs(prev.split(None, 1)[1].split(',')[0])
         assert not (srcc & pdst and 'v_mfma_f32_16x16x32' in prev), f'16-deep MFMA directly behind the 32-deep MFMA that produces its SrcC: {prev} -> {l}'
+        # round 6 (D72_TAIL_SEPARATE): the tail accumulates onto ZERO in registers of its own -- no 16-deep MFMA reads any MFMA's result, whatever the instruction order
+        assert ops_[3].strip() == '0', f'the 16-deep tail MFMA takes a register as SrcC: {l}'
         checked += 1
     assert checked == 8
 

@@ -27,6 +27,33 @@ arena = cache.arena
 out = []
 
 
+def last_form():
+    f = (C.c_int * 2)(); lib().mmd_op_attention_last_form(model._ctx, f)
+    return dict(form=FORMS.get(f[0], str(f[0])), splits_or_shared_blocks=f[1])
+
+
+FORMS = {3: 'attn_gqa128_kernel<1> (decode ring)', 4: 'attn_gqa128_kernel<2> (grid form)', 5: 'attn_gqa128_w1_kernel', 8: 'attn_gqa128_chunk_kernel', 9: 'decode rows of several streams'}
+one_frame = frames[:49]
+one_row = frames[:1]
+
+
+def small_steps(kind):
+    """At the arena's current length: a 49-row frame step (the reference's own schedule, test/inference.py:239) and a decode row, timed (median of 5) and rolled back."""
+    n0 = arena.length()
+    rec = dict(kind=kind, n_ctx=n0)
+    for name, x, rows in (('frame_step_49_rows', one_frame, [48]), ('decode_row', one_row, [0])):
+        ts = []
+        for _ in range(6):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            sc, _c = model.frame_step(x[None], type(cache)(arena, n0), rows)
+            ts.append(time.perf_counter() - t0)
+            assert torch.isfinite(sc).all()
+        rec[name + '_ms'] = round(sorted(ts[1:])[2] * 1e3, 3)
+        rec[name + '_attention'] = last_form()
+    arena.truncate(n0)
+    out.append(rec); print(rec, flush=True)
+
+
 def real_steps(n, kind):
     """n real chunk forwards from the arena's current length; records the first and the last."""
     global cache
@@ -38,16 +65,18 @@ def real_steps(n, kind):
         assert torch.isfinite(sc).all() and arena.length() == n0 + k * 49
         if i in (0, n - 1):
             out.append(dict(kind=kind, n_ctx=n0, kv_GB=round((n0 + k * 49) * 57344 / 1e9, 2), ms_per_26_frames=round(dt * 1e3, 2), llm_frames_per_s=round(k / dt, 1),
-                            tokens_mapped=int(lib().mmd_kv_capacity(arena.h)), row_stride_tokens=int(lib().mmd_kv_stride(arena.h))))
+                            tokens_mapped=int(lib().mmd_kv_capacity(arena.h)), row_stride_tokens=int(lib().mmd_kv_stride(arena.h)), attention=last_form()))
             print(out[-1], flush=True)
 
 
 try:
     real_steps(104, 'real: 0 -> 132 k tokens by forwards, arena growing from 32 k mapped')
-    for mark in (300_000, 1_000_000, 2_000_000, 3_000_000, 4_000_000, 4_500_000):
+    small_steps('per-frame step and decode row at 132 k tokens')
+    for mark in (300_000, 1_000_000, 2_000_000, 2_940_000, 4_000_000, 4_500_000):          # (2.94 M tokens = the 60 k-frame point of SURVEY section 8d config 3)
         start = mark - 4 * k * 49
         check(lib().mmd_kv_debug_set_len(arena.h, start), model._ctx, 'set_len')          # jump (same arena)
         real_steps(8, f'real: forwards across the {mark:,}-token mark (after a jump)')
+        small_steps(f'per-frame step and decode row behind the {mark:,}-token mark')
 except Exception as e:
     out.append(dict(error=str(e)[:200], at_tokens=int(arena.length())))
     print(out[-1], flush=True)

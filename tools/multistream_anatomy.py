@@ -22,6 +22,8 @@ out = {}
 for S, k in cfgs:
     r = bench.MultiRunner(args, model, tok, frames, query, S * per_slot, k)
     r.ms.n_slots = S
+    if os.environ.get('MS_LOOKAHEAD'):
+        r.ms.vit_lookahead_batches = int(os.environ['MS_LOOKAHEAD'])
     r.run(); torch.cuda.synchronize()
     r.ms.round_log = []; r.ms.rounds = 0; r.ms.exec_seconds = 0.0
     t0 = time.perf_counter(); r.run(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
