@@ -560,6 +560,9 @@ extern "C" int mmd_finalize_weights(mmd_ctx* c) {
     return MMD_OK;
 }
 
+// fp32 split-K slab workspace of the LLM side: 64 MB; 192 MB for a model built for several streams' merged chunks (three slabs of a 2548-row down_proj are 110 MB)
+static size_t splitk_ws_size(const mmd_config& g) { return (size_t)(g.max_step_tokens > 2048 ? 192 : 64) << 20; }
+
 static int alloc_workspaces(mmd_ctx* c) {
     const mmd_config& g = c->cfg; const size_t e = es(c);
     const int C = g.vit_hidden, H = g.hidden_size;
@@ -586,7 +589,7 @@ static int alloc_workspaces(mmd_ctx* c) {
     WS(c->l_h, (size_t)S * H * e); WS(c->l_xn, (size_t)S * H * e); WS(c->l_qkv, (size_t)S * c->qkv_w * e);
     WS(c->l_q, (size_t)S * g.num_heads * g.head_dim * e); WS(c->l_attn, (size_t)S * g.num_heads * g.head_dim * e);
     WS(c->l_act, (size_t)round_up(S, 16) * g.intermediate_size * e); WS(c->l_hid, (size_t)S * H * e);          // (l_act rows padded to 16: whole pieces in its piece-major form)
-    c->splitk_bytes = (size_t)(g.max_step_tokens > 2048 ? 192 : 64) << 20; WS(c->splitk_ws, c->splitk_bytes);          // (several streams' merged chunks: three fp32 slabs of a 2548-row down_proj are 110 MB)
+    c->splitk_bytes = splitk_ws_size(g); WS(c->splitk_ws, c->splitk_bytes);
     WS(c->chain_ssq, (size_t)GEMV_CHAIN_ROWS * GEMV_SSQ_STRIDE * sizeof(float)); WS(c->rope_tab, (size_t)S * 64 * 2 * sizeof(float));          // (cos, sin) of a step's positions: decode steps and, since round 3, chunks
     c->attn_bytes = (size_t)128 << 20; WS(c->attn_ws, c->attn_bytes);
     WS(c->logits_ws, (size_t)g.vocab_size * sizeof(float));
@@ -1796,7 +1799,7 @@ extern "C" int mmd_op_gemm(mmd_ctx* c, const void* X, const void* W, const void*
                            int out_f32, int variant) {
     if (!c) return MMD_EINVAL;
     hipSetDevice(c->device);
-    if (!c->splitk_ws) { c->splitk_bytes = (size_t)64 << 20; int rc = dev_alloc(c, (void**)&c->splitk_ws, c->splitk_bytes); if (rc) return rc; }
+    if (!c->splitk_ws) { c->splitk_bytes = splitk_ws_size(c->cfg); int rc = dev_alloc(c, (void**)&c->splitk_ws, c->splitk_bytes); if (rc) return rc; }
     int NO = epi == EPI_SWIGLU ? N / 2 : N;
     void* Wp = nullptr;
     // the model holds every matrix in both layouts (or packed only): give the dispatcher the same choice, variant 0 included
@@ -1837,7 +1840,7 @@ extern "C" int mmd_op_gemm_w8(mmd_ctx* c, const void* X, const void* Wq, const u
     if (!c || !X || !Wq || !q8 || !scale || !Y) return MMD_EINVAL;
     if (c->cfg.dtype != MMD_BF16 || (N % 16) != 0 || (K % 64) != 0) FAIL(c, MMD_EINVAL, "mmd_op_gemm_w8: bf16 context, N %% 16 == 0, K %% 64 == 0");
     hipSetDevice(c->device);
-    if (!c->splitk_ws) { c->splitk_bytes = (size_t)64 << 20; int rc = dev_alloc(c, (void**)&c->splitk_ws, c->splitk_bytes); if (rc) return rc; }
+    if (!c->splitk_ws) { c->splitk_bytes = splitk_ws_size(c->cfg); int rc = dev_alloc(c, (void**)&c->splitk_ws, c->splitk_bytes); if (rc) return rc; }
     void *Wp = nullptr, *Wp8 = nullptr;
     int rc = make_packed(c, Wq, N, K, &Wp); if (rc) return rc;
     rc = dev_alloc(c, &Wp8, (size_t)N * K, false); if (rc) return rc;
@@ -1854,7 +1857,7 @@ extern "C" int mmd_op_gemm_pair(mmd_ctx* c, const void* X, const void* W1, const
                                 int piece_major, int* used_pm_out) {
     if (!c || !X || !W1 || !W2 || !Y) return MMD_EINVAL;
     hipSetDevice(c->device);
-    if (!c->splitk_ws) { c->splitk_bytes = (size_t)64 << 20; int rc = dev_alloc(c, (void**)&c->splitk_ws, c->splitk_bytes); if (rc) return rc; }
+    if (!c->splitk_ws) { c->splitk_bytes = splitk_ws_size(c->cfg); int rc = dev_alloc(c, (void**)&c->splitk_ws, c->splitk_bytes); if (rc) return rc; }
     const int T = epi1 == EPI_SWIGLU ? N1 / 2 : N1;
     void *W1p = nullptr, *W2p = nullptr, *mid = nullptr; int rc;
     if ((rc = make_packed(c, W1, N1, K1, &W1p)) || (rc = make_packed(c, W2, N2, T, &W2p)) || (rc = dev_alloc(c, &mid, (size_t)round_up(M, 16) * T * es(c)))) return rc;
@@ -1877,7 +1880,7 @@ extern "C" int mmd_op_gemm_last_plan(mmd_ctx* c, int* out4) {
 extern "C" int mmd_op_gemm_bench(mmd_ctx* c, int M, int N, int K, int epi, int variant, int iters, float* avg_ms_out, const void* Xin, const void* Win) {
     if (!c || !avg_ms_out || iters <= 0) return MMD_EINVAL;
     hipSetDevice(c->device);
-    if (!c->splitk_ws) { c->splitk_bytes = (size_t)64 << 20; int rc = dev_alloc(c, (void**)&c->splitk_ws, c->splitk_bytes); if (rc) return rc; }
+    if (!c->splitk_ws) { c->splitk_bytes = splitk_ws_size(c->cfg); int rc = dev_alloc(c, (void**)&c->splitk_ws, c->splitk_bytes); if (rc) return rc; }
     const size_t e = es(c);
     int NO = epi == EPI_SWIGLU ? N / 2 : N;
     void *X = nullptr, *W = nullptr, *Y = nullptr, *R = nullptr, *Wp = nullptr;

@@ -8,9 +8,10 @@ from conftest import load_golden_weights
 
 
 class RawOps:
-    def __init__(self, dtype):
+    def __init__(self, dtype, max_step_tokens=64):
+        """max_step_tokens > 2048: the context gets the large (192 MB) split-K slab workspace of a model that runs several streams' merged chunks."""
         cfgd, _ = load_golden_weights('A')
-        self.m = VideoHeadLiveLlavaQwenForCausalLM(product_config(cfgd), torch_dtype=dtype, max_vit_batch=2, max_step_tokens=64, kv_initial_tokens=256)
+        self.m = VideoHeadLiveLlavaQwenForCausalLM(product_config(cfgd), torch_dtype=dtype, max_vit_batch=2, max_step_tokens=max_step_tokens, kv_initial_tokens=256)
         self.ctx, self.dtype, self.dev = self.m._ctx, dtype, self.m.device
 
     def t(self, x):

@@ -113,6 +113,30 @@ def test_production_gemm_shapes_take_the_production_kernel_and_match_fp32(ops, n
         assert plan['kernel'] in RING and plan['splits'] >= expect['min_splits'], plan                                        # automatic split-K over grid.z
 
 
+def test_down_proj_of_merged_chunks_takes_the_split_ring():
+    """Several streams' chunks in one forward (mmduet_amd/multistream.py): down_proj at M = 2548 is 140 output tiles -- over half a block wave, under the plain ring's threshold.
+    The dispatcher splits K three ways there (420 work items in two rounds of K / 3; the 128-row kernel it fell back to ran at 0.28 of peak), given the large slab workspace
+    of a model built for merged chunks.  Against fp32 math; M = 2352 (8 streams x 6 frames) likewise."""
+    from rawops import RawOps
+    ops_big = RawOps(torch.bfloat16, max_step_tokens=4096)
+    dev = ops_big.dev
+    for M in (2548, 2352):
+        N, K = 3584, 18944
+        g = torch.Generator(device=dev).manual_seed(M)
+        X = (torch.randn(M, K, generator=g, device=dev) * 0.7).to(torch.bfloat16)
+        W = (torch.randn(N, K, generator=g, device=dev) / math.sqrt(K)).to(torch.bfloat16)
+        R = torch.randn(M, N, generator=g, device=dev).to(torch.bfloat16)
+        Y = ops_big.gemm(X, W, None, R=R, epi='resid', variant=0)
+        plan = _plan(ops_big)
+        ref = (X.float() @ W.float().T).to(torch.bfloat16).float() + R.float()
+        err = _rel_err(Y, ref)
+        _record(f'gemm_llm_down_merged_M{M}', M=M, N=N, K=K, rel_err=err, **plan)
+        assert plan['kernel'] in RING and plan['splits'] == 3, plan
+        assert torch.isfinite(Y.float()).all() and err <= 2.4e-2, (M, err)
+    del ops_big
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize('variant', [32, 33])
 @pytest.mark.parametrize('name,M,N,K,epi', [('vit_fc1', 25515, 4352, 1152, 'gelu_tanh'), ('vit_o', 25515, 1152, 1152, 'resid'), ('gate_up_tail', 1303, 37888, 3584, 'swiglu'),
                                             ('ragged', 3000, 1184, 704, 'none')])
@@ -581,7 +605,9 @@ def test_vit_ring_attention_repeats_bit_identical_beside_a_copy_stream(width2):
 def test_vit_ring_attention_equals_register_staged_kernel():
     """attn_d72_ring_kernel (K / V by LDS-DMA, row-major V image, 16-deep MFMA for dims 64..71) against attn_rowmajor_kernel<3, 5> (MMDUET_VIT_ATTN_RING=0) inside the
     tower at the true widths: fp16 and bf16 tower, 35 frames (6 query blocks x 16 heads x 35, last key tile 25 of 64) and 3 frames, the pooled output of the sparse last
-    layer (196 query rows over 729 keys) and of the full tower.  Same products, same order outside the matrix instructions -> equal digests."""
+    layer (196 query rows over 729 keys) and of the full tower.  Same products; since round 6 the ring kernel adds the dims 64..71 part of a score with one fp32 v_add behind the
+    64-dim chain (D72_TAIL_SEPARATE: no MFMA reads a different-depth MFMA's result) where the register-staged kernel accumulates it inside the chain -- the same fp32 terms in
+    another order, so the outputs agree to fp32-rounding noise carried through two layers (<= 2 bf16 ulps on a few elements), no longer bit for bit."""
     import subprocess, sys, hashlib
     code = r'''
 import os, sys, json, hashlib, torch
@@ -597,7 +623,7 @@ for tower in ("fp16", "bf16"):
             m.set_full_tower(full)
             y = m.visual_embed(px); torch.cuda.synchronize()
             assert torch.isfinite(y.float()).all()
-            res[f"{tower}_{nf}_{int(full)}"] = hashlib.sha256(y.float().cpu().numpy().tobytes()).hexdigest()
+            res[f"{tower}_{nf}_{int(full)}"] = y.float().cpu().flatten()[::7].tolist()
     m.set_full_tower(False)
     del m, w; torch.cuda.empty_cache()
 print("RES " + json.dumps(res))
@@ -607,8 +633,15 @@ print("RES " + json.dumps(res))
         assert r.returncode == 0, r.stderr[-2000:]
         return json.loads([l for l in r.stdout.splitlines() if l.startswith('RES ')][0][4:])
     ring, staged = run(), run(MMDUET_VIT_ATTN_RING='0')
-    assert len(ring) == 8 and len(set(ring.values())) >= 4
-    assert ring == staged
+    assert len(ring) == 8
+    for k in ring:
+        a, b = torch.tensor(ring[k]), torch.tensor(staged[k])
+        scale = max(1.0, b.abs().max().item())
+        assert (a - b).abs().max().item() <= 2 ** -6 * scale, (k, (a - b).abs().max().item(), scale)           # <= 2 ulps of the bf16 output at its largest magnitude
+        assert (a != b).float().mean().item() <= 0.05, (k, (a != b).float().mean().item())                    # ... and on few elements: the kernels are the same arithmetic
+    # and the ring kernel itself is deterministic
+    again = run()
+    assert all(again[k] == ring[k] for k in ring)
 
 
 def test_chunk_of_26_frames_equals_26_frame_steps_true_width(width2):
