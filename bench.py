@@ -29,7 +29,7 @@ import torch
 HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_BF16_PEAK_TF = 2500.0      # dense bf16 MFMA peak
 PMC_CLOCK = ('profiles/r06_pmc_clock.json',)          # tools/pmc_clock.py over the committed SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE pass of this workload
-PMC_TRAFFIC = ('profiles/r05_pmc_traffic.json', 'profiles/history/r04_pmc_traffic.json', 'profiles/history/r03_pmc_traffic.json')      # newest first
+PMC_TRAFFIC = ('profiles/r06_pmc_traffic.json', 'profiles/history/r05_pmc_traffic.json', 'profiles/history/r04_pmc_traffic.json', 'profiles/history/r03_pmc_traffic.json')      # newest first
 
 CONFIGS = {
     # name: (frames, responses, frames_per_forward, streams_per_gpu, workload text)
@@ -100,7 +100,7 @@ def thread_cpu_times():
 def recorded_parity(args):
     """The second half of BASELINE.json's metric ("resp-head logit delta"): NOT measured by this run -- the recorded result of tests/test_gpu_fullsize.py
     (this workload through the product driver against the fp32 oracle on the GPU, same weights, same frames), copied to profiles/ when the test last ran on an MI355X."""
-    for path in ('profiles/r05_parity_full_size.json', 'profiles/history/r04_parity_full_size.json'):
+    for path in ('profiles/r06_parity_full_size.json', 'profiles/history/r05_parity_full_size.json', 'profiles/history/r04_parity_full_size.json'):
         try:
             rec = json.load(open(os.path.join(ROOT, path))).get(args.config)
             if not rec or rec.get('weights') != ('fp8' if args.weights == 'fp8' else 'bf16'):
@@ -108,7 +108,9 @@ def recorded_parity(args):
             ll, tk = rec['llm_side'], rec.get('tokens', {})
             return {'source': f'{path} (tests/test_gpu_fullsize.py, recorded; not re-measured here)', 'frames': rec['frames'], 'max_abs_vs_fp32_oracle': round(ll['ours_vs_fp32'], 4),
                     'mean_abs_vs_fp32_oracle': round(ll['ours_vs_fp32_mean'], 4), 'bf16_oracle_max_abs_vs_fp32': round(ll['bf16_oracle_vs_fp32'], 4), 'logit_scale': round(ll['logit_scale'], 2),
-                    'response_tokens_equal_fp32_argmax': f"{tk['equal_fp32_argmax']}/{tk['n']}" if tk else None, 'kv_len_equal': rec['kv_len']['ours'] == rec['kv_len']['oracle']}
+                    'response_tokens_equal_fp32_argmax': f"{tk['equal_fp32_argmax']}/{tk['n']}" if tk else None, 'kv_len_equal': rec['kv_len']['ours'] == rec['kv_len']['oracle'],
+                    # the in-run check below reads ONE 26-frame prefix (104 logits): this is that statistic over every 26-frame window of the recorded stream -- the spread it has to be read against
+                    'early_26_frame_windows': ({k: round(v, 4) if isinstance(v, float) else v for k, v in rec['early_stream'].items()} if 'early_stream' in rec else None)}
         except Exception:
             pass
     return None

@@ -17,7 +17,7 @@ Bounds: max |ours - fp32 oracle| <= 1.5 x max |bf16 oracle
 mean |ours - fp32 oracle| <= 1.15 x mean |bf16 oracle - fp32 oracle| + 2e-3 (the mean over all T x 4 head logits is the real evidence; the maximum of
 O(1000) bf16-rounded values is a noisy statistic).  Round 4 adds BASELINE configs[3]'s per-GPU workload (8 concurrent QVH streams in shared forwards,
 plus the 4-stream response-mode leg bench.py reports under `multi_stream`) and one fp32-MODE full-depth run that is held to the north-star 1e-3.
-Measured maxima are written to gpurun_out/parity_full_size.json (copied to profiles/r05_parity_full_size.json).
+Measured maxima are written to gpurun_out/parity_full_size.json (copied to profiles/r06_parity_full_size.json).
 Reference: test/inference.py:276-313 (the loop), models/modeling_live.py:51-77 (generation)."""
 import json, os, random, time
 import pytest

@@ -41,6 +41,6 @@ for S, k in cfgs:
     print(f'== {S} slots x k={k}, {S * per_slot} videos: {fps:.1f} frames/s, wall {dt * 1e3:.0f} ms, {len(log)} rounds, in forwards {r.ms.exec_seconds / dt * 100:.1f} %, replayed {sum(x["replayed_frames"] for x in r.last)}', flush=True)
     for key, c in sorted(cls.items(), key=lambda t: -t[1]['exec_ms'] - t[1]['host_ms']):
         print(f'   {key:10s} n={c["n"]:4d} rows/round={c["rows"] / c["n"]:7.1f} exec {c["exec_ms"]:8.1f} ms ({c["exec_ms"] / c["n"]:6.2f}/round) host-before {c["host_ms"]:7.1f} ms ({c["host_ms"] / c["n"]:5.2f}/round)')
-    out[f'{S}x{k}'] = dict(frames_per_s=round(fps, 1), wall_ms=round(dt * 1e3, 1), rounds=len(log), in_forwards=round(r.ms.exec_seconds / dt, 3), classes={k2: {a: round(b, 2) for a, b in v.items()} for k2, v in cls.items()})
+    out[f'{S}x{k}'] = dict(frames_per_s=round(fps, 1), wall_ms=round(dt * 1e3, 1), rounds=len(log), in_forwards=round(r.ms.exec_seconds / dt, 3), replayed=sum(x['replayed_frames'] for x in r.last), classes={k2: {a: round(b, 2) for a, b in v.items()} for k2, v in cls.items()})
 os.makedirs(os.path.join(R, 'gpurun_out'), exist_ok=True)
 json.dump(out, open(os.path.join(R, 'gpurun_out', 'multistream_anatomy.json'), 'w'), indent=1)
