@@ -261,6 +261,58 @@ class FakeLib:
                 _view(logits_out, n_hid * c.cfg.vocab_size, torch.float32).view(n_hid, -1).copy_(F.linear(rows, c.w['lm_head.weight']).float())
         return 0
 
+    # ---- scheduler rounds with the sampling "on the device" (mmd_sampler_* / mmd_round_multi, include/mmduet.h) -----------------------------------
+    def mmd_sampler_create(self, h, out_ref):
+        out_ref._obj.value = self._new(dict(ctx=_addr(h), tok=0, prev=[], eos=-1, pen=0.0))
+        return 0
+
+    def mmd_sampler_destroy(self, sp):
+        self._objs.pop(_addr(sp), None)
+
+    def mmd_sampler_begin(self, sp, eos, pen, prev, n_prev, max_new):
+        s = self._get(sp)
+        s.update(eos=int(eos), pen=float(pen), prev=[int(prev[i]) for i in range(n_prev)] if pen > 0 else [])
+        return 0
+
+    def mmd_sampler_prev_len(self, sp):
+        return len(self._get(sp)['prev'])
+
+    def mmd_round_multi(self, h, streams, seg_rows, n_segs, seg_embeds, samplers, seg_flags, head_rows, n_head, res, toks):
+        """One merged forward: FEED rows are the embedding of the sampler's last token; SAMPLE segments draw the next token from their last row
+        (models/modeling_live.py:60-72: repetition penalty over the sampler's list, first arg-max, EOS neither fed back nor penalised)."""
+        self._count('mmd_round_multi')
+        c = self._get(h)
+        H = c.cfg.hidden_size
+        hid, at = [], 0
+        for j in range(n_segs):
+            S, fl = int(seg_rows[j]), int(seg_flags[j])
+            sp = self._get(samplers[j]) if fl else None
+            if fl & 1:
+                assert S == 1
+                xin = c.w['model.embed_tokens.weight'][sp['tok']][None].to(c.dtype)
+            else:
+                xin = _view(seg_embeds[j], S * H, c.dtype).view(S, H)
+            hj = self._step(c, self._get(streams[j]), xin)
+            hid.append(hj); at += S
+            toks[j] = -1
+            if fl & 2:
+                scores = F.linear(hj[-1:], c.w['lm_head.weight']).float()[0]
+                if sp['pen'] > 0 and sp['prev']:
+                    idx = torch.as_tensor(sp['prev'], dtype=torch.long)
+                    picked = scores[idx]
+                    scores[idx] = torch.where(picked < 0, picked * sp['pen'], picked / sp['pen'])
+                tok = int(scores.argmax(-1))
+                sp['tok'] = tok
+                if sp['pen'] > 0 and tok != sp['eos']:
+                    sp['prev'].append(tok)
+                toks[j] = tok
+        hid = torch.cat(hid)
+        if n_head:
+            o = self._heads(c, hid[[int(head_rows[i]) for i in range(n_head)]]).reshape(-1).tolist()
+            for i, v in enumerate(o):
+                res[i] = v
+        return 0
+
     def mmd_greedy_generate(self, h, sh, x, S, eos, pen, prev, n_prev_ref, cap, out_ids, max_new, n_out_ref):
         """models/modeling_live.py:51-77: the last token is written, never fed; HF repetition penalty over `prev` (grown in place)."""
         self._count('mmd_greedy_generate')
