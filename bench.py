@@ -658,7 +658,7 @@ def main():
         for path in PMC_CLOCK:
             try:
                 ck = json.load(open(os.path.join(ROOT, path))).get(dom)
-                if ck and 'effective_clock_ghz' in ck:
+                if ck and 'effective_clock_ghz' in ck and ck.get('clock_reliable', True):
                     roof['effective_clock_ghz'] = ck['effective_clock_ghz']
                     roof['mfma_busy_frac_of_cycles'] = ck['mfma_busy_frac_of_cycles']
                     roof['clock_source'] = path + ' (GRBM_GUI_ACTIVE / 8 XCDs / duration; SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / cycles; frac is quoted against the 2.4 GHz peak)'

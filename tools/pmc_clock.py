@@ -41,6 +41,9 @@ def summarise(rows):
     if g > 0:
         cyc = g / XCDS
         out.update(effective_clock_ghz=round(cyc / t, 3), mfma_busy_frac_of_cycles=round(m / SIMDS / cyc, 4))
+        # GRBM_GUI_ACTIVE is sampled around the dispatch, a few microseconds wider than the kernel runs: for kernels of tens of microseconds the quotient reads above the chip's
+        # 2.4 GHz (the window, not the clock); it is a clock only where the kernel is long against that margin
+        out['clock_reliable'] = bool(t / len(rows) >= 100e3)
         w, wa = sum(r['c'].get('SQ_WAVE_CYCLES', 0.0) for r in rows), sum(r['c'].get('SQ_WAIT_ANY', 0.0) for r in rows)
         if w > 0:
             out['wait_any_frac_of_wave_cycles'] = round(wa / w, 3)
