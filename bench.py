@@ -456,14 +456,38 @@ def bench_native336(args):
             'config': {'workload': f'{args.frames}-frame 336px stream, ' + CONFIGS['native336']['text'], 'name': 'native336', 'tower_batch': 32, 'tokens_per_frame_out': 37,
                        'algorithmic_gflop_per_frame': round(gf / 1e9, 1), 'weights': 'random init N(0,0.02), true shape (24 layers)', 'note': 'a separate configuration: never mixed with the 384-px LLaVA path'},
             'roofline': roof, 'cpu_baseline': None}
-    print(json.dumps(line), flush=True)
+    _emit(line)
+
+
+_REAL_STDOUT = None
+
+
+def _quiet_stdout():
+    """The contract is ONE JSON line on stdout.  Native libraries write there too (librccl prints a five-line version banner when its first communicator is created): file
+    descriptor 1 is pointed at stderr for the run and the result line goes to the saved descriptor (_emit)."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def _emit(line):
+    sys.stdout.flush()
+    data = (json.dumps(line) + '\n').encode()
+    if _REAL_STDOUT is None:
+        sys.stdout.buffer.write(data); sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, data)
 
 
 def main():
     args = parse()
     if args.mode == 'vision':
+        _quiet_stdout()
         return bench_native336(args)
-    launch_ranks_if_needed(args)
+    launch_ranks_if_needed(args)          # (the parent of a self-launched multi-rank run leaves its stdout to the ranks)
+    _quiet_stdout()
     torch.set_num_threads(max(1, effective_cpus() // max(1, int(os.environ.get('WORLD_SIZE', '1')))))   # host-side torch ops (and the CPU baseline) use the cores this process really has
     if args.host_sync != 'auto':                            # must precede the first HIP call of the process (so before init_distributed, which initialises the device for RCCL)
         import ctypes
@@ -727,7 +751,7 @@ def main():
         }
         import ctypes
         ctypes.CDLL(None).fflush(None)          # RCCL's banner sits in C stdio's buffer when stdout is a pipe: push it out BEFORE the JSON line
-        print(json.dumps(line), flush=True)
+        _emit(line)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -232,10 +232,12 @@ def _attention(ops, S, nh, nkv, d, n_ctx, causal, variant):
     assert_close(o, ref, ops.dtype, scale=1.5, what=f'attention v{variant}')
 
 
-def test_vit_ring_attention_bits_equal_register_staged_kernel_at_op_level():
+def test_vit_ring_attention_equals_register_staged_kernel_at_op_level():
     """attn_d72_ring_kernel against attn_rowmajor_kernel<3, 5> (MMDUET_VIT_ATTN_RING=0) through the raw attention op, bf16: the tower's shapes (SigLIP 729 x 16 x 72, its
-    196-row last layer over 729 keys) and ragged ends (1 .. 64 keys in the last tile, fewer rows than a block, many heads).  Same products in the same order outside the
-    matrix instructions -> equal bits.  (head_dim 64 -- the secondary towers -- stays on attn_rowmajor_kernel<2, 4>: it already runs four blocks per CU, the ring form
+    196-row last layer over 729 keys) and ragged ends (1 .. 64 keys in the last tile, fewer rows than a block, many heads).  Same products; since round 6 the ring kernel
+    adds the dims 64..71 part of a score with one fp32 v_add behind the 64-dim MFMA chain (D72_TAIL_SEPARATE: no MFMA reads a different-depth MFMA's result) where the
+    register-staged kernel accumulates it inside the chain: the same fp32 terms in another order -> outputs equal to one bf16 ulp on a few elements, and the ring kernel
+    itself bit-reproducible.  (head_dim 64 -- the secondary towers -- stays on attn_rowmajor_kernel<2, 4>: it already runs four blocks per CU, the ring form
     measured 1755-1782 against 1786-1787 frames/s on the native-336 line.)"""
     import subprocess, sys, os, json
     from conftest import ROOT
@@ -251,7 +253,7 @@ for S, nh, d, n_ctx in ((729, 16, 72, 0), (196, 16, 72, 533), (577, 24, 72, 0), 
     q = torch.randn(S, nh * d, generator=g); K = torch.randn(nh, cap, d, generator=g); V = torch.randn(nh, cap, d, generator=g)
     o = ops.attention(q, K.to(ops.dev, ops.dtype), V.to(ops.dev, ops.dtype), nh, nh, d, n_ctx, False, 4)
     assert torch.isfinite(o.float()).all()
-    res[f"{S}_{nh}_{d}_{n_ctx}"] = hashlib.sha256(o.float().cpu().numpy().tobytes()).hexdigest()
+    res[f"{S}_{nh}_{d}_{n_ctx}"] = o.float().cpu().flatten().tolist()
 print("RES " + json.dumps(res))
 '''
     def run(**kw):
@@ -259,7 +261,13 @@ print("RES " + json.dumps(res))
         assert r.returncode == 0, r.stderr[-2000:]
         return json.loads([l for l in r.stdout.splitlines() if l.startswith('RES ')][0][4:])
     ring, staged = run(), run(MMDUET_VIT_ATTN_RING='0')
-    assert len(ring) == 8 and ring == staged
+    assert len(ring) == 8
+    for k in ring:
+        a, b = torch.tensor(ring[k]), torch.tensor(staged[k])
+        assert (a - b).abs().max().item() <= 2 ** -7 * max(1.0, b.abs().max().item()), (k, (a - b).abs().max().item())          # one bf16 ulp at the output's largest magnitude
+        assert (a != b).float().mean().item() <= 0.02, (k, (a != b).float().mean().item())
+    again = run()
+    assert all(again[k] == ring[k] for k in ring)
 
 
 def test_pooling_modes(ops):
