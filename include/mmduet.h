@@ -207,7 +207,7 @@ typedef struct mmd_sampler mmd_sampler;
 #define MMD_SEG_FEED 1
 #define MMD_SEG_SAMPLE 2
 int mmd_sampler_create(mmd_ctx* ctx, mmd_sampler** out);
-void mmd_sampler_destroy(mmd_sampler* sp);
+void mmd_sampler_destroy(mmd_sampler* sp);                /* before mmd_destroy of its context */
 int mmd_sampler_begin(mmd_sampler* sp, int64_t eos_id, float rep_penalty, const int64_t* prev_ids_host, int n_prev, int max_new);
 int mmd_sampler_prev_len(const mmd_sampler* sp);          /* entries of the penalty list that count */
 int mmd_round_multi(mmd_ctx* ctx, mmd_stream* const* streams, const int32_t* seg_rows, int n_segs, const void* const* seg_embeds, mmd_sampler* const* samplers,

@@ -104,6 +104,7 @@ struct mmd_ctx {
     bool no_rope_fuse = false;         // MMDUET_NO_ROPE_FUSE=1: decode steps keep the slab_rope_append launch (A/B)
     float* chain_ssq = 0;              // GemvChain scratch: per-row, per-n-tile sums of squares
     StepState* seg_dev = nullptr; StepState* seg_host = nullptr; int seg_slot = 0;          // per-stream (context, capacity, arena) of a step's batched decode attention: 8 slots of 64, rotated per step
+    hipEvent_t seg_event[8] = {};      // recorded behind a slot's upload: the pinned host slot is rewritten only once that copy has run (steps without a synchronisation may queue up)
     // mmd_round_multi (allocated at its first use): logits of the sampling rows, their gathered hidden rows, the two-stage argmax candidates, the drawn tokens
     float* round_logits = 0; void* round_hidden = 0; void* round_scratch = 0; int64_t* round_toks_dev = 0; int64_t* round_toks_host = 0;
     Prof prof;
@@ -269,6 +270,9 @@ extern "C" void mmd_destroy(mmd_ctx* c) {
     if (c->rows_host) hipHostFree(c->rows_host);
     if (c->tok_host) hipHostFree(c->tok_host);
     if (c->step_host) hipHostFree(c->step_host);
+    if (c->seg_host) hipHostFree(c->seg_host);
+    if (c->round_toks_host) hipHostFree(c->round_toks_host);
+    for (auto& ev : c->seg_event) if (ev) hipEventDestroy(ev);
     if (c->dec_graph) hipGraphExecDestroy(c->dec_graph);
     if (c->dec_graph_src) hipGraphDestroy(c->dec_graph_src);
     hipStreamDestroy(c->own_stream);
@@ -1293,10 +1297,14 @@ static int llm_step_segs(mmd_ctx* c, const StepSeg* segs, int nseg, const void* 
     const bool all_multi = multi_attn && run_n == nseg;          // every segment of the step is in the run (a round of talking streams only)
     const StepState* seg_states = nullptr;
     if (multi_attn) {
-        StepState* hs = c->seg_host + (size_t)c->seg_slot * 64; StepState* ds = c->seg_dev + (size_t)c->seg_slot * 64;
-        c->seg_slot = (c->seg_slot + 1) & 7;
+        const int slot = c->seg_slot;
+        StepState* hs = c->seg_host + (size_t)slot * 64; StepState* ds = c->seg_dev + (size_t)slot * 64;
+        c->seg_slot = (slot + 1) & 7;
+        if (!c->seg_event[slot]) HIPCHK(c, hipEventCreateWithFlags(&c->seg_event[slot], hipEventDisableTiming));
+        else HIPCHK(c, hipEventSynchronize(c->seg_event[slot]));          // (eight steps old: long done unless the caller queues steps without ever synchronising)
         for (int j = 0; j < run_n; ++j) { mmd_stream* sj = segs[run0 + j].s; hs[j].n_ctx = sj->len; hs[j].cap = sj->cap; hs[j].K = sj->K; hs[j].V = sj->V; hs[j].n_prev = 0; hs[j].pad = 0; }
         HIPCHK(c, hipMemcpyAsync(ds, hs, sizeof(StepState) * run_n, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipEventRecord(c->seg_event[slot], st));
         seg_states = ds;
     }
     // rows <= 4, head_dim 128: the attention kernel prepares q / k / v from the qkv slabs itself (AttnArgs::qkv_slabs)

@@ -527,7 +527,7 @@ def test_attention_over_a_million_keys(ops, S, variant, form):
 
 
 # ---- true-width models ---------------------------------------------------------------------------------------------------------------
-def _build(llm_layers, vit_layers, dtype, vocab=2048, max_vit_batch=35, max_step_tokens=1536, seed=3, tower_dtype=None):
+def _build(llm_layers, vit_layers, dtype, vocab=2048, max_vit_batch=35, max_step_tokens=1536, seed=3, tower_dtype=None, weight_dtype=None):
     """(HIP model, oracle weights dict on the device in `dtype`-rounded fp32, oracle config)."""
     from mmduet_amd.configuration_live import VideoHeadLiveLlavaQwenConfig
     from mmduet_amd.modeling_live import VideoHeadLiveLlavaQwenForCausalLM
@@ -537,6 +537,8 @@ def _build(llm_layers, vit_layers, dtype, vocab=2048, max_vit_batch=35, max_step
     ocfg = O.OracleConfig(vocab_size=vocab, num_hidden_layers=llm_layers, vit_layers=vit_layers)
     if tower_dtype:
         pcfg.tower_dtype = tower_dtype
+    if weight_dtype:
+        pcfg.weight_dtype = weight_dtype
     m = VideoHeadLiveLlavaQwenForCausalLM(pcfg, torch_dtype=dtype, max_vit_batch=max_vit_batch, max_step_tokens=max_step_tokens, kv_initial_tokens=4096)
     w = {}
     for name, t in synthetic_weights(pcfg, seed=seed, device=m.device, dtype=dtype, scale='unit'):
@@ -670,8 +672,19 @@ def test_chunk_of_26_frames_equals_26_frame_steps_true_width(width2):
     assert maxerr(chunk, want) < 6e-2 and maxerr(per, want) < 6e-2 and maxerr(chunk, per) < 6e-2
 
 
-@pytest.mark.parametrize('layout', ['four_staggered_with_chunks', 'six_together'])
-def test_native_decode_rounds_equal_single_stream_generate_true_width(width2, layout):
+@pytest.fixture(scope='module')
+def width2_fp8():
+    """true widths, 1 tower layer + 2 decoder layers, fp8-e4m3 decoder weights (BASELINE configs[4])"""
+    m, w, ocfg = _build(2, 1, torch.bfloat16, weight_dtype='fp8_e4m3')
+    yield (m,)
+    del m, w
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize('layout', ['four_staggered_with_chunks', 'six_together', 'four_staggered_with_chunks_fp8', 'six_together_fp8'])
+def test_native_decode_rounds_equal_single_stream_generate_true_width(request, layout):
+    width2 = request.getfixturevalue('width2_fp8' if layout.endswith('_fp8') else 'width2')
+    layout = layout.replace('_fp8', '')
     """mmd_round_multi (several streams per forward, sampling on the device; the multi-stream form of models/modeling_live.py:51-77) against mmd_greedy_generate run
     stream by stream on the same contexts, at true widths in bf16.  The rounds cover the three schedules a round can take: every talking stream's row alone (<= 4 rows:
     the GEMV chain with the q / k / v preparation inside the attention kernel, each stream's rows of the qkv slabs at its row offset), talking rows next to a 98-row
