@@ -116,6 +116,20 @@ def recorded_parity(args):
     return None
 
 
+def recorded_idle():
+    """GPU idle share of a timed-like pass from the committed rocprofv3 kernel trace (tools/gap_trace.sh: union of both HIP streams, no per-launch events) -- the figure
+    `gpu_idle_frac` (every launch bracketed with HIP events, tower inline) is an upper bound of, because the event pairs stretch the pass they measure.  Not re-measured here."""
+    import re
+    for path in ('profiles/r06_gpu_idle_gaps.txt', 'profiles/history/r05_gpu_idle_gaps.txt'):
+        try:
+            m = re.search(r'span ([\d.]+) ms, GPU busy \(union over both streams\) ([\d.]+) ms, idle ([\d.]+) ms = ([\d.]+) %', open(os.path.join(ROOT, path)).read())
+            if m:
+                return {'frac': round(float(m.group(4)) / 100, 4), 'span_ms': float(m.group(1)), 'busy_ms': float(m.group(2)), 'source': path + ' (rocprofv3 --kernel-trace of one timed-like pass of this workload; recorded)'}
+        except Exception:
+            pass
+    return None
+
+
 def measured_parity(args, model, tok, cfg, frames, query, forced, device):
     """The second half of BASELINE.json's metric, MEASURED BY THIS RUN (after the timed region; checker only -- nothing here is timed): a prefix of the timed stream
     (the first `frames_per_forward` frames: the system prompt, the query at t = 0, one full chunk and, for the default workload, the response pinned to frame 21 with the
@@ -739,7 +753,7 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16' if args.weights == 'bf16' else 'fp8_e4m3 weights x bf16 activations',
             'data': 'synthetic', 'rccl_ranks': rccl_ranks,
             'host_cpu_s_per_step': round(host_cpu_s / max(1, args.steps), 3), 'host_sync': args.host_sync, 'host_threads_cpu_s_per_step': [dict(comm=n, cpu_s=c, thread=w) for c, n, w in host_threads if c > 0.005], 'nproc_granted': effective_cpus(), 'nproc_visible': os.cpu_count(),
-            'torch_threads': torch.get_num_threads(), 'gpu_idle_frac': gpu_idle,
+            'torch_threads': torch.get_num_threads(), 'gpu_idle_frac': gpu_idle, 'gpu_idle_frac_kernel_trace': recorded_idle(),
             'config': {'workload': ('tiny-plumbing' if args.tiny else 'llava-onevision-qwen2-7b + siglip-so400m-384') +
                        f', {args.frames}-frame 1fps {R}px stream{"s" if S > 1 else ""} ({S} per GPU), ' + CONFIGS[args.config]['text'],
                        'name': args.config, 'frames_per_forward': args.frames_per_forward, 'streams_per_gpu': S, 'responses_per_stream': int(n_resp),
