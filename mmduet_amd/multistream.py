@@ -39,7 +39,13 @@ class _ModelProxy:
     """What a slot's driver sees as `model`: the real model, except that LLM forwards are posted to the scheduler."""
 
     def __init__(self, real, slot, max_step_tokens):
-        self.__dict__.update(_real=real, _slot=slot, max_step_tokens=max_step_tokens)
+        self.__dict__.update(_real=real, _slot=slot, _rows=max_step_tokens)
+
+    @property
+    def max_step_tokens(self):
+        """Rows this slot's next forward may carry (the driver sizes its frame chunk by it, inference._chunk_size): the slot's fixed share of the step, or -- `dynamic_chunks`
+        -- the share of the streams that are WATCHING right now (the scheduler sets it before it resumes the slot)."""
+        return self._slot.row_cap if self._slot.row_cap else self._rows
 
     def __getattr__(self, name):
         return getattr(self._real, name)
@@ -100,6 +106,7 @@ class _Slot(threading.Thread):
         self.request, self.finished, self.error = None, False, None
         self.driver = None
         self.sampler = None                  # mmd_sampler of this slot (created at its first response)
+        self.row_cap = 0                     # dynamic_chunks: rows this slot's next forward may carry (0 = the fixed share)
 
     # -- called on the slot's thread ---------------------------------------------------------------------------------
     def post(self, request):
@@ -160,7 +167,7 @@ class MultiStreamInfer:
     LiveTestArguments, driver_attrs=optional dict set on the video's driver); returns, in input order, dict(responses,
     debug_data, response_token_ids, generated_token_ids, final_kv_len, forward_calls, replayed_frames) per video."""
 
-    def __init__(self, args, model=None, tokenizer=None, n_slots=4, driver_cls=LiveInferForBenchmark, vit_lookahead_batches=2):
+    def __init__(self, args, model=None, tokenizer=None, n_slots=4, driver_cls=LiveInferForBenchmark, vit_lookahead_batches=2, dynamic_chunks=False, max_chunk_frames=39):
         if n_slots < 1:
             raise ValueError('n_slots must be >= 1')
         if model is None:
@@ -170,6 +177,12 @@ class MultiStreamInfer:
         self.args, self.driver_cls = args, driver_cls
         self.vit_lookahead_batches = vit_lookahead_batches
         self.per_slot_rows = max(256, model.max_step_tokens // n_slots)
+        # dynamic_chunks: while some streams talk (one row each) the streams that watch take their share of the step as well -- frames_per_forward x n_slots / n_watching frames
+        # per forward, at most max_chunk_frames.  A merged forward costs ~8 ms + 11 us per row (weights streamed once, one launch set): the fewer, fuller rounds the watchers
+        # need, the more of a response's 32 rounds are the cheap all-talking kind; against it stands the replay of a chunk's tail behind a response, which grows with the chunk.
+        self.dynamic_chunks = bool(dynamic_chunks)
+        self.max_chunk_frames = int(max_chunk_frames)
+        self.base_frames = max(1, int(getattr(args, 'frames_per_forward', 1) or 1))
         self.keep_drivers = False             # True: a finished video's driver (and its KV handle) stays reachable as slot.driver (tests that read the arena afterwards)
         self.rounds = self.merged_rows = 0
         self.round_log = None                 # set to a list to record (kinds, rows, t_start, t_end) per merged forward (kinds: one letter per segment, f / a / d)
@@ -180,6 +193,9 @@ class MultiStreamInfer:
 
     def _make_driver(self, slot, args):
         d = self.driver_cls(args, model=_ModelProxy(self.model, slot, self.per_slot_rows), tokenizer=self.tokenizer)
+        if self.dynamic_chunks:
+            d.frames_per_forward = max(d.frames_per_forward, self.max_chunk_frames)          # the cap now comes from the slot's row share (`_ModelProxy.max_step_tokens`)
+            slot.row_cap = self._row_cap(self.n_slots)
         if getattr(d, 'overlap_vision', False):
             # ONE tower stream for all slots (the tower's workspace is per context), batches issued just ahead of their use
             if self._vit_stream is None and self.model.device.type == 'cuda':
@@ -187,6 +203,13 @@ class MultiStreamInfer:
             d._vit_stream = self._vit_stream
             d.vit_lookahead_batches = self.vit_lookahead_batches
         return d
+
+    def _row_cap(self, n_watching):
+        """Rows a watching slot may post when n_watching streams watch: the step's frame budget (base frames x slots) dealt to the watchers, capped; + room for a text prefix."""
+        nt = int(getattr(self.model.config, 'frame_num_tokens', 49) or 49)
+        k = min(self.max_chunk_frames, max(self.base_frames, (self.base_frames * self.n_slots) // max(1, n_watching)))
+        k = min(k, max(1, (self.model.max_step_tokens - 128 * max(1, n_watching) - self.n_slots) // (nt * max(1, n_watching))))
+        return 128 + nt * k
 
     def _execute(self, requests):
         """Merge the parked requests into as few multi-stream forwards as the row budget allows."""
@@ -306,9 +329,11 @@ class MultiStreamInfer:
             if not running:
                 break
             self._execute([s.request for s in running])
+            talking = lambda s: s.request is not None and s.request.kind == 'generate' and s.request.result is None and not s.request.gen.get('done')
             for s in running:                  # strictly one thread at a time: resume, wait until it parks again or ends
-                rq = s.request
-                if rq is not None and rq.kind == 'generate' and rq.result is None and not rq.gen.get('done'):
+                if talking(s):
                     continue                   # mid-response: the slot stays parked, the scheduler feeds its next token itself
+                if self.dynamic_chunks:        # (slots resumed before this one have posted already: the ones that started a response count as talking)
+                    s.row_cap = self._row_cap(sum(1 for o in running if not o.finished and not (o.request is not None and o.request.kind == 'generate' and o.request.result is None)))
                 s.go.release(); self.parked.acquire()
         return self.results

@@ -22,6 +22,8 @@ out = {}
 for S, k in cfgs:
     r = bench.MultiRunner(args, model, tok, frames, query, S * per_slot, k)
     r.ms.n_slots = S
+    if os.environ.get('MS_DYNAMIC'):
+        r.ms.dynamic_chunks = True; r.ms.max_chunk_frames = int(os.environ['MS_DYNAMIC'])
     if os.environ.get('MS_LOOKAHEAD'):
         r.ms.vit_lookahead_batches = int(os.environ['MS_LOOKAHEAD'])
     r.run(); torch.cuda.synchronize()
