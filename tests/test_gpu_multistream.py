@@ -83,3 +83,34 @@ def test_multi_step_equals_separate_calls(model_f32):
     torch.testing.assert_close(r2.hidden_states, r1.hidden_states, atol=2e-5, rtol=1e-5)
     with pytest.raises(ValueError):
         m.multi_step([dict(x=xa, cache=out[1]['cache']), dict(x=xb, cache=out[1]['cache'])])      # one arena twice
+
+
+def test_round_multi_rejects_misuse_and_matches_multi_step(model_f32):
+    """mmd_round_multi: the plain part (rows + heads) equals mmd_frame_step_multi; a FEED segment must be one row with a sampler of this context, a sampler may sample once
+    per round, an arena may appear once; the error leaves the arenas untouched."""
+    from mmduet_amd._lib import MmduetError
+    m = model_f32
+    H = m.config.hidden_size
+    g = torch.Generator().manual_seed(9)
+    xa, xb = (torch.randn(n, H, generator=g).cuda() * 0.3 for n in (9, 5))
+    ca = m(inputs_embeds=xa[None]).past_key_values; cb = m(inputs_embeds=xb[None]).past_key_values
+    ya, yb = (torch.randn(n, H, generator=g).cuda() * 0.3 for n in (6, 3))
+    ref = m.multi_step([dict(x=ya, cache=m.cache_prefix(ca, 9), head_rows=[2, 5]), dict(x=yb, cache=m.cache_prefix(cb, 5), head_rows=[2], hidden='last')])
+    smp = m.new_sampler(); smp.begin(-1, None, None, 4)
+    out = m.round_multi([dict(x=ya, cache=m.cache_prefix(ca, 9), head_rows=[2, 5]), dict(x=yb, cache=m.cache_prefix(cb, 5), head_rows=[2], sampler=smp, sample=True)])
+    torch.testing.assert_close(out[0]['heads'], ref[0]['heads'], atol=2e-5, rtol=1e-5)
+    torch.testing.assert_close(out[1]['heads'], ref[1]['heads'], atol=2e-5, rtol=1e-5)
+    assert out[1]['token'] == int(ref[1]['logits'][0].argmax()) and out[0]['token'] is None
+    assert [len(o['cache']) for o in out] == [15, 8]
+    # the next round feeds the drawn token: equal to embedding it by hand
+    nxt = m.round_multi([dict(x=None, cache=out[1]['cache'], sampler=smp, feed=True, sample=True)])
+    by_hand = m(inputs_embeds=m.get_input_embeddings()(torch.tensor([[out[1]['token']]], device=m.device)).view(1, 1, H), past_key_values=m.cache_prefix(out[1]['cache'], 8))
+    assert nxt[0]['token'] == int(by_hand.logits[0, -1].argmax()) and len(nxt[0]['cache']) == 9
+    la, lb = len(out[0]['cache']), len(nxt[0]['cache'])
+    with pytest.raises(MmduetError):          # feed without a sampler
+        m.round_multi([dict(x=None, cache=out[0]['cache'], feed=True)])
+    with pytest.raises(MmduetError):          # one sampler sampling twice in a round
+        m.round_multi([dict(x=ya, cache=m.cache_prefix(out[0]['cache'], la), sampler=smp, sample=True), dict(x=yb, cache=m.cache_prefix(nxt[0]['cache'], lb), sampler=smp, sample=True)])
+    with pytest.raises(ValueError):           # one arena twice
+        m.round_multi([dict(x=ya, cache=out[0]['cache']), dict(x=yb, cache=out[0]['cache'])])
+    assert out[0]['cache'].arena.length() == la and nxt[0]['cache'].arena.length() == lb
