@@ -185,7 +185,7 @@ class MultiStreamInfer:
         self.base_frames = max(1, int(getattr(args, 'frames_per_forward', 1) or 1))
         self.keep_drivers = False             # True: a finished video's driver (and its KV handle) stays reachable as slot.driver (tests that read the arena afterwards)
         self.rounds = self.merged_rows = 0
-        self.round_log = None                 # set to a list to record (kinds, rows, t_start, t_end) per merged forward (kinds: one letter per segment, f / a / d)
+        self.round_log = None                 # set to a list to record (kinds, rows, t_start, t_end) per merged forward (kinds: one letter per segment: f = frame chunk, f of 'forward' = query turn, g = a talking stream's row(s), d = a decode row of the python_decode loop)
         self.exec_seconds = 0.0               # time inside the merged forwards (launch + the one sync), the rest is driver host work
         self.python_decode = False            # True: responses decode through per-token Python (logits tensor, host arg-max, embedding call per slot and token) -- the
                                               # round-5 form, kept as the cross-check of the native rounds and for duck-typed models without `round_multi`
@@ -293,8 +293,8 @@ class MultiStreamInfer:
                 r.result = dict(heads=o['heads'], cache=o['cache'])
 
     def _round_with_hidden(self, group, segs):
-        """A round that contains a 'forward' request (all hidden rows of a query turn wanted): the forwards go through multi_step; talking streams sit the round out
-        (their requests stay posted)."""
+        """A round that contains a 'forward' request (all hidden rows of a query turn wanted -- lazy logits): the watching streams' rows go through multi_step, which
+        returns hidden states; the talking streams' rows follow in a round of their own."""
         out = [None] * len(group)
         idx = [i for i, r in enumerate(group) if r.kind != 'generate']
         res = self.model.multi_step([dict(x=group[i].x, cache=group[i].cache, head_rows=group[i].head_rows, hidden='all' if group[i].kind == 'forward' else 'none') for i in idx],
