@@ -8,7 +8,7 @@ cfgs = [(int(a), int(b)) for a, b in (x.split('x') for x in (sys.argv[1] if len(
 per_slot = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 phase_b = len(sys.argv) > 3 and sys.argv[3] == 'b'          # Phase B alone: the frame embeddings are computed once up front and handed over as features (no tower in the timed pass)
 sys.argv = [sys.argv[0]]
-args = bench.parse()
+args = bench.parse(['--weights', os.environ['MS_WEIGHTS']] if os.environ.get('MS_WEIGHTS') else [])          # MS_WEIGHTS=fp8: e4m3 decoder weights (BASELINE configs[4])
 args.multi_stream, args.multi_frames_per_forward = max(((s, k) for s, k in cfgs), key=lambda t: t[0] * (t[1] * 49 + 192))
 dev = torch.device('cuda', 0)
 model, tok, cfg = bench.build(args, dev)
