@@ -17,6 +17,7 @@ for s in 1 2 4 8; do
   $B --config qvh --streams-per-gpu $s --steps 2 --warmup 1 --multi-stream 0 --no-cpu-baseline > $O/${tag}_bench_qvh_s$s.json 2>> $O/${tag}_bench.err
 done
 $B --config youcook2 --steps 2 --warmup 1 --multi-stream 0 --no-cpu-baseline > $O/${tag}_bench_youcook2_fp8.json 2>> $O/${tag}_bench.err
+$B --config youcook2 --streams-per-gpu 4 --steps 1 --warmup 1 --multi-stream 0 --no-cpu-baseline > $O/${tag}_bench_youcook2_fp8_s4.json 2>> $O/${tag}_bench.err
 $B --config youcook2 --weights bf16 --steps 2 --warmup 1 --multi-stream 0 --no-cpu-baseline > $O/${tag}_bench_youcook2_bf16ref.json 2>> $O/${tag}_bench.err
 $B --weights fp8 --steps 3 --warmup 1 --multi-stream 0 --no-cpu-baseline > $O/${tag}_bench_stream300_fp8.json 2>> $O/${tag}_bench.err
 $B --phase b --steps 3 --warmup 1 --multi-stream 0 --no-cpu-baseline > $O/${tag}_bench_phase_b.json 2>> $O/${tag}_bench.err
