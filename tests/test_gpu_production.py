@@ -797,6 +797,46 @@ def test_native_decode_rounds_equal_single_stream_generate_true_width(request, l
     assert len(watcher) == (0 if layout == 'six_together' else 2 * (98 * 2 + 637))
 
 
+def test_batched_decode_attention_repeats_bit_identical_beside_a_copy_stream(width2):
+    """Race screen of launch_attention_decode_multi (the decode ring kernel with grid.x = stream: per-stream context / arena from a device table, partials [stream][split][rows],
+    each stream's q / k / v prepared from its rows of the shared qkv slabs, the new K / V rows appended by the block whose key range holds the position): the same four-stream
+    decode round -- GEMV chain, 4 rows -- and the same six-stream round (slab schedule) from the same state, 40 times beside a copy stream: the same bits in every hidden row."""
+    import ctypes as C
+    from mmduet_amd._lib import lib
+    m = width2[0]
+    H = m.config.hidden_size
+    g = torch.Generator(device=m.device).manual_seed(31)
+    rnd = lambda n: (torch.randn(n, H, generator=g, device=m.device) * 0.5).to(torch.bfloat16)
+    lens = [5000, 700, 64, 1200, 4100, 333]
+    caches = []
+    for n in lens:
+        c = None
+        x = rnd(n)
+        for s0 in range(0, n, 1024):
+            c = m(inputs_embeds=x[None, s0:s0 + 1024], past_key_values=c).past_key_values
+        caches.append(c)
+    rows = [rnd(1) for _ in lens]
+    noise = torch.empty(256 << 20, dtype=torch.uint8, device=m.device)
+    side = torch.cuda.Stream()
+    form = (C.c_int * 2)()
+    for n_str in (4, 6):
+        first = None
+        for r in range(40):
+            if r % 3 == 0:
+                with torch.cuda.stream(side):
+                    noise[:128 << 20].copy_(noise[128 << 20:], non_blocking=True)
+            out = m.multi_step([dict(x=rows[i], cache=m.cache_prefix(caches[i], lens[i]), hidden='all') for i in range(n_str)], want_logits=False)
+            hid = torch.cat([o['hidden'] for o in out]).clone()
+            lib().mmd_op_attention_last_form(m._ctx, form)
+            assert form[0] == 9, list(form)
+            assert torch.isfinite(hid.float()).all()
+            if first is None:
+                first = hid
+            else:
+                assert torch.equal(hid, first), (n_str, r)
+    torch.cuda.synchronize()
+
+
 def test_per_frame_steps_over_a_long_context_true_width(width2):
     """The reference's own schedule -- ONE frame per forward (test/inference.py:221-246) -- deep into a stream: three 1372-row chunks build a 4.1 k-token context, then eight
     49-row frame steps and a 98-row step run on attn_gqa128_w1_kernel (asserted), against the fp32 oracle fed the same inputs; the bf16 oracle (the reference's eager rounding
