@@ -54,6 +54,48 @@ def test_gather_scores_world2_gloo(tmp_path):
     assert sorted(bal[0] + bal[1]) == [0, 1, 2, 3, 4] and abs(sum([5, 9, 3, 7, 4][i] for i in bal[0]) - 14) <= 2
 
 
+FAIL_WORKER = r'''
+import os, sys, json, types, torch
+sys.path.insert(0, os.environ["MMD_ROOT"])
+from mmduet_amd.distributed import init_distributed, shard_indices
+from mmduet_amd.__main__ import _gather_and_write
+import torch.distributed as dist
+rank, world, local = init_distributed(backend="gloo")
+data = [{"question_id": f"q{i}"} for i in range(5)]
+mine = shard_indices(len(data), rank, world)
+done = mine if rank == 0 else mine[:1]          # rank 1 "fails" after its first clip
+scores = {i: [[0.25 + i, 0.5]] * (3 + i) for i in done}
+ids = {i: [[7, 8, 9 + i]] for i in done}
+args = types.SimpleNamespace(output_fname=os.environ["OUT"])
+_gather_and_write(args, data, mine, world, rank, scores, ids, RuntimeError("device fault") if rank == 1 else None, torch.device("cpu"))
+print("RESULT ok", flush=True)
+dist.destroy_process_group()
+'''
+
+
+def test_failed_rank_joins_the_collectives_and_the_files_say_partial(tmp_path):
+    """ADVICE r05: a rank that failed still takes part in the gathers (the other ranks must not hang) -- but the merged files then carry the suffix `.partial` and name the
+    failed ranks, so its unprocessed clips (zero-length streams) cannot be mistaken for unreadable ones."""
+    script = tmp_path / 'worker.py'
+    script.write_text(FAIL_WORKER)
+    port = _free_port()
+    out = str(tmp_path / 'run.jsonl')
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', LOCAL_RANK=str(r), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), MMD_ROOT=ROOT, OUT=out)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    for p in procs:
+        o, e = p.communicate(timeout=180)
+        assert p.returncode == 0 and 'RESULT ok' in o, e[-2000:]
+    assert not os.path.exists(out + '.scores.json')
+    sc = json.load(open(out + '.scores.json.partial'))
+    assert sc['__failed_ranks__'] == [1]
+    assert len(sc['q0']) == 3 and len(sc['q2']) == 5 and len(sc['q4']) == 7          # rank 0's clips complete
+    assert len(sc['q1']) == 4 and sc['q3'] == []                                       # rank 1: one clip done, one never reached
+    ids = json.load(open(out + '.responses.json.partial'))
+    assert ids['__failed_ranks__'] == [1] and ids['q0'] == [[7, 8, 9]] and ids['q3'] == []
+
+
 def test_single_process_gather_is_local():
     import torch
     from mmduet_amd.distributed import gather_scores, shard_indices
