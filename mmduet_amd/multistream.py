@@ -22,6 +22,9 @@ from .inference import LiveInferForBenchmark
 from .modeling_live import VideoHeadCausalLMOutputWithPast
 
 
+MAX_TALKERS_PER_ROUND = 32          # mmd_round_multi samples for at most 32 streams per forward (include/mmduet.h); more talking slots than that are dealt over two forwards
+
+
 class _Request:
     __slots__ = ('kind', 'x', 'cache', 'head_rows', 'result', 'gen')
 
@@ -214,12 +217,13 @@ class MultiStreamInfer:
     def _execute(self, requests):
         """Merge the parked requests into as few multi-stream forwards as the row budget allows."""
         budget = self.model.max_step_tokens
-        group, rows = [], 0
+        group, rows, talkers = [], 0, 0
         groups = []
         for r in requests:
-            if group and rows + r.rows > budget:
-                groups.append(group); group, rows = [], 0
-            group.append(r); rows += r.rows
+            t = 1 if r.kind == 'generate' else 0
+            if group and (rows + r.rows > budget or talkers + t > MAX_TALKERS_PER_ROUND):
+                groups.append(group); group, rows, talkers = [], 0, 0
+            group.append(r); rows += r.rows; talkers += t
         if group:
             groups.append(group)
         t0 = time.perf_counter()
